@@ -1,0 +1,160 @@
+"""Arithmetic contract shared by the oracle and (restated in HIP) by the kernels.
+
+TEST INFRASTRUCTURE ONLY -- nothing under ``bliss_gnn_amd/`` may import this.
+
+The reference keeps every value tensor in bfloat16 (``load_graph.py:7``,
+``bandit_sampler.py:24,343``) and performs its reductions inside DGL
+(``dgl.ops.copy_e_sum`` at ``bandit_sampler.py:67,73,129,150,151,316``).  DGL is
+absent from this image, so the order in which DGL adds the terms of such a sum
+cannot be observed ("parity unpinned").  The contract used
+by BOTH sides of every parity test is therefore the order-independent ideal:
+
+  * an element-wise op reads bf16, computes in fp32 (IEEE, correctly rounded
+    ``+ - * / sqrt``) and rounds ONCE to bf16 with round-to-nearest-even.  That
+    is exactly what torch's CPU kernels do for bf16 tensors, so the oracle
+    simply calls torch for those;
+  * a segment reduction adds its bf16 terms EXACTLY (as integers, in a fixed
+    point format given per call site) and rounds the exact sum once to bf16.
+    Integer addition commutes, so any schedule on any number of GPUs gives the
+    same bits.
+
+Fixed-point formats (value = integer * 2**-frac):
+  FRAC_DST = 40   per-destination sums of weights / probabilities
+  FRAC_SRC = 44   per-source sum of squared normalised probabilities
+  FRAC_BLK = 36   per-destination sum of Hajek weights inside a block
+A bf16 term whose least significant mantissa bit lies below 2**-frac is
+truncated toward zero (never happens for in-degrees < ~2**18).
+"""
+import numpy as np
+import torch
+
+FRAC_DST = 40
+FRAC_SRC = 44
+FRAC_BLK = 36
+
+
+def bf16_bits(x: torch.Tensor) -> torch.Tensor:
+    """bf16 tensor -> int64 tensor holding the 16 raw bits (0..65535)."""
+    assert x.dtype == torch.bfloat16
+    return x.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+
+
+def bits_to_bf16(bits: torch.Tensor) -> torch.Tensor:
+    b = (bits & 0xFFFF).to(torch.int64)
+    b = torch.where(b >= 32768, b - 65536, b).to(torch.int16)
+    return b.view(torch.bfloat16)
+
+
+def bf16_to_fixed(x: torch.Tensor, frac: int) -> torch.Tensor:
+    """Exact (truncating below 2**-frac) bf16 -> signed int64 fixed point.
+
+    Non-finite inputs are not representable: they raise, and the HIP side sets
+    its error flag for them (tests cover both)."""
+    bits = bf16_bits(x)
+    sign = bits >> 15
+    exp = (bits >> 7) & 0xFF
+    man = bits & 0x7F
+    if bool((exp == 255).any()):
+        raise FloatingPointError("non-finite bf16 term in an exact reduction")
+    m = torch.where(exp == 0, man, man | 0x80)
+    e = torch.where(exp == 0, torch.ones_like(exp), exp)  # subnormals share exponent 1
+    shift = e - 134 + frac                                # value = m * 2**(e-134)
+    if bool((shift > 55).any()):
+        raise OverflowError("bf16 term too large for the fixed-point format")
+    left = m << shift.clamp(min=0)
+    right = m >> (-shift).clamp(min=0, max=63)
+    mag = torch.where(shift >= 0, left, right)
+    return torch.where(sign == 1, -mag, mag)
+
+
+def fixed_to_bf16(n: torch.Tensor, frac: int) -> torch.Tensor:
+    """Signed int64 fixed point -> bf16, round-to-nearest-even, exact."""
+    n = n.to(torch.int64)
+    sign = (n < 0).to(torch.int64)
+    mag = n.abs()
+    mag_np = mag.numpy().astype(np.uint64)
+    # position of the most significant set bit (float64 guess, then corrected)
+    guess = np.zeros(mag_np.shape, dtype=np.int64)
+    nz = mag_np != 0
+    guess[nz] = np.frexp(mag_np[nz].astype(np.float64))[1] - 1
+    too_high = nz & ((np.uint64(1) << guess.astype(np.uint64)) > mag_np)
+    guess[too_high] -= 1
+    msb = torch.from_numpy(guess)
+    shift = (msb - 7).clamp(min=0)
+    q = mag >> shift
+    rem = mag & ((torch.ones_like(mag) << shift) - 1)
+    half = torch.where(shift > 0, torch.ones_like(mag) << (shift - 1).clamp(min=0), torch.zeros_like(mag))
+    up = (shift > 0) & ((rem > half) | ((rem == half) & ((q & 1) == 1)))
+    q = q + up.to(torch.int64)
+    # left-justify values with fewer than 8 significant bits
+    lshift = (7 - msb).clamp(min=0)
+    q = q << lshift
+    carry = q >= 256
+    q = torch.where(carry, q >> 1, q)
+    e = msb - frac + carry.to(torch.int64) + 127
+    if bool(((e <= 0) & (mag != 0)).any()) or bool((e >= 255).any()):
+        raise OverflowError("fixed-point sum outside the bf16 normal range")
+    bits = (sign << 15) | (e << 7) | (q & 0x7F)
+    bits = torch.where(mag == 0, torch.zeros_like(bits), bits)
+    return bits_to_bf16(bits)
+
+
+def exact_segment_sum(values: torch.Tensor, seg: torch.Tensor, nseg: int, frac: int) -> torch.Tensor:
+    """``dgl.ops.copy_e_sum`` under the contract: exact sum per segment -> bf16.
+
+    Returns (bf16 sums [nseg], int64 fixed-point sums [nseg])."""
+    fx = bf16_to_fixed(values, frac)
+    acc = torch.zeros(nseg, dtype=torch.int64)
+    acc.index_add_(0, seg.to(torch.int64), fx)
+    return fixed_to_bf16(acc, frac), acc
+
+
+# ----------------------------------------------------------------------------
+# Three-limb accumulator for the whole-row L1 norm of the EXP3 weights
+# (bandit_sampler.py:249).  value = (l0 + l1*2**32 + l2*2**64) * 2**-ROW_FRAC
+# ----------------------------------------------------------------------------
+ROW_FRAC = 64
+
+
+def row_exact_sum(values: torch.Tensor):
+    """Exact sum of a non-negative bf16 row as a Python int scaled by 2**ROW_FRAC."""
+    bits = bf16_bits(values)
+    exp = (bits >> 7) & 0xFF
+    man = bits & 0x7F
+    if bool((exp == 255).any()) or bool((values < 0).any()):
+        raise FloatingPointError("row sum needs finite non-negative weights")
+    m = torch.where(exp == 0, man, man | 0x80)
+    e = torch.where(exp == 0, torch.ones_like(exp), exp)
+    shift = e - 134 + ROW_FRAC            # may reach ~+60 for weights near 1
+    # split: the term m * 2**shift is spread over 32-bit limbs
+    total = 0
+    for s in torch.unique(shift).tolist():
+        cnt_m = int(m[shift == s].sum())
+        if s >= 0:
+            total += cnt_m << s
+        else:
+            # truncation happens per term, so shift each term separately
+            total += int((m[shift == s] >> (-s if -s < 63 else 63)).sum())
+    return total
+
+
+def int_to_bf16(total: int, frac: int) -> torch.Tensor:
+    """Exact Python-int fixed point -> bf16 scalar tensor (RNE)."""
+    if total == 0:
+        return torch.zeros((), dtype=torch.bfloat16)
+    msb = total.bit_length() - 1
+    if msb > 7:
+        shift = msb - 7
+        q = total >> shift
+        rem = total & ((1 << shift) - 1)
+        half = 1 << (shift - 1)
+        if rem > half or (rem == half and (q & 1)):
+            q += 1
+    else:
+        q = total << (7 - msb)
+    e = msb - frac + 127
+    if q >= 256:
+        q >>= 1
+        e += 1
+    assert 0 < e < 255
+    return bits_to_bf16(torch.tensor((e << 7) | (q & 0x7F), dtype=torch.int64))
