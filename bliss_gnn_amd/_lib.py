@@ -1,0 +1,91 @@
+"""ctypes binding of libbliss_gnn.so (the C ABI in include/bliss_gnn.h).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent, importing this
+module raises.  The product path never routes through oracle/ or torch re-implementations.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbliss_gnn.so")
+
+EINVAL = -1
+MODE_BANDIT, MODE_LADIES = 0, 1
+
+ERR_BITS = {
+    1: "frontier larger than 2^31-1 edges",
+    2: "candidate capacity exceeded / seed id out of range",
+    4: "kept-node capacity exceeded",
+    8: "block-edge capacity exceeded",
+    16: "non-finite or negative weight reached an exact reduction",
+    32: "exact sum left its fixed-point range",
+}
+
+
+class Graph(C.Structure):
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("eid", C.c_void_p),
+                ("num_nodes", C.c_int32), ("num_edges", C.c_int64)]
+
+
+class NodeMaps(C.Structure):
+    _fields_ = [("local_id", C.c_void_p), ("first_pos", C.c_void_p), ("acc_p2", C.c_void_p)]
+
+
+class LayerCounts(C.Structure):
+    _fields_ = [("S", C.c_int32), ("E", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("B", C.c_int32),
+                ("err", C.c_int32), ("iters", C.c_int32), ("all_one", C.c_int32), ("c", C.c_double)]
+
+
+class LayerWs(C.Structure):
+    _fields_ = [("counts", C.c_void_p), ("seg_ptr", C.c_void_p), ("seed_acc", C.c_void_p), ("chunk_cnt", C.c_void_p),
+                ("cand_nid", C.c_void_p), ("p", C.c_void_p), ("P", C.c_void_p), ("new_id", C.c_void_p),
+                ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32)]
+
+
+class BlockOut(C.Structure):
+    _fields_ = [("indptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("pos", C.c_void_p),
+                ("eid", C.c_void_p), ("edge_weights", C.c_void_p), ("q_ij", C.c_void_p), ("cap_b", C.c_int32)]
+
+
+_P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes; every symbol declared in include/bliss_gnn.h must appear here (tests check)
+SIGNATURES = {
+    "bliss_layer_counts_bytes": [],
+    "bliss_frontier_prob": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), _P],
+    "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _I64, _P],
+    "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],
+    "bliss_normalized_edata": [C.POINTER(Graph), _P, _P],
+    "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],
+    "bliss_spmm_fwd": [_P, _P, _P, _P, _I64, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P],
+    "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P],
+    "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, _P],
+    "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
+    "bliss_row_sum": [_P, _I64, _P, _P],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C bliss_gnn_amd/csrc`.  bliss_gnn_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    assert lib.bliss_layer_counts_bytes() == C.sizeof(LayerCounts), "LayerCounts layout mismatch"
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}" + (" (invalid argument)" if rc == EINVAL else " (hipError_t)"))
+
+
+def err_string(bits):
+    return "; ".join(msg for b, msg in ERR_BITS.items() if bits & b) or "unknown"

@@ -1,0 +1,181 @@
+"""EXP3-bandit LADIES samplers on MI355X -- same names, constructor arguments and call sites as the
+reference's ``bandit_sampler.py`` so that ``train_lightning.py:358-370, 469-471`` work unchanged:
+
+    sampler = PoissonBanditLadiesSampler(fanouts, importance_sampling=..., node_embedding='features',
+                                         num_steps=..., eta=..., model=...)
+    input_nodes, output_nodes, blocks = sampler.sample_blocks(g, seed_nodes)
+    ...forward / backward / optimiser step...
+    sampler.exp3(blocks, g)
+
+The bodies are hand-written gfx950 kernels behind the C ABI of include/bliss_gnn.h.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._engine import LayerEngine, _stream
+from .graph import EID, NID, Graph
+
+
+def find_indices_in(a, b):
+    """bandit_sampler.py:5-14 -- kept for API compatibility (the kernels never need it: seeds are
+    local ids 0..S-1 by construction)."""
+    b_sorted, indices = torch.sort(b)
+    sorted_indices = torch.searchsorted(b_sorted, a)
+    sorted_indices[sorted_indices >= indices.shape[0]] = 0
+    return indices[sorted_indices]
+
+
+def union(*arrays):
+    """bandit_sampler.py:16-18."""
+    return torch.unique(torch.cat(arrays))
+
+
+def normalized_edata(g: Graph, weight=None):
+    """bandit_sampler.py:20-27 with weight=None: ``w_e = 1 / indeg(dst(e))`` in bf16, by edge id."""
+    if weight is not None:
+        raise NotImplementedError("only the weight=None form is used by the reference (train_lightning.py:359,362)")
+    w_pos = torch.empty(g.num_edges(), dtype=torch.bfloat16, device=g.device)
+    cg = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), 0, g.num_nodes(), g.num_edges())
+    _lib.check(_lib.lib.bliss_normalized_edata(C.byref(cg), w_pos.data_ptr(), _stream()), "bliss_normalized_edata")
+    return g.by_edge_id(w_pos)
+
+
+class BlockSampler:
+    """The part of ``dgl.dataloading.BlockSampler`` the DataLoader relies on."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def sample(self, g, seed_nodes, exclude_eids=None):
+        return self.sample_blocks(g, seed_nodes, exclude_eids=exclude_eids)
+
+
+class BanditLadiesSampler(BlockSampler):
+    """bandit_sampler.py:29-367.  Multinomial selection (``select_neighbors`` :84-99) is not built yet;
+    use the Poisson subclass."""
+
+    _poisson = False
+
+    def __init__(self, nodes_per_layer, importance_sampling=True, weight="w", out_weight="edge_weights",
+                 node_embedding="nfeat", node_prob="node_prob", replace=False, eta=0.4, num_steps=5000,
+                 model="sage"):
+        super().__init__()
+        self.nodes_per_layer = nodes_per_layer
+        self.importance_sampling = importance_sampling
+        self.edge_weight = weight
+        self.output_weight = out_weight
+        self.node_prob = node_prob
+        self.node_embedding = node_embedding
+        self.replace = replace
+        self.eta = eta
+        self.T = num_steps
+        self.model = model
+        self.eps = 0.9999
+        self.delta = 0.01                      # bandit_sampler.py:233
+        self._w_pos = None                     # exp3 weights [L, |E|] bf16 in CSC-position order
+        self._row_sum = None                   # exact row sums, int64 [L, 3]
+        self._engine = None
+        if not importance_sampling:
+            raise NotImplementedError("importance_sampling=False (bandit_sampler.py:77-81) is not built yet")
+
+    # -- state ------------------------------------------------------------------------------
+    def _bind(self, g):
+        if self._engine is None or self._engine.g is not g:
+            self._engine = LayerEngine(g)
+        return self._engine
+
+    def _ensure_weights(self, g):
+        if self._w_pos is None:                                         # bandit_sampler.py:342-343
+            L, E = len(self.nodes_per_layer), g.num_edges()
+            self._w_pos = torch.ones(L, E, dtype=torch.bfloat16, device=g.device)
+            rs = torch.zeros(L, 3, dtype=torch.int64, device=g.device)
+            rs[:, 2] = E                                                # sum of E ones = E * 2^64
+            self._row_sum = rs
+            self._scratch = torch.zeros(L, 4, dtype=torch.int64, device=g.device)
+            self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
+            self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
+
+    @property
+    def exp3_weights(self):
+        """[L, |E|] bf16 indexed by EDGE ID like the reference's attribute (bandit_sampler.py:43)."""
+        if self._w_pos is None:
+            return None
+        return self._engine.g.by_edge_id(self._w_pos)
+
+    @exp3_weights.setter
+    def exp3_weights(self, value):
+        if value is None:
+            self._w_pos = None
+            return
+        g = self._engine.g
+        self._w_pos = g.by_position(value.to(torch.bfloat16)).contiguous().clone()
+        L = self._w_pos.shape[0]
+        self._row_sum = torch.zeros(L, 3, dtype=torch.int64, device=g.device)
+        self._scratch = torch.zeros(L, 4, dtype=torch.int64, device=g.device)
+        self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
+        self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
+        for l in range(L):
+            _lib.check(_lib.lib.bliss_row_sum(self._w_pos[l].data_ptr(), g.num_edges(), self._row_sum[l].data_ptr(),
+                                              _stream()), "bliss_row_sum")
+
+    # -- sampling ---------------------------------------------------------------------------
+    def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
+        """bandit_sampler.py:341-367.  ``uniforms``: optional list (sampling order, last layer first)
+        of fp32 vectors used instead of the global CPU generator."""
+        eng = self._bind(g)
+        self._ensure_weights(g)
+        output_nodes = seed_nodes
+        blocks = []
+        for n, block_id in enumerate(reversed(range(len(self.nodes_per_layer)))):
+            blk = eng.sample_layer(self._w_pos[block_id], seed_nodes, self.nodes_per_layer[block_id], _lib.MODE_BANDIT,
+                                   self.eta, poisson=self._poisson, eps=self.eps,
+                                   uniforms=None if uniforms is None else uniforms[n])
+            blk.edata[self.output_weight] = blk._edge_weights           # :324
+            blk.edata["q_ij"] = blk._q                                  # :326
+            blk.srcdata[self.node_prob] = blk._node_prob                # :328
+            seed_nodes = blk.srcdata[NID]                               # :364
+            blocks.insert(0, blk)                                       # :366
+        return seed_nodes, output_nodes, blocks
+
+    # -- bandit update ----------------------------------------------------------------------
+    def exp3(self, mfgs, g):
+        """bandit_sampler.py:251-267: rewards + weight update + L1 renormalisation, per block."""
+        self._bind(g)
+        st = _stream()
+        edge_w_pos = g.edata_by_position(self.edge_weight)
+        cg = self._engine.c_graph
+        for idx, mfg in enumerate(mfgs):
+            B = mfg.num_edges()
+            alpha = None
+            if self.model == "gat":
+                raise NotImplementedError("GAT alpha (bandit_sampler.py:146-154) lands with the GAT path")
+            n_edges = torch.tensor([B], dtype=torch.int32, device=g.device)
+            rewards = torch.empty(B, dtype=torch.bfloat16, device=g.device)
+            en = mfg.srcdata["embed_norm"]
+            if en.dtype != torch.bfloat16:
+                en = en.bfloat16()
+            _lib.check(_lib.lib.bliss_exp3_update(
+                C.byref(cg), edge_w_pos.data_ptr(), self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr(),
+                mfg.indptr.data_ptr(), mfg.src.data_ptr(), mfg.dst.data_ptr(), mfg.pos.data_ptr(),
+                mfg.edata["q_ij"].data_ptr(), mfg.srcdata[self.node_prob].data_ptr(), en.contiguous().data_ptr(),
+                0 if alpha is None else alpha.data_ptr(), mfg.dstdata[NID].data_ptr(), mfg.num_dst_nodes(),
+                n_edges.data_ptr(), B, float(torch.tensor(self.delta, dtype=torch.float32)), rewards.data_ptr(),
+                self._err.data_ptr(), st), "bliss_exp3_update")
+            mfg.edata["rewards"] = rewards                              # :193
+            _lib.check(_lib.lib.bliss_exp3_normalize(self._w_pos[idx].data_ptr(), g.num_edges(),
+                                                     self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
+                                                     self._norms[idx:].data_ptr(), st), "bliss_exp3_normalize")
+
+    def check_errors(self):
+        """Raise if any exp3 kernel flagged a non-finite weight (one sync; call off the hot path)."""
+        bits = int(self._err.item()) | int((self._scratch[:, 0] >> 20).max().item())
+        if bits:
+            raise RuntimeError(f"exp3 kernel error 0x{bits:x}: {_lib.err_string(bits)}")
+
+
+class PoissonBanditLadiesSampler(BanditLadiesSampler):
+    """bandit_sampler.py:369-425."""
+
+    _poisson = True

@@ -1,0 +1,156 @@
+// Shared device helpers for the BLISS-GNN gfx950 kernels.
+//
+// Arithmetic contract (mirrors oracle/numerics.py, which mirrors what torch's CPU kernels do
+// for the reference's bf16 tensors):
+//   * element-wise op: read bf16 -> fp32 IEEE op (correctly rounded + - * / sqrt) -> ONE
+//     round-to-nearest-even to bf16;
+//   * segment reduction (DGL's copy_e_sum, bandit_sampler.py:67,73,129,316): terms are added
+//     EXACTLY as 64-bit fixed point (integer adds commute => any schedule, any wave order, any
+//     number of GPUs gives the same bits) and the exact sum is rounded once to bf16.
+// This file is compiled with -ffp-contract=off so no multiply-add is ever fused across these
+// rounding points.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bliss_gnn.h"
+
+#define BLISS_WAVE 64
+
+// fixed-point formats (value = integer * 2^-FRAC); see oracle/numerics.py
+#define FRAC_DST 40
+#define FRAC_SRC 44
+#define FRAC_BLK 36
+
+// error bits, accumulated into LayerCounts::err
+#define BLISS_ERR_CAP_FRONTIER 1   // frontier larger than 2^31-1 positions
+#define BLISS_ERR_CAP_CAND     2   // candidate capacity exceeded
+#define BLISS_ERR_CAP_KEPT     4   // kept-node capacity exceeded
+#define BLISS_ERR_CAP_EDGES    8   // block-edge capacity exceeded
+#define BLISS_ERR_NONFINITE   16   // a non-finite / negative term reached an exact reduction
+#define BLISS_ERR_FIXED_RANGE 32   // an exact sum left its fixed-point range
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// fp32 -> bf16 round-to-nearest-even, NaN stays NaN (quiet), like torch's c10::BFloat16.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;   // NaN (c10 returns 0x7FC0)
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round-trip through bf16
+
+// bf16 -> signed 64-bit fixed point with `frac` fractional bits; truncates below 2^-frac.
+// Sets *bad on a non-finite input or a magnitude that does not fit.
+__device__ __forceinline__ int64_t bf_to_fixed(bf16_t b, int frac, int* bad) {
+  uint32_t e = (b >> 7) & 0xff, m = b & 0x7f;
+  if (e == 255) { *bad |= BLISS_ERR_NONFINITE; return 0; }
+  if (e == 0) e = 1; else m |= 0x80;
+  int shift = (int)e - 134 + frac;
+  uint64_t mag;
+  if (shift >= 0) {
+    if (shift > 55) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+    mag = (uint64_t)m << shift;
+  } else {
+    mag = (-shift >= 8) ? 0 : ((uint64_t)m >> (-shift));
+  }
+  return (b & 0x8000) ? -(int64_t)mag : (int64_t)mag;
+}
+
+// signed fixed point -> bf16, exact round-to-nearest-even.
+__device__ __forceinline__ bf16_t fixed_to_bf(int64_t n, int frac, int* bad) {
+  if (n == 0) return 0;
+  uint32_t sign = n < 0 ? 0x8000u : 0u;
+  uint64_t mag = n < 0 ? (uint64_t)(-n) : (uint64_t)n;
+  int msb = 63 - __clzll((long long)mag);
+  uint64_t q;
+  if (msb > 7) {
+    int sh = msb - 7;
+    q = mag >> sh;
+    uint64_t rem = mag & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+    if (rem > half || (rem == half && (q & 1))) q += 1;
+  } else {
+    q = mag << (7 - msb);
+  }
+  int e = msb - frac + 127;
+  if (q >= 256) { q >>= 1; e += 1; }
+  if (e <= 0 || e >= 255) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+  return (bf16_t)(sign | ((uint32_t)e << 7) | ((uint32_t)q & 0x7f));
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (BLISS_WAVE - 1); }
+
+__device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) {
+  int lo = __shfl_up((int)(v & 0xffffffffll), d), hi = __shfl_up((int)(v >> 32), d);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// Wave-level segmented sum of 64-bit terms keyed by a NON-DECREASING int key; the last lane of
+// every key run adds the run's total to acc[key] with one atomic.  Lanes with key < 0 are idle.
+__device__ __forceinline__ void wave_segsum_atomic_i64(int key, int64_t v, unsigned long long* acc) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < BLISS_WAVE; d <<= 1) {
+    int64_t vu = shfl_up_i64(v, d);
+    int ku = __shfl_up(key, d);
+    if (lane >= d && ku == key) v += vu;
+  }
+  int kn = __shfl_down(key, 1);
+  if (key >= 0 && (lane == BLISS_WAVE - 1 || kn != key) && v != 0)
+    atomicAdd(acc + key, (unsigned long long)v);
+}
+__device__ __forceinline__ void wave_segsum_atomic_i32(int key, int v, int* acc) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < BLISS_WAVE; d <<= 1) {
+    int vu = __shfl_up(v, d);
+    int ku = __shfl_up(key, d);
+    if (lane >= d && ku == key) v += vu;
+  }
+  int kn = __shfl_down(key, 1);
+  if (key >= 0 && (lane == BLISS_WAVE - 1 || kn != key) && v != 0) atomicAdd(acc + key, v);
+}
+
+// Block-wide exclusive scan of one int per thread (blockDim.x <= 1024, multiple of 64).
+// Returns the exclusive prefix; *total gets the block sum.  `sh` needs 17 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int* total) {
+  const int lane = lane_id(), wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < BLISS_WAVE; d <<= 1) {
+    int t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();                       // protect sh from a previous use
+  if (lane == BLISS_WAVE - 1) sh[wid] = inc;
+  __syncthreads();
+  if (wid == 0) {
+    int w = lane < nw ? sh[lane] : 0, winc = w;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      int t = __shfl_up(winc, d);
+      if (lane >= d) winc += t;
+    }
+    if (lane < nw) sh[lane] = winc - w;  // exclusive wave offsets
+    if (lane == nw - 1) sh[16] = winc;
+  }
+  __syncthreads();
+  *total = sh[16];
+  return sh[wid] + inc - v;
+}
+
+// Largest k in [0, n) with seg_ptr[k] <= pos (seg_ptr non-decreasing, seg_ptr[0] = 0).
+// Empty segments are skipped correctly because we take the LAST k whose start <= pos.
+__device__ __forceinline__ int find_segment(const int* __restrict__ seg_ptr, int n, int pos) {
+  int lo = 0, hi = n;           // invariant: seg_ptr[lo] <= pos < seg_ptr[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (seg_ptr[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// Per-layer sizes kept on the device (the S/E/C/K/B symbols of SURVEY.md); layout = the ABI's.
+typedef bliss_layer_counts_t LayerCounts;

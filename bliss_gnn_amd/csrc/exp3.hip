@@ -1,0 +1,234 @@
+// EXP3 bandit state for gfx950: reward, weight update, exact L1 renormalisation.
+//
+// Replaces BanditLadiesSampler.calculate_alpha (SAGE/GCN branch), calculate_rewards and
+// update_exp3_weights (bandit_sampler.py:140-249) -- ~15 DGL/ATen launches per block plus an
+// 18*|E_g|-byte whole-row normalise per layer per step -- with ONE edge-parallel launch per block
+// and a renormalisation that is bit-exact to F.normalize(p=1) yet touches the row only when the
+// bf16 norm differs from 1.0:
+//   the exact sum of the row is carried as three signed 64-bit limbs (value * 2^64, 32-bit digits);
+//   the update kernel adds digits(new) - digits(old) for the B edges it rewrites, so the norm
+//   bf16(exact sum) is known in O(B); dividing a bf16 by 1.0 is the identity, so when the norm
+//   rounds to 1.0 -- the steady state, the row sums to 1 +- 0.4% -- the 2 x |E_g| pass is skipped
+//   on the device with identical bits.
+#include "common.cuh"
+#include "bliss_gnn.h"
+
+namespace {
+
+#define E3_TPB 256
+
+// digits of (bf16 value * 2^64), truncated below 2^-64; non-negative finite input required
+__device__ __forceinline__ void row_digits(bf16_t b, int64_t d[3], int* bad) {
+  uint32_t e = (b >> 7) & 0xff, m = b & 0x7f;
+  d[0] = d[1] = d[2] = 0;
+  if (e == 255 || (b & 0x8000 && (b & 0x7fff))) { *bad |= BLISS_ERR_NONFINITE; return; }
+  if (e == 0) e = 1; else m |= 0x80;
+  int shift = (int)e - 134 + 64;                 // value*2^64 = m << shift
+  if (shift > 80) { *bad |= BLISS_ERR_FIXED_RANGE; return; }
+  unsigned __int128 t = shift >= 0 ? ((unsigned __int128)m << shift) : ((-shift >= 8) ? 0 : (unsigned __int128)(m >> (-shift)));
+  d[0] = (int64_t)(uint64_t)(t & 0xffffffffu);
+  d[1] = (int64_t)(uint64_t)((t >> 32) & 0xffffffffu);
+  d[2] = (int64_t)(uint64_t)(t >> 64);
+}
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    int lo = __shfl_xor((int)(v & 0xffffffffll), d), hi = __shfl_xor((int)(v >> 32), d);
+    v += ((int64_t)hi << 32) | (uint32_t)lo;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void flush_digits(int64_t d[3], int64_t* limbs) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int64_t s = wave_sum_i64(d[i]);
+    if (lane_id() == 0 && s != 0) atomicAdd((unsigned long long*)(limbs + i), (unsigned long long)s);
+  }
+}
+
+// exact (l0 + l1*2^32 + l2*2^64) * 2^-64 -> bf16 RNE
+__device__ bf16_t limbs_to_bf16(const int64_t* limbs, int* bad) {
+  __int128 t = (__int128)limbs[0] + ((__int128)limbs[1] << 32) + ((__int128)limbs[2] << 64);
+  if (t < 0) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+  if (t == 0) return 0;
+  unsigned __int128 u = (unsigned __int128)t;
+  uint64_t hi = (uint64_t)(u >> 64), lo = (uint64_t)u;
+  int msb = hi ? 127 - __clzll((long long)hi) : 63 - __clzll((long long)lo);
+  unsigned __int128 q;
+  if (msb > 7) {
+    int sh = msb - 7;
+    q = u >> sh;
+    unsigned __int128 rem = u & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+    if (rem > half || (rem == half && (q & 1))) q += 1;
+  } else q = u << (7 - msb);
+  int e = msb - 64 + 127;
+  if (q >= 256) { q >>= 1; e += 1; }
+  if (e <= 0 || e >= 255) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+  return (bf16_t)(((uint32_t)e << 7) | ((uint32_t)q & 0x7f));
+}
+
+__device__ __forceinline__ float nan_to_num_posinf0(float x) {   // torch.nan_to_num(x, posinf=0) on bf16
+  if (x != x) return 0.f;
+  if (x == __builtin_inff()) return 0.f;
+  if (x == -__builtin_inff()) return -3.3895313892515355e38f;     // lowest bf16
+  return x;
+}
+
+// one thread per block edge
+__global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restrict__ g_indptr, const bf16_t* __restrict__ edge_w,
+                                                       bf16_t* w_row, int64_t* row_sum, const int* __restrict__ blk_indptr,
+                                                       const int* __restrict__ blk_src, const int* __restrict__ blk_dst,
+                                                       const int* __restrict__ blk_pos, const bf16_t* __restrict__ q_ij,
+                                                       const bf16_t* __restrict__ node_prob, const bf16_t* __restrict__ embed_norm,
+                                                       const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
+                                                       const int* __restrict__ n_edges_dev, float delta_f,
+                                                       bf16_t* __restrict__ rewards_out, int* err) {
+  const int B = *n_edges_dev;
+  int bad = 0;
+  int64_t dg[3] = {0, 0, 0};
+  for (int base = blockIdx.x * E3_TPB + (threadIdx.x & ~63); base < B; base += gridDim.x * E3_TPB) {
+    const int e = base + lane_id();
+    if (e < B) {
+      const int i = blk_dst[e], j = blk_src[e], pos = blk_pos[e];
+      const float alpha = bf2f(alpha_in ? alpha_in[e] : edge_w[pos]);                  // :157 mfg.edata['w']
+      const float k_i = rbf((float)(blk_indptr[i + 1] - blk_indptr[i]));               // :180 in_degrees().bfloat16()
+      float adk = rbf(rbf(alpha * alpha) / k_i);                                       // :186 e_div_v(alpha**2, k_i)
+      adk = nan_to_num_posinf0(adk);                                                   // :187
+      const float hn = bf2f(embed_norm[j]), q = bf2f(q_ij[e]);
+      const float hq = rbf(rbf(hn * hn) / rbf(q * q));                                 // :189 u_div_e
+      const float r = rbf(adk * hq);                                                   // :191
+      if (rewards_out) rewards_out[e] = f2bf(r);                                       // :193
+      const int dn = dst_nid[i];
+      const float n_i = rbf((float)(g_indptr[dn + 1] - g_indptr[dn]));                 // :223
+      const float r_hat = rbf(r / bf2f(node_prob[j]));                                 // :240 e_div_u
+      float dr = rbf(r_hat * rbf(delta_f / n_i));                                      // :242 e_mul_v(rewards_hat, delta / n_i)
+      if (dr > 1.0f) dr = 1.0f;                                                        // :244
+      const float ex = rbf((float)exp((double)dr));                                    // :246 torch.exp on bf16
+      const bf16_t w_old = w_row[pos];
+      const bf16_t w_new = f2bf(bf2f(w_old) * ex);                                     // :248
+      if (w_new != w_old) {
+        w_row[pos] = w_new;
+        int64_t a[3], b[3];
+        row_digits(w_new, a, &bad);
+        row_digits(w_old, b, &bad);
+        dg[0] += a[0] - b[0]; dg[1] += a[1] - b[1]; dg[2] += a[2] - b[2];
+      }
+    }
+  }
+  flush_digits(dg, row_sum);
+  if (bad) atomicOr(err, bad);
+}
+
+__global__ void __launch_bounds__(E3_TPB) k_row_sum(const bf16_t* __restrict__ w, int64_t n, int64_t* limbs, int* err) {
+  int bad = 0;
+  int64_t dg[3] = {0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * E3_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * E3_TPB) {
+    int64_t a[3];
+    row_digits(w[i], a, &bad);
+    dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
+  }
+  flush_digits(dg, limbs);
+  if (bad && err) atomicOr(err, bad);
+}
+
+// scratch: [0] = norm bits | (skip << 16) | (err << 20), [1..3] = limbs of the renormalised row
+__global__ void k_norm_decide(const int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
+  int bad = 0;
+  bf16_t n = limbs_to_bf16(row_sum, &bad);
+  int skip = (n == 0x3f80);                       // x / 1.0 == x : nothing to do
+  scratch[0] = (int64_t)n | ((int64_t)skip << 16) | ((int64_t)bad << 20);
+  scratch[1] = scratch[2] = scratch[3] = 0;
+  if (norm_out) *norm_out = n;
+}
+
+__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* scratch) {
+  const int64_t s0 = scratch[0];
+  if ((s0 >> 16) & 1) return;
+  const float norm = bf2f((bf16_t)(s0 & 0xffff));
+  const float denom = rbf(fmaxf(norm, 1e-12f));    // F.normalize: norm.clamp_min(eps)
+  int bad = 0;
+  int64_t dg[3] = {0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * E3_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * E3_TPB) {
+    bf16_t v = f2bf(bf2f(w[i]) / denom);           // :249 input / denom
+    w[i] = v;
+    int64_t a[3];
+    row_digits(v, a, &bad);
+    dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
+  }
+  flush_digits(dg, scratch + 1);
+  if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
+}
+
+__global__ void k_norm_commit(int64_t* row_sum, const int64_t* scratch) {
+  if ((scratch[0] >> 16) & 1) return;
+  row_sum[0] = scratch[1]; row_sum[1] = scratch[2]; row_sum[2] = scratch[3];
+}
+
+// w_pos[p] = bf16(1 / bf16(indeg(dst(p))))          bandit_sampler.py:20-27
+__global__ void __launch_bounds__(E3_TPB) k_normalized_edata(const int64_t* __restrict__ indptr, int num_nodes, bf16_t* __restrict__ out) {
+  const int lane = lane_id();
+  for (int v = blockIdx.x * (E3_TPB / 64) + (threadIdx.x >> 6); v < num_nodes; v += gridDim.x * (E3_TPB / 64)) {
+    const int64_t b = indptr[v], e = indptr[v + 1];
+    // exact sum of (e-b) ones = the integer, rounded once to bf16 by the int->float->bf16 chain (exact below 2^24)
+    const bf16_t val = f2bf(1.0f / rbf((float)(e - b)));
+    for (int64_t p = b + lane; p < e; p += 64) out[p] = val;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_pos, int64_t* row_sum,
+                      const int32_t* blk_indptr, const int32_t* blk_src, const int32_t* blk_dst,
+                      const int32_t* blk_pos, const void* q_ij, const void* node_prob, const void* embed_norm,
+                      const void* alpha_or_null, const int32_t* dst_nid, int32_t n_dst, const int32_t* n_edges_dev,
+                      int32_t edges_bound, float delta_f, void* rewards_out, int32_t* err, void* stream) {
+  if (!g || !w_pos || !row_sum || !blk_indptr || !blk_src || !blk_dst || !blk_pos || !q_ij || !node_prob ||
+      !embed_norm || !dst_nid || !n_edges_dev || !err || (!edge_w_pos && !alpha_or_null))
+    return BLISS_EINVAL;
+  (void)n_dst;
+  if (edges_bound <= 0) return 0;
+  int grid = (edges_bound + E3_TPB - 1) / E3_TPB;
+  if (grid > 2048) grid = 2048;
+  k_exp3_update<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(g->indptr, (const bf16_t*)edge_w_pos, (bf16_t*)w_pos, row_sum, blk_indptr,
+                                                          blk_src, blk_dst, blk_pos, (const bf16_t*)q_ij, (const bf16_t*)node_prob,
+                                                          (const bf16_t*)embed_norm, (const bf16_t*)alpha_or_null, dst_nid,
+                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64_t* scratch, void* norm_out_bf16, void* stream) {
+  if (!w_pos || !row_sum || !scratch || num_edges <= 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  k_norm_decide<<<1, 1, 0, st>>>(row_sum, scratch, (bf16_t*)norm_out_bf16);
+  int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, scratch);
+  k_norm_commit<<<1, 1, 0, st>>>(row_sum, scratch);
+  return (int)hipGetLastError();
+}
+
+int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream) {
+  if (!w_pos || !row_sum || num_edges <= 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(row_sum, 0, 3 * sizeof(int64_t), st);
+  if (e != hipSuccess) return (int)e;
+  int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
+  if (grid > 4096) grid = 4096;
+  k_row_sum<<<(int)grid, E3_TPB, 0, st>>>((const bf16_t*)w_pos, num_edges, row_sum, nullptr);
+  return (int)hipGetLastError();
+}
+
+int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream) {
+  if (!g || !w_pos) return BLISS_EINVAL;
+  int grid = (g->num_nodes + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  k_normalized_edata<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(g->indptr, g->num_nodes, (bf16_t*)w_pos);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,559 @@
+// Layer-wise bandit / LADIES block sampler for gfx950 -- frontier expansion, EXP3 edge
+// probabilities, LADIES node importance, Poisson scale + draw, block construction.
+//
+// Replaces, per layer, the ~40 DGL/ATen launches and >= 8 host syncs of
+//   bandit_sampler.py:101-138 (exp3_probabilities), :47-82 + :381-406 (compute_prob),
+//   :408-425 (select_neighbors), :269-339 (generate_block)      and the ladies_sampler.py twins
+// with 12 sync-free launches that never materialise the frontier: every pass re-reads the
+// seeds' CSC columns (coalesced, 4 B index + 2 B weight per edge) and keeps only per-seed,
+// per-candidate and per-kept-edge state.  Sizes (E, C, K, B) live on the device in LayerCounts.
+//
+// Node maps are dense |V|-sized arrays (local_id, first_pos, acc_p2) -- on a 288 GB part a dense
+// map beats a hash table: one L2-resident gather per edge, no probing, reset by touched entry.
+//
+// Ordering contract: candidates = seeds in given order, then every other frontier
+// source by FIRST APPEARANCE in the dst-major frontier; kept nodes and block edges keep that
+// relative order, so the block comes out CSR-by-destination with no sort anywhere.
+#include "common.cuh"
+#include "bliss_gnn.h"
+
+#define TPB 256
+#define ITEMS 4
+#define CHUNK (TPB * ITEMS)
+
+namespace {
+
+struct EdgeAt {
+  int k;          // seed index (local destination id)
+  int64_t pos;    // CSC position
+  int src;        // global source id
+};
+
+__device__ __forceinline__ EdgeAt decode(int e, int S, const int* __restrict__ seg_ptr,
+                                         const int* __restrict__ seeds, const int64_t* __restrict__ indptr,
+                                         const int* __restrict__ indices) {
+  EdgeAt r;
+  r.k = find_segment(seg_ptr, S, e);
+  r.pos = indptr[seeds[r.k]] + (e - seg_ptr[r.k]);
+  r.src = indices[r.pos];
+  return r;
+}
+
+// q_ij = eta/n_i + (1-eta) * w_ij / sum_j w_ij        bandit_sampler.py:131-137
+__device__ __forceinline__ bf16_t edge_q(bf16_t w, bf16_t wsum, int n, float eta_f, float ome_f) {
+  float wd = rbf(bf2f(w) / bf2f(wsum));     // :131 e_div_v
+  float a = rbf(eta_f / (float)n);          // :137 (self.eta / n_i).bfloat16()
+  float b = rbf(ome_f * wd);                // :137 (1 - self.eta) * exp_weights_divided
+  return f2bf(a + b);                       // :137 v_add_e
+}
+
+// ---------------------------------------------------------------- K_a: seed columns -> seg_ptr
+__global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
+                                                   LayerCounts* cnt, int* __restrict__ seg_ptr,
+                                                   int* __restrict__ local_id, int num_nodes) {
+  __shared__ int sh[17];
+  const int S = cnt->S;
+  long long run = 0;
+  int bad = 0;
+  for (int base = 0; base < S; base += blockDim.x) {
+    int k = base + threadIdx.x, deg = 0;
+    if (k < S) {
+      int s = seeds[k];
+      if (s < 0 || s >= num_nodes) { bad |= BLISS_ERR_CAP_CAND; }
+      else {
+        deg = (int)(indptr[s + 1] - indptr[s]);
+        local_id[s] = k;
+      }
+    }
+    int tot, ex = block_excl_scan(deg, sh, &tot);
+    if (k < S) seg_ptr[k] = (int)(run + ex);
+    run += tot;
+    if (run > 0x7fffffffll) bad |= BLISS_ERR_CAP_FRONTIER;
+  }
+  if (threadIdx.x == 0) {
+    seg_ptr[S] = (int)run;
+    cnt->E = (bad & BLISS_ERR_CAP_FRONTIER) ? 0 : (int)run;
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- K_b: first appearance + sum_j w_ij
+template <bool BANDIT>
+__global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                        const bf16_t* __restrict__ w, const int* __restrict__ seeds,
+                                                        const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                        const int* __restrict__ local_id, unsigned* first_pos,
+                                                        unsigned long long* acc_w) {
+  const int S = cnt->S, E = cnt->E;
+  int bad = 0;
+  for (int base = blockIdx.x * TPB + (threadIdx.x & ~63); base < E; base += gridDim.x * TPB) {
+    int e = base + lane_id();
+    int k = -1;
+    int64_t term = 0;
+    if (e < E) {
+      EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
+      k = a.k;
+      if (local_id[a.src] < 0) {                       // not a seed: seeds are numbered already
+        if (first_pos[a.src] > (unsigned)e) atomicMin(first_pos + a.src, (unsigned)e);
+      }
+      if (BANDIT) term = bf_to_fixed(w[a.pos], FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
+    }
+    if (BANDIT) wave_segsum_atomic_i64(k, term, acc_w);
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- K_d: sum_k q_ik + count first appearances
+template <bool BANDIT>
+__global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                        const bf16_t* __restrict__ w, const int* __restrict__ seeds,
+                                                        const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                        const unsigned* __restrict__ first_pos,
+                                                        const unsigned long long* __restrict__ acc_w,
+                                                        unsigned long long* acc_q, int* __restrict__ chunk_cnt,
+                                                        float eta_f, float ome_f) {
+  __shared__ int sh[17];
+  const int S = cnt->S, E = cnt->E;
+  const int nchunks = (E + CHUNK - 1) / CHUNK;
+  int bad = 0;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    int nfirst = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      int e = chunk * CHUNK + i * TPB + threadIdx.x;
+      int k = -1;
+      int64_t term = 0;
+      if (e < E) {
+        EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
+        k = a.k;
+        nfirst += (first_pos[a.src] == (unsigned)e);
+        if (BANDIT) {
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
+          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+          term = bf_to_fixed(q, FRAC_DST, &bad);       // :67 copy_e_sum(insg, edge_prob)
+        }
+      }
+      if (BANDIT) wave_segsum_atomic_i64(k, term, acc_q);
+    }
+    int tot;
+    block_excl_scan(nfirst, sh, &tot);
+    if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- single-block exclusive scan of chunk counts
+// which: 0 -> C = S + total (candidates), 1 -> K = total (kept nodes), 2 -> B = total (block edges)
+__global__ void __launch_bounds__(1024) k_chunk_scan(int* __restrict__ chunk_cnt, LayerCounts* cnt, int which, int cap) {
+  __shared__ int sh[17];
+  int n_items = which == 1 ? cnt->C : cnt->E;
+  const int n = (n_items + CHUNK - 1) / CHUNK;
+  int run = 0;
+  for (int base = 0; base < n; base += blockDim.x) {
+    int i = base + threadIdx.x;
+    int v = i < n ? chunk_cnt[i] : 0;
+    int tot, ex = block_excl_scan(v, sh, &tot);
+    if (i < n) chunk_cnt[i] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) {
+    int total = which == 0 ? cnt->S + run : run;
+    int errbit = which == 0 ? BLISS_ERR_CAP_CAND : (which == 1 ? BLISS_ERR_CAP_KEPT : BLISS_ERR_CAP_EDGES);
+    if (total > cap) { atomicOr(&cnt->err, errbit); total = cap; }   // clamp: results invalid but in bounds
+    if (which == 0) cnt->C = total; else if (which == 1) cnt->K = total; else cnt->B = total;
+  }
+}
+
+// ---------------------------------------------------------------- K_f: number candidates + scatter (q/sum q)^2 by source
+template <bool BANDIT>
+__global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                        const bf16_t* __restrict__ w, const int* __restrict__ seeds,
+                                                        const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                        const unsigned* __restrict__ first_pos,
+                                                        const unsigned long long* __restrict__ acc_w,
+                                                        const unsigned long long* __restrict__ acc_q,
+                                                        const int* __restrict__ chunk_off, int* local_id,
+                                                        int* __restrict__ cand_nid, unsigned long long* acc_p2,
+                                                        float eta_f, float ome_f, int cap_c) {
+  __shared__ int sh[17];
+  const int S = cnt->S, E = cnt->E;
+  const int nchunks = (E + CHUNK - 1) / CHUNK;
+  int bad = 0;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    int run = chunk_off[chunk];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      int e = chunk * CHUNK + i * TPB + threadIdx.x;
+      int flag = 0, src = 0;
+      if (e < E) {
+        EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
+        src = a.src;
+        flag = (first_pos[src] == (unsigned)e);
+        bf16_t t;
+        if (BANDIT) {
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
+          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
+          bf16_t qsum = fixed_to_bf((int64_t)acc_q[a.k], FRAC_DST, &bad);
+          float r = rbf(bf2f(q) / bf2f(qsum));          // :71 e_div_u on the reversed frontier
+          t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
+        } else {
+          float x = bf2f(w[a.pos]);                     // ladies_sampler.py:46-47  weight ** 2
+          t = f2bf(x * x);
+        }
+        int64_t fx = bf_to_fixed(t, FRAC_SRC, &bad);
+        if (fx) atomicAdd(acc_p2 + src, (unsigned long long)fx);   // :73 copy_e_sum by SOURCE
+      }
+      int tot, rank = block_excl_scan(flag, sh, &tot);
+      if (flag) {
+        int id = S + run + rank;
+        if (id < cap_c) { local_id[src] = id; cand_nid[id] = src; }
+      }
+      run += tot;
+    }
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- K_g: p_j = sqrt(sum), reset the dense maps
+__global__ void __launch_bounds__(TPB) k_cand_finalize(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
+                                                       unsigned long long* acc_p2, unsigned* first_pos,
+                                                       bf16_t* __restrict__ p, int cap_c) {
+  const int S = cnt->S;
+  const int C = min(cnt->C, cap_c);
+  int bad = 0;
+  for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) {
+    int g;
+    if (id < S) { g = seeds[id]; cand_nid[id] = g; } else g = cand_nid[id];
+    bf16_t p2 = fixed_to_bf((int64_t)acc_p2[g], FRAC_SRC, &bad);
+    acc_p2[g] = 0;
+    first_pos[g] = 0xffffffffu;
+    p[id] = f2bf(sqrtf(bf2f(p2)));                    // :75 torch.sqrt(prob)
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- K_h: Poisson scale c  (bandit_sampler.py:391-401)
+__device__ __forceinline__ double block_sum_f64(double v, double* shd) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    long long b = __double_as_longlong(v);
+    int lo = __shfl_down((int)(b & 0xffffffffll), d), hi = __shfl_down((int)(b >> 32), d);
+    v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+  __syncthreads();
+  if (lane_id() == 0) shd[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += shd[i];   // same order in every thread
+  return t;
+}
+
+__global__ void __launch_bounds__(1024) k_poisson_scale(const bf16_t* __restrict__ p, LayerCounts* cnt, int num, double eps) {
+  __shared__ double shd[16];
+  const int C = cnt->C;
+  if (C <= num) {                                     // :392-393 everything is kept
+    if (threadIdx.x == 0) { cnt->c = 1.0; cnt->all_one = 1; cnt->iters = 0; }
+    return;
+  }
+  double c = 1.0;
+  int it = 0;
+  for (; it < 50; ++it) {                             // :396
+    const float c32 = (float)c;                       // torch multiplies a bf16 tensor by a Python float in fp32
+    double loc = 0;
+    for (int j = threadIdx.x; j < C; j += blockDim.x) {
+      float v = rbf(bf2f(p[j]) * c32);
+      loc += (double)(v < 1.0f ? v : (v != v ? v : 1.0f));   // torch.minimum propagates NaN
+    }
+    double Ssum = block_sum_f64(loc, shd);            // :397, exact in fp64 (bf16 terms, < 2^24 of them)
+    double lo = Ssum < (double)num ? Ssum : (double)num, hi = Ssum < (double)num ? (double)num : Ssum;
+    if (lo / hi >= eps) { ++it; break; }              // :398
+    c *= (double)num / Ssum;                          // :401
+  }
+  if (threadIdx.x == 0) { cnt->c = c; cnt->all_one = 0; cnt->iters = it > 50 ? 50 : it; }
+}
+
+__device__ __forceinline__ bf16_t incl_prob(const bf16_t* __restrict__ p, int j, int S, int all_one, float c32) {
+  if (all_one || j < S) return 0x3f80;                // 1.0: early-out (:393) or a seed (:403-404, inf*c -> min -> 1)
+  float v = rbf(bf2f(p[j]) * c32);                    // :406
+  return (v < 1.0f || v != v) ? f2bf(v) : (bf16_t)0x3f80;
+}
+
+// ---------------------------------------------------------------- K_i: P_j, Bernoulli compare, count per chunk
+__global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__ p, const float* __restrict__ uniforms,
+                                                      LayerCounts* cnt, bf16_t* __restrict__ P, int* __restrict__ chunk_cnt, int cap_c) {
+  __shared__ int sh[17];
+  const int S = cnt->S, C = min(cnt->C, cap_c), all_one = cnt->all_one;
+  const float c32 = (float)cnt->c;
+  const int nchunks = (C + CHUNK - 1) / CHUNK;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    int kept = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      int j = chunk * CHUNK + i * TPB + threadIdx.x;
+      if (j < C) {
+        bf16_t Pj = incl_prob(p, j, S, all_one, c32);
+        P[j] = Pj;
+        kept += (uniforms[j] < bf2f(Pj));             // :422-424  ATen CPU bernoulli: u24 < float(P)
+      }
+    }
+    int tot;
+    block_excl_scan(kept, sh, &tot);
+    if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
+  }
+}
+
+// ---------------------------------------------------------------- K_k: ordered compaction of the kept nodes
+__global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ uniforms, LayerCounts* cnt,
+                                                      const bf16_t* __restrict__ P, const int* __restrict__ chunk_off,
+                                                      const int* __restrict__ cand_nid, int* __restrict__ new_id,
+                                                      int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
+                                                      int cap_c, int cap_k) {
+  __shared__ int sh[17];
+  const int C = min(cnt->C, cap_c);
+  const int nchunks = (C + CHUNK - 1) / CHUNK;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    int run = chunk_off[chunk];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      int j = chunk * CHUNK + i * TPB + threadIdx.x;
+      int flag = 0;
+      bf16_t Pj = 0;
+      if (j < C) { Pj = P[j]; flag = (uniforms[j] < bf2f(Pj)); }
+      int tot, rank = block_excl_scan(flag, sh, &tot);
+      if (j < C) {
+        int r = run + rank;
+        if (flag && r < cap_k) { kept_nid[r] = cand_nid[j]; node_prob[r] = Pj; new_id[j] = r; }   // :306,:309
+        else new_id[j] = -1;
+      }
+      run += tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- K_l: kept in-degree, sum of q/P per destination
+template <bool BANDIT>
+__global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                     const bf16_t* __restrict__ w, const int* __restrict__ seeds,
+                                                     const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                     const unsigned long long* __restrict__ acc_w,
+                                                     const int* __restrict__ local_id, const int* __restrict__ new_id,
+                                                     const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
+                                                     int* __restrict__ chunk_cnt, float eta_f, float ome_f) {
+  __shared__ int sh[17];
+  const int S = cnt->S, E = cnt->E;
+  const int nchunks = (E + CHUNK - 1) / CHUNK;
+  int bad = 0;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    int nkept = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      int e = chunk * CHUNK + i * TPB + threadIdx.x;
+      int k = -1, kept = 0;
+      int64_t term = 0;
+      if (e < E) {
+        EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
+        k = a.k;
+        int lid = local_id[a.src];
+        kept = new_id[lid] >= 0;                       // :289-298 source was drawn (seeds always are)
+        if (kept) {
+          bf16_t q;
+          if (BANDIT) {
+            bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
+            q = edge_q(w[a.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+          } else q = w[a.pos];
+          bf16_t wt = f2bf(bf2f(q) / bf2f(P[lid]));    // :314 e_div_u(sg, W, P)
+          term = bf_to_fixed(wt, FRAC_BLK, &bad);      // :316 copy_e_sum
+        }
+        nkept += kept;
+      }
+      wave_segsum_atomic_i32(k, kept, deg_blk);        // :318 sg.in_degrees()
+      if (BANDIT) wave_segsum_atomic_i64(k, term, acc_wt);
+    }
+    int tot;
+    block_excl_scan(nkept, sh, &tot);
+    if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- block CSR indptr from kept in-degrees
+__global__ void __launch_bounds__(1024) k_indptr_scan(const int* __restrict__ deg_blk, LayerCounts* cnt, int* __restrict__ blk_indptr) {
+  __shared__ int sh[17];
+  const int S = cnt->S;
+  int run = 0;
+  for (int base = 0; base < S; base += blockDim.x) {
+    int k = base + threadIdx.x;
+    int v = k < S ? deg_blk[k] : 0;
+    int tot, ex = block_excl_scan(v, sh, &tot);
+    if (k < S) blk_indptr[k] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) blk_indptr[S] = run;
+}
+
+// ---------------------------------------------------------------- K_n: emit the block's edges in frontier order
+template <bool BANDIT>
+__global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                     const int* __restrict__ eid_map, const bf16_t* __restrict__ w,
+                                                     const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
+                                                     LayerCounts* cnt, const unsigned long long* __restrict__ acc_w,
+                                                     const int* __restrict__ local_id, const int* __restrict__ new_id,
+                                                     const bf16_t* __restrict__ P, const int* __restrict__ deg_blk,
+                                                     const unsigned long long* __restrict__ acc_wt,
+                                                     const int* __restrict__ chunk_off, int* __restrict__ out_src,
+                                                     int* __restrict__ out_dst, int* __restrict__ out_pos,
+                                                     int* __restrict__ out_eid, bf16_t* __restrict__ out_w,
+                                                     bf16_t* __restrict__ out_q, float eta_f, float ome_f, int cap_b) {
+  __shared__ int sh[17];
+  const int S = cnt->S, E = cnt->E;
+  const int nchunks = (E + CHUNK - 1) / CHUNK;
+  int bad = 0;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    int run = chunk_off[chunk];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      int e = chunk * CHUNK + i * TPB + threadIdx.x;
+      int kept = 0, nid = -1, lid = 0;
+      EdgeAt a;
+      a.k = 0; a.pos = 0; a.src = 0;
+      if (e < E) {
+        a = decode(e, S, seg_ptr, seeds, indptr, indices);
+        lid = local_id[a.src];
+        nid = new_id[lid];
+        kept = nid >= 0;
+      }
+      int tot, rank = block_excl_scan(kept, sh, &tot);
+      int idx = run + rank;
+      if (kept && idx < cap_b) {
+        const int k = a.k;
+        bf16_t q;
+        if (BANDIT) {
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
+          q = edge_q(w[a.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+        } else q = w[a.pos];
+        float wt = rbf(bf2f(q) / bf2f(P[lid]));                        // :314
+        float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
+        float out;
+        if (BANDIT) {
+          bf16_t wts = fixed_to_bf((int64_t)acc_wt[k], FRAC_BLK, &bad);
+          float ratio = rbf(d / bf2f(wts));                            // :320  d / W_tilde_sum
+          out = wt * ratio;                                            // :320  e_mul_v
+        } else {
+          out = wt * d;                                                // ladies_sampler.py:97
+        }
+        out_src[idx] = nid;
+        out_dst[idx] = k;
+        out_pos[idx] = (int)a.pos;
+        out_eid[idx] = eid_map ? eid_map[a.pos] : (int)a.pos;          // :335-337
+        out_w[idx] = f2bf(out);                                        // :324 edge_weights
+        out_q[idx] = q;                                                // :326 q_ij
+      }
+      run += tot;
+    }
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- K_o: leave the dense id map clean
+__global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __restrict__ cand_nid, int* local_id, int cap_c) {
+  const int C = min(cnt->C, cap_c);
+  for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) local_id[cand_nid[id]] = -1;
+}
+
+__global__ void k_init_counts(LayerCounts* cnt, int S) {
+  cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = 0; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+}
+
+inline int grid_for(int64_t n, int per_block, int max_blocks = 2048) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+}  // namespace
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+extern "C" {
+
+int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
+
+int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
+                        int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
+                        const bliss_layer_ws_t* ws, void* stream_) {
+  if (!g || !m || !seeds || !ws || n_seeds <= 0) return BLISS_EINVAL;
+  if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
+  if (!w_pos) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  LayerCounts* cnt = (LayerCounts*)ws->counts;
+  const bf16_t* w = (const bf16_t*)w_pos;
+  unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;            // [S]
+  unsigned long long* acc_q = acc_w + n_seeds;                              // [S]
+  if (frontier_bound < 1) frontier_bound = 1;
+  const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
+  k_init_counts<<<1, 1, 0, st>>>(cnt, n_seeds);
+  CK(hipMemsetAsync(ws->seed_acc, 0, (size_t)n_seeds * 32, st));            // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
+  k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes);
+  if (mode == BLISS_MODE_BANDIT) {
+    k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w);
+    k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f);
+  } else {
+    k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w);
+    k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f);
+  }
+  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 0, ws->cap_c);
+  if (mode == BLISS_MODE_BANDIT)
+    k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c);
+  else
+    k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c);
+  k_cand_finalize<<<grid_for(ws->cap_c < frontier_bound + n_seeds ? ws->cap_c : frontier_bound + n_seeds, TPB), TPB, 0, st>>>(
+      seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->cap_c);
+  return (int)hipGetLastError();
+}
+
+int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps, const float* uniforms,
+                         int64_t cand_bound, void* stream_) {
+  if (!ws || !uniforms || fanout < 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  LayerCounts* cnt = (LayerCounts*)ws->counts;
+  if (cand_bound < 1) cand_bound = 1;
+  if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
+  const int gc = grid_for(cand_bound, CHUNK);
+  k_poisson_scale<<<1, 1024, 0, st>>>((const bf16_t*)ws->p, cnt, fanout, eps);
+  k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c);
+  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k);
+  k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
+                                     ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k);
+  return (int)hipGetLastError();
+}
+
+int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
+                      int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
+                      const bliss_layer_ws_t* ws, const bliss_block_out_t* out, void* stream_) {
+  if (!g || !m || !seeds || !ws || !out || !w_pos || n_seeds <= 0) return BLISS_EINVAL;
+  if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  LayerCounts* cnt = (LayerCounts*)ws->counts;
+  const bf16_t* w = (const bf16_t*)w_pos;
+  unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;
+  unsigned long long* acc_wt = acc_w + 2 * (size_t)n_seeds;
+  int* deg_blk = (int*)(acc_w + 3 * (size_t)n_seeds);
+  if (frontier_bound < 1) frontier_bound = 1;
+  const int gc = grid_for(frontier_bound, CHUNK);
+  if (mode == BLISS_MODE_BANDIT)
+    k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f);
+  else
+    k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f);
+  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 2, out->cap_b);
+  k_indptr_scan<<<1, 1024, 0, st>>>(deg_blk, cnt, out->indptr);
+  if (mode == BLISS_MODE_BANDIT)
+    k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b);
+  else
+    k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b);
+  int64_t cb = frontier_bound + n_seeds;
+  if (cb > ws->cap_c) cb = ws->cap_c;
+  k_cleanup<<<grid_for(cb, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Graph and Block (MFG) containers with the slice of the DGL surface the reference consumes.
+
+The reference hands ``dgl.DGLGraph`` / DGLBlock objects between its DataLoader, samplers, models
+and callback (SURVEY.md section 8b lists every attribute touched).  DGL is not available on this
+platform, so these two small classes provide that surface -- and only that -- over plain device
+tensors: a CSC graph (``train_lightning.py:373`` keeps only CSC) and a CSR-by-destination block.
+"""
+import contextlib
+
+import torch
+
+NID = "_ID"   # dgl.NID
+EID = "_ID"   # dgl.EID
+
+
+class Graph:
+    """CSC message graph.  ``indptr`` int64 [V+1], ``indices`` int32 [E] (source of every in-edge,
+    grouped by destination), ``eid`` int32 [E] = edge id of every CSC position (None: identity).
+
+    ``ndata`` / ``edata`` hold per-node / per-EDGE-ID tensors exactly like DGL frames."""
+
+    is_block = False
+
+    def __init__(self, indptr, indices, eid=None, ndata=None, edata=None):
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
+        assert indptr.device == indices.device
+        self.indptr = indptr.contiguous()
+        self.indices = indices.contiguous()
+        self.eid = None if eid is None else eid.to(torch.int32).contiguous()
+        self.ndata = dict(ndata or {})
+        self.edata = dict(edata or {})
+        self.idtype = torch.int32
+        self._inv_eid = None
+        self._pos_cache = {}
+
+    # -- DGL surface ------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.indptr.device
+
+    def num_nodes(self):
+        return self.indptr.numel() - 1
+
+    number_of_nodes = num_nodes
+
+    def num_edges(self):
+        return self.indices.numel()
+
+    number_of_edges = num_edges
+
+    def in_degrees(self, v=None):
+        deg = (self.indptr[1:] - self.indptr[:-1]).to(self.idtype)
+        return deg if v is None else deg[v.long()]
+
+    def int(self):
+        return self
+
+    def formats(self, fmts=None):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = Graph(self.indptr.to(device), self.indices.to(device), None if self.eid is None else self.eid.to(device),
+                  {k: v.to(device) for k, v in self.ndata.items()}, {k: v.to(device) for k, v in self.edata.items()})
+        return g
+
+    # -- edge-id <-> CSC-position plumbing --------------------------------------------
+    def by_position(self, edge_tensor):
+        """[.., E] tensor indexed by edge id -> indexed by CSC position (a view when eid is identity)."""
+        if self.eid is None:
+            return edge_tensor
+        return edge_tensor[..., self.eid.long()]
+
+    def by_edge_id(self, pos_tensor):
+        if self.eid is None:
+            return pos_tensor
+        if self._inv_eid is None:
+            inv = torch.empty_like(self.eid, dtype=torch.int64)
+            inv[self.eid.long()] = torch.arange(self.eid.numel(), device=self.device)
+            self._inv_eid = inv
+        return pos_tensor[..., self._inv_eid]
+
+    def edata_by_position(self, key):
+        """Cached CSC-position-ordered copy of ``edata[key]`` (kernels read columns contiguously)."""
+        t = self.edata[key]
+        tag = (t.data_ptr(), t._version)
+        hit = self._pos_cache.get(key)
+        if hit is None or hit[0] != tag:
+            self._pos_cache[key] = (tag, self.by_position(t).contiguous())
+        return self._pos_cache[key][1]
+
+
+class _LazyFrame(dict):
+    """A frame that materialises parent features on first access, like DGL's lazy feature slicing:
+    ``blocks[0].srcdata['features'] == g.ndata['features'][input_nodes]`` (train_lightning.py:138)."""
+
+    def __init__(self, parent_frame, index_fn):
+        super().__init__()
+        self._parent = parent_frame
+        self._index_fn = index_fn
+
+    def __missing__(self, key):
+        if self._parent is not None and key in self._parent:
+            v = self._parent[key][self._index_fn()]
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (self._parent is not None and key in self._parent)
+
+    def update(self, other=(), **kw):   # dict.update bypasses __setitem__ semantics we rely on; keep simple
+        for k, v in dict(other, **kw).items():
+            self[k] = v
+
+
+class Block:
+    """One message-flow graph: ``n_src`` source nodes, the first ``n_dst`` of which are the
+    destinations; edges stored CSR-by-destination in frontier order (``indptr``, ``src``) with the
+    per-edge ``dst`` alongside.  Mirrors the DGLBlock members listed in SURVEY.md section 8b."""
+
+    is_block = True
+
+    def __init__(self, g, n_src, n_dst, indptr, src, dst, pos, eid, src_nid):
+        self.g = g
+        self._n_src, self._n_dst = int(n_src), int(n_dst)
+        self.indptr, self.src, self.dst, self.pos = indptr, src, dst, pos
+        self.idtype = torch.int32
+        self.srcdata = _LazyFrame(g.ndata if g is not None else None, lambda: self.srcdata[NID].long())
+        self.dstdata = _LazyFrame(g.ndata if g is not None else None, lambda: self.dstdata[NID].long())
+        self.edata = _LazyFrame(g.edata if g is not None else None, lambda: self.edata[EID].long())
+        self.srcdata[NID] = src_nid
+        self.dstdata[NID] = src_nid[: self._n_dst]
+        self.edata[EID] = eid
+        self._transposed = None
+
+    @property
+    def device(self):
+        return self.src.device
+
+    def num_src_nodes(self):
+        return self._n_src
+
+    def num_dst_nodes(self):
+        return self._n_dst
+
+    number_of_dst_nodes = num_dst_nodes
+    number_of_src_nodes = num_src_nodes
+
+    def num_edges(self):
+        return self.src.numel()
+
+    number_of_edges = num_edges
+
+    def in_degrees(self):
+        return (self.indptr[1:] - self.indptr[:-1]).to(self.idtype)
+
+    def edges(self):
+        return self.src, self.dst
+
+    def int(self):
+        return self
+
+    def to(self, device):
+        assert torch.device(device) == self.device, "sampling device must equal training device (SURVEY.md 3.1)"
+        return self
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        saved = [dict.copy(f) for f in (self.srcdata, self.dstdata, self.edata)]
+        try:
+            yield
+        finally:
+            for f, s in zip((self.srcdata, self.dstdata, self.edata), saved):
+                dict.clear(f)
+                dict.update(f, s)
+
+    def transposed(self):
+        """Edges grouped by SOURCE (stable, i.e. ascending edge index inside a source): ``(t_indptr
+        int32 [n_src+1], t_edge int32 [B])``.  Only the SpMM backward needs it; index plumbing."""
+        if self._transposed is None:
+            order = torch.argsort(self.src, stable=True).to(torch.int32)
+            cnt = torch.bincount(self.src, minlength=self._n_src)
+            t_indptr = torch.zeros(self._n_src + 1, dtype=torch.int32, device=self.device)
+            t_indptr[1:] = torch.cumsum(cnt, 0)
+            self._transposed = (t_indptr, order)
+        return self._transposed

@@ -1,0 +1,56 @@
+"""LADIES samplers on MI355X -- same names and call sites as the reference's ``ladies_sampler.py``
+(``train_lightning.py:358-360``): ``(PoissonLadiesSampler | LadiesSampler)(fanouts)``, static edge
+weights ``g.edata['w']`` instead of the EXP3 state.  Kernels: include/bliss_gnn.h, BLISS_MODE_LADIES.
+"""
+import torch
+
+from . import _lib
+from ._engine import LayerEngine
+from .bandit_sampler import BlockSampler, find_indices_in, normalized_edata, union  # noqa: F401  (same helpers, ladies_sampler.py:6-22)
+from .graph import NID
+
+
+class LadiesSampler(BlockSampler):
+    """ladies_sampler.py:24-123.  Multinomial selection (:54-69) is not built yet; use the Poisson subclass."""
+
+    _poisson = False
+
+    def __init__(self, nodes_per_layer, importance_sampling=True, weight="w", out_weight="edge_weights",
+                 replace=False, allow_zero_in_degree=False):
+        super().__init__()
+        self.nodes_per_layer = nodes_per_layer
+        self.importance_sampling = importance_sampling
+        self.edge_weight = weight
+        self.output_weight = out_weight
+        self.replace = replace
+        self.allow_zero_in_degree = allow_zero_in_degree
+        self.eps = 0.9999
+        self._engine = None
+        if not importance_sampling:
+            raise NotImplementedError("importance_sampling=False (ladies_sampler.py:49-51) is not built yet")
+
+    def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
+        """ladies_sampler.py:109-123."""
+        if self._engine is None or self._engine.g is not g:
+            self._engine = LayerEngine(g)
+        w_pos = g.edata_by_position(self.edge_weight)                    # :114
+        output_nodes = seed_nodes
+        blocks = []
+        for n, block_id in enumerate(reversed(range(len(self.nodes_per_layer)))):
+            blk = self._engine.sample_layer(w_pos, seed_nodes, self.nodes_per_layer[block_id], _lib.MODE_LADIES, 0.0,
+                                            poisson=self._poisson, eps=self.eps,
+                                            uniforms=None if uniforms is None else uniforms[n])
+            blk.edata[self.output_weight] = blk._edge_weights            # :100
+            seed_nodes = blk.srcdata[NID]                                # :121
+            blocks.insert(0, blk)
+        return seed_nodes, output_nodes, blocks
+
+
+class PoissonLadiesSampler(LadiesSampler):
+    """ladies_sampler.py:125-183."""
+
+    _poisson = True
+
+    def __init__(self, nodes_per_layer, importance_sampling=True, weight="w", out_weight="edge_weights",
+                 allow_zero_in_degree=False):
+        super().__init__(nodes_per_layer, importance_sampling, weight, out_weight, False, allow_zero_in_degree)

@@ -1,0 +1,37 @@
+"""Models over bliss Blocks with the reference's constructor and forward signatures (model.py).
+
+``SAGE(in_feats, n_hidden, n_classes, n_layers, activation, dropout).forward(blocks, x)`` stores the
+source-row norms the bandit reward needs on ``block.srcdata['embed_norm']`` (model.py:318-320) and
+runs the SAGEConv layers with the sampler's edge weights (model.py:321-329).
+"""
+import torch.nn as nn
+
+from .nn import SAGEConv, embed_norm
+
+
+class SAGE(nn.Module):
+    """model.py:292-333 (``inference`` = SURVEY 8f 'next' row, not built yet)."""
+
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout):
+        super().__init__()
+        self.n_layers, self.n_hidden, self.n_classes = n_layers, n_hidden, n_classes
+        self.layers = nn.ModuleList()
+        if n_layers > 1:
+            self.layers.append(SAGEConv(in_feats, n_hidden, "mean"))
+            for _ in range(1, n_layers - 1):
+                self.layers.append(SAGEConv(n_hidden, n_hidden, "mean"))
+            self.layers.append(SAGEConv(n_hidden, n_classes, "mean"))
+        else:
+            self.layers.append(SAGEConv(in_feats, n_classes, "mean"))
+        self.dropout = nn.Dropout(dropout)
+        self.activation = activation
+
+    def forward(self, blocks, x):
+        h = x
+        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+            block.srcdata["embed_norm"] = embed_norm(h)                       # model.py:318-320
+            h = layer(block, h, edge_weight=(block.edata["edge_weights"] if "edge_weights" in block.edata else None))
+            if l < len(self.layers) - 1:
+                h = self.activation(h)
+                h = self.dropout(h)
+        return h

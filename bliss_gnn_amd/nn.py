@@ -1,0 +1,106 @@
+"""Message-passing layers over bliss Blocks: the ``dglnn.SAGEConv`` the reference instantiates
+(model.py:303-308) with its g-SpMM replaced by the gfx950 kernels of csrc/spmm.hip.
+
+[DGL-recalled] dglnn.SAGEConv(in, out, 'mean'):  rst = fc_self(h[:S]) + fc_neigh o mean_w(h);
+fc_neigh (bias-free) is applied BEFORE aggregation iff in > out; fc_self carries the bias; both
+weights xavier-uniform with gain('relu').  The dense transforms are plain library GEMMs (hipBLASLt
+through torch.nn.functional.linear); the aggregation and its backward are ours.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._engine import _stream
+
+
+def embed_norm(h):
+    """``th.reshape(th.norm(h, dim=1, keepdim=True), (-1,))`` of model.py:318-320 -> bf16 [K]."""
+    h = h.detach()
+    if h.dtype != torch.bfloat16:
+        h = h.bfloat16()
+    if h.stride(1) != 1:
+        h = h.contiguous()
+    out = torch.empty(h.shape[0], dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.lib.bliss_embed_norm(h.data_ptr(), h.shape[0], h.shape[1], h.stride(0), out.data_ptr(), _stream()),
+               "bliss_embed_norm")
+    return out
+
+
+class _WeightedAggregate(torch.autograd.Function):
+    """out[i] = (1/deg_i if mean) * sum_{e -> i} w_e h[src_e]; gradient w.r.t. h only (the sampler's
+    edge weights carry no grad)."""
+
+    @staticmethod
+    def forward(ctx, h, block, edge_weight, mean, out_fp32):
+        assert h.is_cuda and h.dtype == torch.bfloat16, "bf16 features on the GPU (load_graph.py:7)"
+        if h.stride(1) != 1:
+            h = h.contiguous()
+        S, D = block.num_dst_nodes(), h.shape[1]
+        out = torch.empty(S, D, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=h.device)
+        w = None
+        if edge_weight is not None:
+            w = edge_weight.reshape(-1)
+            if w.dtype != torch.bfloat16:
+                w = w.bfloat16()
+            w = w.contiguous()
+            assert w.numel() == block.num_edges()
+        _lib.check(_lib.lib.bliss_spmm_fwd(block.indptr.data_ptr(), block.src.data_ptr(), 0 if w is None else w.data_ptr(),
+                                           h.data_ptr(), h.stride(0), S, D, int(mean), out.data_ptr(), out.stride(0),
+                                           int(out_fp32), _stream()), "bliss_spmm_fwd")
+        ctx.block, ctx.w, ctx.mean, ctx.n_src = block, w, mean, h.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        block, w = ctx.block, ctx.w
+        gout = gout.contiguous()
+        if gout.dtype != torch.bfloat16:
+            gout = gout.bfloat16()
+        D = gout.shape[1]
+        t_indptr, t_edge = block.transposed()
+        gh = torch.empty(ctx.n_src, D, dtype=torch.bfloat16, device=gout.device)
+        _lib.check(_lib.lib.bliss_spmm_bwd(t_indptr.data_ptr(), t_edge.data_ptr(), block.dst.data_ptr(),
+                                           block.indptr.data_ptr(), 0 if w is None else w.data_ptr(), gout.data_ptr(),
+                                           gout.stride(0), ctx.n_src, D, int(ctx.mean), gh.data_ptr(), gh.stride(0), 0,
+                                           _stream()), "bliss_spmm_bwd")
+        return gh, None, None, None, None
+
+
+def weighted_aggregate(block, h, edge_weight=None, mean=True, out_fp32=False):
+    return _WeightedAggregate.apply(h, block, edge_weight, mean, out_fp32)
+
+
+class SAGEConv(nn.Module):
+    """dglnn.SAGEConv(in_feats, out_feats, 'mean') as used at model.py:303-308, 321-329."""
+
+    def __init__(self, in_feats, out_feats, aggregator_type="mean", feat_drop=0.0, bias=True, norm=None, activation=None):
+        super().__init__()
+        if aggregator_type != "mean":
+            raise NotImplementedError("the reference only builds SAGEConv(..., 'mean') (model.py:303-308)")
+        self._in_src_feats = self._in_dst_feats = in_feats
+        self._out_feats = out_feats
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.norm, self.activation = norm, activation
+        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=False)
+        self.fc_self = nn.Linear(in_feats, out_feats, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+    def forward(self, graph, feat, edge_weight=None):
+        feat_src = self.feat_drop(feat)
+        feat_dst = feat_src[: graph.num_dst_nodes()]
+        lin_before_mp = self._in_src_feats > self._out_feats
+        if lin_before_mp:
+            h_neigh = weighted_aggregate(graph, self.fc_neigh(feat_src), edge_weight, mean=True)
+        else:
+            h_neigh = self.fc_neigh(weighted_aggregate(graph, feat_src, edge_weight, mean=True))
+        rst = self.fc_self(feat_dst) + h_neigh
+        if self.activation is not None:
+            rst = self.activation(rst)
+        if self.norm is not None:
+            rst = self.norm(rst)
+        return rst

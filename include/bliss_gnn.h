@@ -1,0 +1,156 @@
+/* bliss_gnn.h -- C ABI of libbliss_gnn.so, the MI355X (gfx950) implementation of the BLISS-GNN
+ * hot path: layer-wise bandit / LADIES block sampling, per-block weighted SpMM, EXP3 update.
+ *
+ * The reference (linhthi/BLISS-GNN) has no FFI of its own: its boundary is the Python protocol
+ * between dgl.dataloading.DataLoader / Lightning and the sampler + model classes.
+ * Each entry point below therefore names the reference METHOD whose body it replaces; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and is what
+ * bliss_gnn_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it points to one of the small descriptor structs
+ *     below, which live on the host and only carry device pointers and sizes;
+ *   - "bf16" = raw bfloat16 bits (uint16_t), passed as void*;
+ *   - node / edge ids are int32 (train_lightning.py:340-342 casts the graph to int32), CSC
+ *     indptr is int64;
+ *   - `stream` is a hipStream_t cast to void* (NULL = default stream); nothing here
+ *     synchronises, allocates or frees: all entry points are graph-capturable;
+ *   - return value: 0 on success, a hipError_t (> 0) from the runtime, or BLISS_E* (< 0).
+ *     Data-dependent failures (capacity, non-finite weights) are reported through the `err`
+ *     word of the per-layer counts record, read by the caller together with the sizes.
+ */
+#ifndef BLISS_GNN_H
+#define BLISS_GNN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLISS_EINVAL (-1)
+
+#define BLISS_MODE_BANDIT 0   /* EXP3 edge probabilities  (bandit_sampler.py) */
+#define BLISS_MODE_LADIES 1   /* static edge weights      (ladies_sampler.py) */
+
+/* The message graph g as the sampler sees it (train_lightning.py:373: CSC only). */
+typedef struct {
+  const int64_t* indptr;    /* [num_nodes + 1] */
+  const int32_t* indices;   /* [num_edges] source of every in-edge, grouped by destination */
+  const int32_t* eid;       /* [num_edges] edge id of every CSC position, or NULL = identity */
+  int32_t num_nodes;
+  int64_t num_edges;
+} bliss_graph_t;
+
+/* Dense per-node scratch, owned by one sampler, clean between calls
+ * (local_id = -1, first_pos = 0xFFFFFFFF, acc_p2 = 0). */
+typedef struct {
+  int32_t* local_id;        /* [num_nodes] */
+  uint32_t* first_pos;      /* [num_nodes] */
+  uint64_t* acc_p2;         /* [num_nodes] */
+} bliss_node_maps_t;
+
+/* Per-layer counts record (device).  Layout fixed: 8 x int32 then one double. */
+typedef struct {
+  int32_t S, E, C, K, B;    /* seeds, frontier edges, candidates, kept nodes, block edges */
+  int32_t err;              /* BLISS_ERR_* bits, 0 = ok */
+  int32_t iters;            /* evaluations of the Poisson fixed point (bandit_sampler.py:396) */
+  int32_t all_one;          /* 1 if C <= fanout (bandit_sampler.py:392) */
+  double c;                 /* Poisson scale */
+} bliss_layer_counts_t;
+
+/* Per-layer workspace (all device memory, caller allocated). */
+typedef struct {
+  void* counts;             /* bliss_layer_counts_t */
+  int32_t* seg_ptr;         /* [n_seeds + 1] start of every seed's column in the frontier */
+  void* seed_acc;           /* [32 * n_seeds bytes] exact per-seed accumulators */
+  int32_t* chunk_cnt;       /* [max(frontier_bound, cap_c) / 1024 + 2] */
+  int32_t* cand_nid;        /* [cap_c] global id of every candidate, seeds first (ndata[NID]) */
+  void* p;                  /* bf16 [cap_c] LADIES importance p_j */
+  void* P;                  /* bf16 [cap_c] inclusion probability P_j */
+  int32_t* new_id;          /* [cap_c] block-local id of a kept candidate, -1 otherwise */
+  int32_t* kept_nid;        /* [cap_k] global id of every kept node (block srcdata[NID]) */
+  void* node_prob;          /* bf16 [cap_k] srcdata['node_prob'] */
+  int32_t cap_c, cap_k;
+} bliss_layer_ws_t;
+
+/* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
+typedef struct {
+  int32_t* indptr;          /* [n_seeds + 1] */
+  int32_t* src;             /* [cap_b] block-local source id */
+  int32_t* dst;             /* [cap_b] block-local destination id (= seed index) */
+  int32_t* pos;             /* [cap_b] CSC position in g of every block edge */
+  int32_t* eid;             /* [cap_b] edata[dgl.EID] */
+  void* edge_weights;       /* bf16 [cap_b] edata['edge_weights'] */
+  void* q_ij;               /* bf16 [cap_b] edata['q_ij'] (bandit) / the static weight (ladies) */
+  int32_t cap_b;
+} bliss_block_out_t;
+
+int bliss_layer_counts_bytes(void);
+
+/* exp3_probabilities + BanditLadiesSampler.compute_prob      bandit_sampler.py:101-138, :47-82
+ * LadiesSampler.compute_prob                                 ladies_sampler.py:34-52
+ * In: seeds [n_seeds] (unique).  w_pos: bf16 [num_edges] in CSC-position order -- the layer's
+ * exp3_weights row (BANDIT) or g.edata['w'] (LADIES).  eta_f = (float)eta,
+ * one_minus_eta_f = (float)(1.0 - eta).  frontier_bound >= number of in-edges of the seeds
+ * (num_edges is always valid).  Out (in ws): counts{S,E,C}, seg_ptr, cand_nid, p; the node maps
+ * hold local ids of all candidates until bliss_build_block cleans them. */
+int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* maps, const void* w_pos,
+                        const int32_t* seeds, int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f,
+                        int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream);
+
+/* PoissonBanditLadiesSampler.compute_prob (scale c, :391-406) + select_neighbors (:408-425).
+ * uniforms: fp32 [>= C], the values torch.rand(C) draws from the CPU generator (ATen's serial
+ * Bernoulli kernel consumes the same 24-bit stream).  Out: counts{K,c,iters,all_one}, P, new_id,
+ * kept_nid, node_prob. */
+int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps, const float* uniforms,
+                         int64_t cand_bound, void* stream);
+
+/* generate_block      bandit_sampler.py:269-339 (BANDIT: Hajek weights) / ladies_sampler.py:71-107.
+ * Same g, maps, w_pos, seeds, eta as the matching bliss_frontier_prob call.  Out: counts{B}, the block;
+ * leaves the node maps clean. */
+int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* maps, const void* w_pos,
+                      const int32_t* seeds, int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f,
+                      int64_t frontier_bound, const bliss_layer_ws_t* ws, const bliss_block_out_t* out, void* stream);
+
+/* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
+int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);
+
+/* th.norm(h, dim=1)   model.py:318-320: embed_norm[j] = ||h_j||_2, fp32 accumulation, bf16 out. */
+int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_stride, void* out, void* stream);
+
+/* SAGEConv 'mean' message passing with edge weights [DGL-recalled: update_all(u_mul_e, mean)],
+ * model.py:321-329.  out[i,:] = (1/max(deg_i,1)) * sum_{e in row i} w_e * h[src_e,:]  (mean != 0)
+ * or the plain weighted sum (mean == 0).  h bf16 [n_src, dim] (row stride in elements), w bf16
+ * [nnz] or NULL (= 1), out bf16 (out_fp32 == 0) or fp32 [n_dst, dim]. */
+int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const void* w, const void* h, int64_t h_stride,
+                   int32_t n_dst, int32_t dim, int mean, void* out, int64_t out_stride, int out_fp32, void* stream);
+
+/* Backward of the above w.r.t. h: gh[j,:] = sum_{e: src_e = j} (w_e / max(deg_dst(e),1)) * gout[dst_e,:].
+ * t_indptr [n_src+1], t_edge [nnz]: the block's edges grouped by SOURCE (bliss_block_transpose). */
+int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* dst, const int32_t* indptr,
+                   const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t dim, int mean,
+                   void* gh, int64_t gh_stride, int out_fp32, void* stream);
+
+/* calculate_alpha (SAGE/GCN) + calculate_rewards + update_exp3_weights up to the scatter,
+ * bandit_sampler.py:157, :180-193, :221-248.  One launch per block.
+ * edge_w_pos: g.edata['w'] by CSC position.  w_pos: the layer's exp3 row (updated in place).
+ * row_sum: int64[3] exact running sum of the row (32-bit limbs, value * 2^64), updated.
+ * rewards_out: bf16 [n_edges] edata['rewards'] or NULL. */
+int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_pos, int64_t* row_sum,
+                      const int32_t* blk_indptr, const int32_t* blk_src, const int32_t* blk_dst,
+                      const int32_t* blk_pos, const void* q_ij, const void* node_prob, const void* embed_norm,
+                      const void* alpha_or_null, const int32_t* dst_nid, int32_t n_dst, const int32_t* n_edges_dev,
+                      int32_t edges_bound, float delta_f, void* rewards_out, int32_t* err, void* stream);
+
+/* F.normalize(row, p=1, dim=0), bandit_sampler.py:249, bit-exact: norm = bf16(exact sum).  The pass
+ * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[4]. */
+int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64_t* scratch, void* norm_out_bf16,
+                         void* stream);
+
+/* Exact row sum from scratch (initialisation / verification): row_sum int64[3]. */
+int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,41 @@
+"""CPU suite: the C-ABI library builds, loads, and exports every symbol include/bliss_gnn.h declares
+(no compute calls here -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "bliss_gnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(bliss_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from bliss_gnn_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/bliss_gnn.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in bliss_gnn_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_counts_struct_layout():
+    from bliss_gnn_amd import _lib
+    assert ctypes.sizeof(_lib.LayerCounts) == 40 == _lib.lib.bliss_layer_counts_bytes()
+    assert _lib.LayerCounts.c.offset == 32
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bliss_gnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

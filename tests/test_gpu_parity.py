@@ -1,0 +1,333 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against
+  (a) the golden vectors produced by running the reference (bit-exact),
+  (b) the oracle on seeded random graphs (bit-exact for ids / bf16 sampler state),
+  (c) an fp32 torch reference for the floating-point kernels (tolerance written in each test).
+Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16_bits, bits_to_bf16, golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _bg():
+    import bliss_gnn_amd as bg
+    return bg
+
+
+def _graphs(z, dev):
+    from oracle import bliss_oracle as bo
+    bg = _bg()
+    ip, ix, ei = torch.from_numpy(z["indptr"]), torch.from_numpy(z["indices"]), torch.from_numpy(z["eid"])
+    g = bg.Graph(ip.to(dev), ix.to(dev), ei.to(dev))
+    g.edata["w"] = bg.normalized_edata(g)
+    return g, bo.CSC(ip, ix, ei)
+
+
+def _check_block(z, prefix, blk, bandit):
+    bg = _bg()
+    assert np.array_equal(z[prefix + "src"], blk.src.cpu().numpy())
+    assert np.array_equal(z[prefix + "dst"], blk.dst.cpu().numpy())
+    assert np.array_equal(z[prefix + "eid"], blk.edata[bg.EID].cpu().numpy())
+    assert np.array_equal(z[prefix + "src_nid"], blk.srcdata[bg.NID].cpu().numpy())
+    assert np.array_equal(z[prefix + "dst_nid"], blk.dstdata[bg.NID].cpu().numpy())
+    assert np.array_equal(z[prefix + "edge_weights"], bf16_bits(blk.edata["edge_weights"]))
+    if bandit:
+        assert np.array_equal(z[prefix + "q_ij"], bf16_bits(blk.edata["q_ij"]))
+        assert np.array_equal(z[prefix + "node_prob"], bf16_bits(blk.srcdata["node_prob"]))
+
+
+@pytest.mark.parametrize("name", golden_cases("poisson_bandit"))
+def test_poisson_bandit_golden(cuda, name):
+    """sample_blocks + exp3 over consecutive steps == the reference run, bit for bit."""
+    bg = _bg()
+    z = load_golden(name)
+    g, _ = _graphs(z, cuda)
+    assert np.array_equal(z["edge_w"], bf16_bits(g.edata["w"]))                 # normalized_edata
+    fanouts, eta, seed = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"])
+    sampler = bg.PoissonBanditLadiesSampler(fanouts, importance_sampling=1, node_embedding="features", num_steps=1000,
+                                            eta=eta, model="sage")
+    for step in range(int(z["n_steps"])):
+        seeds = torch.from_numpy(z[f"s{step}_seeds"]).to(cuda)
+        torch.manual_seed(seed + step)
+        inp, outp, blocks = sampler.sample_blocks(g, seeds)
+        assert outp is seeds
+        for l, blk in enumerate(blocks):
+            _check_block(z, f"s{step}_l{l}_", blk, True)
+            assert blk._counts.c == float(z[f"s{step}_l{l}_c"])
+            assert blk._counts.E == int(z[f"s{step}_l{l}_E"])
+            assert np.array_equal(z[f"s{step}_l{l}_cand_nid"], blk._trace["cand_nid"].cpu().numpy())
+            assert np.array_equal(z[f"s{step}_l{l}_p"], bf16_bits(blk._trace["p"]))
+            assert np.array_equal(z[f"s{step}_l{l}_P"], bf16_bits(blk._trace["P"]))
+            blk.srcdata["embed_norm"] = bits_to_bf16(z[f"s{step}_l{l}_embed_norm"]).to(cuda)
+        assert torch.equal(inp, blocks[0].srcdata[bg.NID])
+        sampler.exp3(blocks, g)
+        sampler.check_errors()
+        for l, blk in enumerate(blocks):
+            assert np.array_equal(z[f"s{step}_l{l}_rewards"], bf16_bits(blk.edata["rewards"]))
+        assert np.array_equal(z[f"s{step}_exp3_weights"], bf16_bits(sampler.exp3_weights))
+
+
+@pytest.mark.parametrize("name", golden_cases("poisson_ladies"))
+def test_poisson_ladies_golden(cuda, name):
+    bg = _bg()
+    z = load_golden(name)
+    g, _ = _graphs(z, cuda)
+    sampler = bg.PoissonLadiesSampler(z["fanouts"].tolist())
+    torch.manual_seed(int(z["torch_seed"]))
+    _, _, blocks = sampler.sample_blocks(g, torch.from_numpy(z["seeds"]).to(cuda))
+    for l, blk in enumerate(blocks):
+        _check_block(z, f"l{l}_", blk, False)
+
+
+@pytest.mark.parametrize("V,E,fan,batch,eta,seed", [
+    (3000, 60000, [256, 128, 64], 48, 0.1, 0),
+    (20000, 400000, [1024, 512, 256], 128, 0.1, 1),
+    (5000, 15000, [4096, 2048, 1024], 64, 0.4, 2),       # fanout > candidates: the C <= fanout early-out
+    (50000, 2000000, [2048, 1024, 512], 256, 0.1, 3),    # long columns, many waves per destination
+])
+def test_bandit_vs_oracle_random_graphs(cuda, V, E, fan, batch, eta, seed):
+    """Three consecutive train steps on seeded graphs the oracle finishes in seconds: ids, probabilities,
+    Hajek weights, rewards and the evolving exp3 state all bit-exact."""
+    from oracle import bliss_oracle as bo
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(V, E, seed=seed)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    g.edata["w"] = bg.normalized_edata(g)
+    og = bo.CSC(ip, ix, ei)
+    edge_w = bo.normalized_edata(og)
+    assert torch.equal(edge_w.view(torch.int16), g.edata["w"].cpu().view(torch.int16))
+    sampler = bg.PoissonBanditLadiesSampler(fan, eta=eta)
+    o_w = torch.ones(3, og.num_edges, dtype=torch.bfloat16)
+    gen = torch.Generator().manual_seed(100 + seed)
+    for step in range(3):
+        seeds = torch.randperm(V, generator=gen)[:batch].to(torch.int32)
+        torch.manual_seed(step)
+        inp, _, blocks = sampler.sample_blocks(g, seeds.to(cuda))
+        torch.manual_seed(step)
+        o_inp, _, o_blocks = bo.sample_blocks_bandit(og, seeds, fan, o_w, eta)
+        assert torch.equal(inp.cpu().long(), o_inp)
+        embed = []
+        for b, ob in zip(blocks, o_blocks):
+            assert b._counts.E == ob.trace["E"] and b._counts.c == ob.trace["c"] and b._counts.iters == ob.trace["iters"]
+            assert torch.equal(b._trace["cand_nid"].cpu().long(), ob.trace["cand_nid"])
+            assert torch.equal(b._trace["p"].cpu().view(torch.int16), ob.trace["p"].view(torch.int16))
+            assert torch.equal(b._trace["P"].cpu().view(torch.int16), ob.trace["P"].view(torch.int16))
+            assert torch.equal(b.indptr.cpu().long(), ob.indptr)
+            assert torch.equal(b.src.cpu().long(), ob.src) and torch.equal(b.dst.cpu().long(), ob.dst)
+            assert torch.equal(b.edata[bg.EID].cpu().long(), ob.eid)
+            assert torch.equal(b.srcdata[bg.NID].cpu().long(), ob.src_nid)
+            for mine, ref in ((b.edata["edge_weights"], ob.edge_weights), (b.edata["q_ij"], ob.q_ij),
+                              (b.srcdata["node_prob"], ob.node_prob)):
+                assert torch.equal(mine.cpu().view(torch.int16), ref.view(torch.int16))
+            en = (torch.rand(ob.n_src, generator=gen) * 40).bfloat16()
+            b.srcdata["embed_norm"] = en.to(cuda)
+            embed.append(en)
+        sampler.exp3(blocks, g)
+        sampler.check_errors()
+        o_w, traces = bo.exp3(og, o_blocks, o_w, edge_w, embed)
+        for b, tr in zip(blocks, traces):
+            assert torch.equal(b.edata["rewards"].cpu().view(torch.int16), tr["rewards"].view(torch.int16))
+        assert torch.equal(sampler.exp3_weights.cpu().view(torch.int16), o_w.view(torch.int16))
+
+
+def test_empty_and_ragged_inputs(cuda):
+    """Zero-in-degree seeds (empty columns), a single seed, seeds without self loops."""
+    from oracle import bliss_oracle as bo
+    bg = _bg()
+    # node 0: no in-edges, node 1: one in-edge from 3, node 2: in-edges from 0,1 ; no self loops
+    ip = torch.tensor([0, 0, 1, 3, 3, 3])
+    ix = torch.tensor([3, 0, 1], dtype=torch.int32)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda))
+    og = bo.CSC(ip, ix)
+    for seeds in ([0, 2, 1], [2], [1, 0]):
+        s = torch.tensor(seeds, dtype=torch.int32)
+        sampler = bg.PoissonBanditLadiesSampler([8], eta=0.1)
+        torch.manual_seed(0)
+        inp, _, (b,) = sampler.sample_blocks(g, s.to(cuda))
+        torch.manual_seed(0)
+        o_inp, _, (ob,) = bo.sample_blocks_bandit(og, s, [8], torch.ones(1, 3, dtype=torch.bfloat16), 0.1)
+        assert torch.equal(inp.cpu().long(), o_inp)
+        assert torch.equal(b.indptr.cpu().long(), ob.indptr) and torch.equal(b.src.cpu().long(), ob.src)
+        assert torch.equal(b.edata["edge_weights"].cpu().view(torch.int16), ob.edge_weights.view(torch.int16))
+
+
+def test_explicit_uniforms_and_inclusion_frequency(cuda):
+    """empirical inclusion frequency of every candidate ~= P_j."""
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(800, 12000, seed=4)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    sampler = bg.PoissonBanditLadiesSampler([40], eta=0.1)
+    seeds = torch.arange(0, 16, dtype=torch.int32, device=cuda)
+    gen = torch.Generator().manual_seed(0)
+    hits, P, nid = None, None, None
+    n_rep = 400
+    for _ in range(n_rep):
+        u = torch.rand(800, generator=gen)
+        _, _, (b,) = sampler.sample_blocks(g, seeds, uniforms=[u])
+        kept = (b._trace["new_id"] >= 0).float().cpu()
+        hits = kept if hits is None else hits + kept
+        P = b._trace["P"].float().cpu()
+    freq = hits / n_rep
+    sigma = (P * (1 - P) / n_rep).sqrt() + 1e-3
+    assert ((freq - P).abs() < 5 * sigma).all()
+    assert (freq[:16] == 1).all()                                             # seeds are always kept
+
+
+def test_spmm_forward_backward_vs_fp32(cuda):
+    """m3/m6: weighted-mean SpMM and its transposed backward.  fp32 output: <= 1e-4 rel (north star);
+    bf16 output: within one bf16 rounding of the fp32 result."""
+    from bliss_gnn_amd.nn import weighted_aggregate
+    from bliss_gnn_amd.graph import Block
+    gen = torch.Generator().manual_seed(0)
+    for (K, S, B, D) in [(500, 60, 4000, 256), (300, 40, 1500, 41), (1000, 100, 20000, 64), (50, 50, 50, 602), (64, 8, 0, 16)]:
+        dst = torch.sort(torch.randint(0, S, (B,), generator=gen))[0]
+        src = torch.randint(0, K, (B,), generator=gen)
+        indptr = torch.zeros(S + 1, dtype=torch.int64)
+        indptr[1:] = torch.cumsum(torch.bincount(dst, minlength=S), 0)
+        w = torch.rand(B, generator=gen).bfloat16()
+        h = torch.randn(K, D, generator=gen).bfloat16()
+        blk = Block(None, K, S, indptr.to(torch.int32).to(cuda), src.to(torch.int32).to(cuda), dst.to(torch.int32).to(cuda),
+                    torch.zeros(B, dtype=torch.int32, device=cuda), torch.zeros(B, dtype=torch.int32, device=cuda),
+                    torch.arange(K, dtype=torch.int32, device=cuda))
+        deg = (indptr[1:] - indptr[:-1]).clamp(min=1).float()
+        ref = torch.zeros(S, D).index_add_(0, dst, h.float()[src] * w.float()[:, None]) / deg[:, None]
+        hd = h.to(cuda).requires_grad_(True)
+        out32 = weighted_aggregate(blk, hd, w.to(cuda), mean=True, out_fp32=True)
+        assert torch.allclose(out32.cpu(), ref, rtol=1e-4, atol=1e-5)
+        out16 = weighted_aggregate(blk, hd, w.to(cuda), mean=True)
+        assert (out16.float().cpu() - ref).abs().max() <= (ref.abs() * 2 ** -8 + 1e-6).max()
+        gout = torch.randn(S, D, generator=gen).bfloat16()
+        out16.backward(gout.to(cuda))
+        coef = w.float() / deg[dst]
+        gref = torch.zeros(K, D).index_add_(0, src, gout.float()[dst] * coef[:, None])
+        assert (hd.grad.float().cpu() - gref).abs().max() <= (gref.abs().max() * 2 ** -8 + 1e-6)
+        # unweighted sum (edge_weight=None, mean=False)
+        out_sum = weighted_aggregate(blk, hd, None, mean=False, out_fp32=True)
+        ref_sum = torch.zeros(S, D).index_add_(0, dst, h.float()[src])
+        assert torch.allclose(out_sum.cpu(), ref_sum, rtol=1e-4, atol=1e-5)
+
+
+def test_embed_norm_vs_fp32(cuda):
+    from bliss_gnn_amd.nn import embed_norm
+    gen = torch.Generator().manual_seed(1)
+    for K, D in [(100, 602), (257, 256), (33, 41), (5, 1433)]:
+        h = (torch.randn(K, D, generator=gen) * 3).bfloat16()
+        ref = torch.linalg.vector_norm(h.float(), dim=1)
+        got = embed_norm(h.to(cuda)).float().cpu()
+        assert ((got - ref).abs() <= ref * 2 ** -8).all()          # one bf16 rounding of an fp32 result
+
+
+def test_sage_forward_matches_oracle(cuda):
+    """a17/a18: SAGE.forward activations vs the fp32 oracle.  Layers are bf16 (train_lightning.py:618),
+    so the comparison is against the oracle fed the same bf16 weights; tolerance 2 bf16 ulps of the
+    row scale per layer."""
+    from oracle import bliss_oracle as bo
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(2000, 30000, seed=8)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    feats = torch.randn(2000, 96, generator=torch.Generator().manual_seed(2)).bfloat16()
+    g.ndata["features"] = feats.to(cuda)
+    sampler = bg.PoissonBanditLadiesSampler([128, 64, 32], eta=0.1)
+    seeds = torch.arange(100, 132, dtype=torch.int32)
+    torch.manual_seed(3)
+    inp, _, blocks = sampler.sample_blocks(g, seeds.to(cuda))
+    torch.manual_seed(3)
+    _, _, o_blocks = bo.sample_blocks_bandit(bo.CSC(ip, ix, ei), seeds, [128, 64, 32], torch.ones(3, ip[-1], dtype=torch.bfloat16), 0.1)
+    torch.manual_seed(0)
+    model = SAGE(96, 64, 7, 3, torch.relu, 0.0).to(cuda).bfloat16()
+    x = blocks[0].srcdata["features"]
+    assert torch.equal(x.cpu(), feats[inp.cpu().long()])
+    h = x
+    ho = x.cpu().float()
+    for l, (layer, blk, ob) in enumerate(zip(model.layers, blocks, o_blocks)):
+        h_in = h
+        h = layer(blk, h, edge_weight=blk.edata["edge_weights"])
+        ref = bo.sage_conv_ref(ob, h_in.cpu(), layer.fc_self.weight.cpu(), layer.fc_self.bias.cpu(), layer.fc_neigh.weight.cpu(),
+                               ob.edge_weights)
+        scale = ref.abs().max()
+        assert (h.float().cpu() - ref).abs().max() <= 4 * scale * 2 ** -8, f"layer {l}"
+        if l < 2:
+            h = torch.relu(h)
+    out = model(blocks, x)
+    for blk, ob in zip(blocks, o_blocks):
+        assert "embed_norm" in blk.srcdata and blk.srcdata["embed_norm"].shape[0] == ob.n_src
+    out.float().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in model.parameters())
+
+
+def test_exp3_update_exp_table(cuda):
+    """Drive k_exp3_update so that delta_reward sweeps every bf16 value in [0, 1]: q_ij = 1, embed_norm = 1,
+    alpha = 1, k_i = n_i = 1, delta = 1, node_prob = 1/x' chosen from the bf16 grid, then compare the updated
+    weight with torch CPU arithmetic step by step (the oracle's formula)."""
+    from oracle import bliss_oracle as bo
+    from bliss_gnn_amd import _lib
+    import ctypes as C
+    cand = torch.arange(0x0080, 0x7F80, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)   # all positive normals
+    one = torch.ones_like(cand)
+    dr = (one / cand) * (1.0 / one)                                           # what the kernel will compute as delta_reward
+    n = cand.numel()
+    dev = cuda
+    ipd = torch.arange(0, n + 1, dtype=torch.int64, device=dev)
+    g = _lib.Graph(ipd.data_ptr(), 0, 0, n, n)
+    blk_indptr = torch.arange(0, n + 1, dtype=torch.int32, device=dev)
+    ar = torch.arange(n, dtype=torch.int32, device=dev)
+    w = torch.full((n,), 0.5, dtype=torch.bfloat16, device=dev)
+    ones = torch.ones(n, dtype=torch.bfloat16, device=dev)
+    row_sum = torch.zeros(3, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    nE = torch.tensor([n], dtype=torch.int32, device=dev)
+    rewards = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib.bliss_row_sum(w.data_ptr(), n, row_sum.data_ptr(), 0), "row_sum")
+    _lib.check(_lib.lib.bliss_exp3_update(C.byref(g), ones.data_ptr(), w.data_ptr(), row_sum.data_ptr(), blk_indptr.data_ptr(),
+                                          ar.data_ptr(), ar.data_ptr(), ar.data_ptr(), ones.data_ptr(), cand.to(dev).data_ptr(),
+                                          ones.data_ptr(), 0, ar.data_ptr(), n, nE.data_ptr(), n, 1.0, rewards.data_ptr(),
+                                          err.data_ptr(), 0), "exp3_update")
+    torch.cuda.synchronize()
+    d = dr.clone(); d[d > 1] = 1
+    expect = torch.full((n,), 0.5, dtype=torch.bfloat16) * torch.exp(d)
+    assert torch.equal(w.cpu().view(torch.int16), expect.view(torch.int16)), \
+        f"{(w.cpu().view(torch.int16) != expect.view(torch.int16)).sum().item()} exp() results differ from torch CPU"
+    # and the incrementally maintained exact row sum equals a from-scratch one
+    rs2 = torch.zeros(3, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib.bliss_row_sum(w.data_ptr(), n, rs2.data_ptr(), 0), "row_sum")
+    tot = lambda r: int(r[0]) + (int(r[1]) << 32) + (int(r[2]) << 64)
+    assert tot(row_sum.cpu()) == tot(rs2.cpu())
+    from oracle import numerics as nx
+    assert tot(rs2.cpu()) == nx.row_exact_sum(w.cpu())
+
+
+def test_exp_exhaustive_over_unit_interval(cuda):
+    """EVERY bf16 delta_reward in [0, 1] (bandit_sampler.py:244-246 clamps to 1): one single-edge launch per
+    value with delta = y, everything else 1, so that delta_reward == y exactly; compare with torch CPU exp."""
+    from bliss_gnn_amd import _lib
+    import ctypes as C
+    ys = torch.arange(0, 0x3F81, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)      # +0 .. 1.0
+    n = ys.numel()
+    dev = cuda
+    ipd = torch.arange(0, n + 1, dtype=torch.int64, device=dev)
+    g = _lib.Graph(ipd.data_ptr(), 0, 0, n, n)
+    one_ptr = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+    zero = torch.zeros(1, dtype=torch.int32, device=dev)
+    ar = torch.arange(n, dtype=torch.int32, device=dev)
+    w = torch.full((n,), 0.75, dtype=torch.bfloat16, device=dev)
+    ones = torch.ones(n, dtype=torch.bfloat16, device=dev)
+    row_sum = torch.zeros(3, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    nE = torch.tensor([1], dtype=torch.int32, device=dev)
+    for i, y in enumerate(ys.float().tolist()):
+        _lib.check(_lib.lib.bliss_exp3_update(C.byref(g), ones.data_ptr(), w.data_ptr(), row_sum.data_ptr(), one_ptr.data_ptr(),
+                                              zero.data_ptr(), zero.data_ptr(), ar[i:].data_ptr(), ones.data_ptr(), ones.data_ptr(),
+                                              ones.data_ptr(), 0, zero.data_ptr(), 1, nE.data_ptr(), 1, y, 0, err.data_ptr(), 0),
+                   "exp3_update")
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    expect = torch.full((n,), 0.75, dtype=torch.bfloat16) * torch.exp(ys)
+    bad = (w.cpu().view(torch.int16) != expect.view(torch.int16))
+    assert not bad.any(), f"exp differs from torch CPU for {bad.sum().item()} inputs, first y={ys[bad][0].item()}"

@@ -1,0 +1,131 @@
+"""CPU suite: the oracle against the golden vectors produced by RUNNING the reference
+(tests/golden/make_golden.py), the toy known-answer test of SURVEY.md section 4, and the
+arithmetic contract helpers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16_bits, bits_to_bf16, golden_cases, load_golden
+from oracle import bliss_oracle as bo
+from oracle import numerics as nx
+
+
+def _graph(z):
+    return bo.CSC(torch.from_numpy(z["indptr"]), torch.from_numpy(z["indices"]), torch.from_numpy(z["eid"]))
+
+
+def _check_block(z, prefix, blk, bandit):
+    assert np.array_equal(z[prefix + "src"], blk.src.numpy())
+    assert np.array_equal(z[prefix + "dst"], blk.dst.numpy())
+    assert np.array_equal(z[prefix + "eid"], blk.eid.numpy())
+    assert np.array_equal(z[prefix + "src_nid"], blk.src_nid.numpy())
+    assert np.array_equal(z[prefix + "dst_nid"], blk.dst_nid.numpy())
+    assert np.array_equal(z[prefix + "edge_weights"], bf16_bits(blk.edge_weights))
+    if bandit:
+        assert np.array_equal(z[prefix + "q_ij"], bf16_bits(blk.q_ij))
+        assert np.array_equal(z[prefix + "node_prob"], bf16_bits(blk.node_prob))
+
+
+@pytest.mark.parametrize("name", golden_cases("bandit"))
+def test_bandit_matches_reference_run(name):
+    z = load_golden(name)
+    g = _graph(z)
+    fanouts, eta, seed = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"])
+    poisson = bool(int(z["poisson"]))
+    edge_w = bo.normalized_edata(g)
+    assert np.array_equal(z["edge_w"], bf16_bits(edge_w))
+    w = torch.ones(len(fanouts), g.num_edges, dtype=torch.bfloat16)
+    for step in range(int(z["n_steps"])):
+        seeds = torch.from_numpy(z[f"s{step}_seeds"])
+        torch.manual_seed(seed + step)
+        inp, outp, blocks = bo.sample_blocks_bandit(g, seeds, fanouts, w, eta, poisson=poisson)
+        embed = []
+        for l, blk in enumerate(blocks):
+            _check_block(z, f"s{step}_l{l}_", blk, True)
+            assert float(z[f"s{step}_l{l}_c"]) == blk.trace["c"]
+            embed.append(bits_to_bf16(z[f"s{step}_l{l}_embed_norm"]))
+        w, traces = bo.exp3(g, blocks, w, edge_w, embed)
+        for l, tr in enumerate(traces):
+            assert np.array_equal(z[f"s{step}_l{l}_rewards"], bf16_bits(tr["rewards"]))
+        assert np.array_equal(z[f"s{step}_exp3_weights"], bf16_bits(w))
+
+
+@pytest.mark.parametrize("name", golden_cases("ladies"))
+def test_ladies_matches_reference_run(name):
+    z = load_golden(name)
+    g = _graph(z)
+    edge_w = bits_to_bf16(z["edge_w"])
+    torch.manual_seed(int(z["torch_seed"]))
+    _, _, blocks = bo.sample_blocks_ladies(g, torch.from_numpy(z["seeds"]), z["fanouts"].tolist(), edge_w,
+                                           poisson=bool(int(z["poisson"])))
+    for l, blk in enumerate(blocks):
+        _check_block(z, f"l{l}_", blk, False)
+
+
+def test_toy_known_answers():
+    """SURVEY.md section 4 item 1 (ToyDataset, load_graph.py:96 + self loops), probed with plain torch."""
+    g = bo.CSC(torch.tensor([0, 3, 6, 7, 8, 9]), torch.tensor([2, 3, 0, 3, 4, 1, 2, 3, 4], dtype=torch.int32),
+               torch.tensor([0, 1, 4, 2, 3, 5, 6, 7, 8], dtype=torch.int32))
+    for eta in (0.1, 0.4):
+        torch.manual_seed(0)
+        _, _, (b,) = bo.sample_blocks_bandit(g, torch.tensor([0, 1]), [2], torch.ones(1, 9, dtype=torch.bfloat16), eta)
+        t = b.trace
+        assert b.src.tolist() == [2, 3, 0, 3, 4, 1] and t["cand_nid"].tolist() == [0, 1, 2, 3, 4]
+        assert t["q"].float().tolist() == [0.333984375] * 6
+        assert t["p"].float().tolist() == [0.333984375, 0.333984375, 0.333984375, 0.47265625, 0.333984375]
+        assert t["c"] == 1.1058315334773219 and t["iters"] == 2
+        assert t["P"].float().tolist() == [1.0, 1.0, 0.369140625, 0.5234375, 0.369140625]
+        assert t["chosen"].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_structural_invariants():
+    """SURVEY.md section 4 item 2 on a random graph."""
+    from bliss_gnn_amd.synth import chung_lu_csc
+    ip, ix, ei = chung_lu_csc(500, 6000, seed=5)
+    g = bo.CSC(ip, ix, ei)
+    seeds = torch.randperm(500, generator=torch.Generator().manual_seed(1))[:24]
+    torch.manual_seed(7)
+    inp, outp, blocks = bo.sample_blocks_bandit(g, seeds, [60, 30, 15], torch.ones(3, g.num_edges, dtype=torch.bfloat16), 0.1)
+    assert torch.equal(outp, seeds) and torch.equal(blocks[-1].dst_nid, seeds)
+    assert torch.equal(inp, blocks[0].src_nid)
+    for l, b in enumerate(blocks):
+        assert torch.equal(b.src_nid[: b.n_dst], b.dst_nid)                 # seeds are a prefix
+        assert b.src_nid.unique().numel() == b.n_src                          # ids unique
+        if l + 1 < len(blocks):
+            assert torch.equal(b.dst_nid, blocks[l + 1].src_nid)              # chaining
+        # Hajek: per destination sum of edge weights ~= sampled in-degree (bandit_sampler.py:314-320)
+        s = torch.zeros(b.n_dst).index_add_(0, b.dst, b.edge_weights.float())
+        d = (b.indptr[1:] - b.indptr[:-1]).float()
+        assert torch.allclose(s, d, rtol=0.03)
+
+
+def test_fixed_point_roundtrip_and_rounding():
+    torch.manual_seed(0)
+    x = (torch.rand(50000) * torch.exp(torch.randn(50000) * 4)).bfloat16()
+    x = x[(x.float() > 2 ** -30) & (x.float() < 2 ** 9)]
+    for frac in (nx.FRAC_DST, nx.FRAC_SRC, nx.FRAC_BLK):
+        xx = x[x.float() > 2.0 ** (8 - frac)]
+        assert torch.equal(nx.fixed_to_bf16(nx.bf16_to_fixed(xx, frac), frac), xx)
+    # ties to even: 257 * 2^-40 -> 256 (even), 259 -> 260
+    n = torch.tensor([257, 259, 255, 511, 513], dtype=torch.int64)
+    out = nx.fixed_to_bf16(n, 0).float().tolist()
+    assert out == [256.0, 260.0, 255.0, 512.0, 512.0]
+    vals = (torch.rand(3000) * 0.01).bfloat16()
+    seg = torch.randint(0, 11, (3000,))
+    s, _ = nx.exact_segment_sum(vals, seg, 11, nx.FRAC_DST)
+    ref = torch.zeros(11, dtype=torch.float64).index_add_(0, seg, vals.double())   # exact in fp64 at this size
+    assert torch.equal(s, ref.float().bfloat16())
+
+
+def test_row_sum_matches_fp64():
+    w = (torch.rand(4000) * 1e-6).bfloat16()
+    tot = nx.row_exact_sum(w)
+    assert tot / 2.0 ** 64 == float(w.double().sum())
+
+
+def test_poisson_draw_matches_torch_bernoulli():
+    """CPU bernoulli(P) == (rand(n) < float(P)) under the same seed."""
+    P = torch.rand(70000, generator=torch.Generator().manual_seed(3)).bfloat16()
+    torch.manual_seed(11); a = bo.poisson_draw(P)
+    torch.manual_seed(11); b = bo.poisson_draw(P, torch.rand(70000))
+    assert torch.equal(a, b)
