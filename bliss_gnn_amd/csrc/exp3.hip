@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restric
       const int dn = dst_nid[i];
       const float n_i = rbf((float)(g_indptr[dn + 1] - g_indptr[dn]));                 // :223
       const float r_hat = rbf(r / bf2f(node_prob[j]));                                 // :240 e_div_u
-      float dr = rbf(r_hat * rbf(delta_f / n_i));                                      // :242 e_mul_v(rewards_hat, delta / n_i)
+      // :242 e_mul_v(rewards_hat, delta / n_i): `delta / n_i` is n_i.reciprocal() * delta on a bf16 tensor
+      float dr = rbf(r_hat * rbf(rbf(1.0f / n_i) * delta_f));
       if (dr > 1.0f) dr = 1.0f;                                                        // :244
       const float ex = rbf((float)exp((double)dr));                                    // :246 torch.exp on bf16
       const bf16_t w_old = w_row[pos];

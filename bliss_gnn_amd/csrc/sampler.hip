@@ -42,7 +42,9 @@ __device__ __forceinline__ EdgeAt decode(int e, int S, const int* __restrict__ s
 // q_ij = eta/n_i + (1-eta) * w_ij / sum_j w_ij        bandit_sampler.py:131-137
 __device__ __forceinline__ bf16_t edge_q(bf16_t w, bf16_t wsum, int n, float eta_f, float ome_f) {
   float wd = rbf(bf2f(w) / bf2f(wsum));     // :131 e_div_v
-  float a = rbf(eta_f / (float)n);          // :137 (self.eta / n_i).bfloat16()
+  // :137 (self.eta / n_i).bfloat16(): Python `scalar / tensor` is Tensor.__rtruediv__ = reciprocal() * scalar,
+  // i.e. TWO fp32 roundings on the int32 -> fp32 degree, then one to bf16
+  float a = rbf((1.0f / (float)n) * eta_f);
   float b = rbf(ome_f * wd);                // :137 (1 - self.eta) * exp_weights_divided
   return f2bf(a + b);                       // :137 v_add_e
 }

@@ -156,14 +156,14 @@ extern "C" {
 
 int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const void* w, const void* h, int64_t h_stride,
                    int32_t n_dst, int32_t dim, int mean, void* out, int64_t out_stride, int out_fp32, void* stream) {
-  if (!indptr || !src || !h || !out) return BLISS_EINVAL;
+  if (!indptr || !h || !out) return BLISS_EINVAL;   // src may be NULL for an edgeless block
   return launch_spmm<false>(indptr, src, nullptr, nullptr, w, h, h_stride, n_dst, dim, mean, out, out_stride, out_fp32, (hipStream_t)stream);
 }
 
 int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* dst, const int32_t* indptr,
                    const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t dim, int mean,
                    void* gh, int64_t gh_stride, int out_fp32, void* stream) {
-  if (!t_indptr || !t_edge || !dst || !indptr || !gout || !gh) return BLISS_EINVAL;
+  if (!t_indptr || !indptr || !gout || !gh) return BLISS_EINVAL;   // t_edge/dst may be NULL for an edgeless block
   return launch_spmm<true>(t_indptr, t_edge, dst, indptr, w, gout, gout_stride, n_src, dim, mean, gh, gh_stride, out_fp32, (hipStream_t)stream);
 }
 
