@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- steps/sec of the BLISS-GNN hot path on MI355X.
+
+One *step* = sample_blocks (3 layers) + feature gather + SAGE forward + backward + Adam + exp3 update
+(validation excluded) on the workload BASELINE.json's metric is quoted on:
+Reddit-shaped synthetic graph, 3-layer SAGE, poisson-bandit sampler, fanouts 4096/2048/1024, batch 256.
+Synthetic data (no network): seeded Chung-Lu graph with Reddit's |V|, |E|, F, classes.
+
+    python bench.py --gpus N --steps K --warmup W      (N > 1: launched under torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, every rank holds a replica of the graph
+and samples its own batch (weak scaling); gradients are all-reduced over RCCL and the EXP3 updates are
+all-gathered so that the bandit state stays identical on every rank.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="reddit", choices=["cora", "pubmed", "reddit", "yelp"])
+    ap.add_argument("--cpu-baseline-steps", type=int, default=-1, help="-1: auto (bounded sample), 0: skip")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(sizes, feat, dims):
+    """SURVEY.md section 8d per-step algorithmic HBM bytes from the ACTUAL sizes of a step.
+    sizes: list over layers (block order 0..L-1) of dicts S,E,C,K,B;  dims: SpMM widths per layer."""
+    samp = sum(8 * s["S"] + 6 * s["E"] + 12 * s["C"] + 16 * s["B"] + 6 * s["K"] for s in sizes)
+    gather = 2 * sizes[0]["K"] * feat
+    spmm = sum(2 * (4 * (s["S"] + 1) + 6 * s["B"] + 2 * s["K"] * d + 2 * s["S"] * d) for s, d in zip(sizes, dims))
+    bandit = sum(12 * s["B"] + 4 * s["K"] + 4 * s["S"] for s in sizes)
+    return dict(sampler=samp, gather=gather, spmm=spmm, bandit=bandit, total=samp + gather + spmm + bandit)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import bliss_gnn_amd as bg
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc, node_data
+    from bliss_gnn_amd.train import BatchLoader, TrainStep
+    from bliss_gnn_amd import dist as bdist
+
+    cfg = CONFIGS[args.config]
+    t0 = time.time()
+    ip, ix, ei = chung_lu_csc(cfg["num_nodes"], cfg["num_edges"], seed=0, device=dev)
+    feats, labels, train_nid = node_data(cfg["num_nodes"], cfg["feat"], cfg["classes"], cfg["n_train"], seed=1, device=dev,
+                                         multilabel=cfg["multilabel"])
+    g = bg.Graph(ip, ix, ei, ndata={"features": feats, "labels": labels})
+    g.edata["w"] = bg.normalized_edata(g)                                              # train_lightning.py:362
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+
+    fan, eta, hidden = cfg["fanouts"], 0.1, 256
+    sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000, eta=eta,
+                                            model="sage")
+    torch.manual_seed(1234)
+    model = SAGE(cfg["feat"], hidden, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()   # train_lightning.py:609-618
+    grad_sync = exp3_sync = None
+    if world > 1:
+        bdist.broadcast_parameters(model)
+        grad_sync, exp3_sync = bdist.allreduce_gradients, bdist.exp3_all_ranks
+    step = TrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"], grad_sync=grad_sync, exp3_sync=exp3_sync)
+    # every rank draws its own batches (different loader seed) and its own sampler stream
+    loader = BatchLoader(train_nid, cfg["batch"], shuffle=True, drop_last=True, seed=2 + rank).forever()
+    torch.manual_seed(3 + rank)                                                          # sampler stream (CPU generator)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(next(loader))
+    sync()
+    sizes_acc, n_edges, n_frontier = None, 0, 0
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step(next(loader))
+        mf = step.last["mfgs"]
+        n_edges += sum(b.num_edges() for b in mf)
+        n_frontier += sum(b._counts.E for b in mf)
+        sz = [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in mf]
+        sizes_acc = sz if sizes_acc is None else [{k: a[k] + b[k] for k in a} for a, b in zip(sizes_acc, sz)]
+    sync()
+    dt = time.perf_counter() - t1
+    t = torch.tensor([dt, float(n_edges), float(n_frontier)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, n_edges, n_frontier = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    sampler.check_errors()
+    steps_total = args.steps * world
+    mean_sizes = [{k: v / args.steps for k, v in s.items()} for s in sizes_acc]
+    dims = [hidden, hidden, cfg["classes"]]
+    alg = algorithmic_bytes(mean_sizes, cfg["feat"], dims)
+
+    out = {
+        "metric": "steps/sec (train step: sample_blocks + gather + SAGE fwd/bwd + Adam + exp3), %s-like" % args.config,
+        "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer SAGE hidden %d, poisson-bandit eta %.1f, "
+                               "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"], hidden, eta,
+                                                                 "/".join(map(str, fan)), cfg["batch"]),
+                   "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather)" % world if world > 1 else "single GPU",
+                   "global_batch": cfg["batch"] * world},
+        "sampled_edges_per_sec": n_edges / dt, "frontier_edges_per_sec": n_frontier / dt,
+        "sizes_per_step": mean_sizes, "algorithmic_bytes_per_step": alg,
+        "algorithmic_GBps": alg["total"] * (args.steps / dt) / 1e9, "frac_of_8TBps": alg["total"] * (args.steps / dt) / 8e12,
+        "setup_s": t_setup,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        from bliss_gnn_amd import roofline
+        out["roofline"] = roofline.measure(step, loader, sampler, mean_sizes)
+    if rank == 0 and world == 1 and args.cpu_baseline_steps != 0:
+        out["cpu_baseline"] = cpu_baseline(g, feats, labels, train_nid, cfg, fan, eta, hidden, args.cpu_baseline_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, feats, labels, train_nid, cfg, fan, eta, hidden, n_steps):
+    """The oracle port of the same step on the host cores, bounded sample."""
+    from oracle import bliss_oracle as bo
+    from oracle.train_ref import RefTrainStep
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    og = bo.CSC(g.indptr.cpu(), g.indices.cpu(), g.eid.cpu())
+    ref = RefTrainStep(og, feats.cpu(), labels.cpu(), fan, eta, cfg["feat"], hidden, cfg["classes"], multilabel=cfg["multilabel"])
+    ids = train_nid.cpu()
+    bs = cfg["batch"]
+    torch.manual_seed(3)
+    t0 = time.perf_counter()
+    ref(ids[:bs])                                       # first step allocates + normalises from ones; not timed
+    first = time.perf_counter() - t0
+    budget = 25.0
+    n = n_steps if n_steps > 0 else max(2, min(20, int(budget / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    edges = 0
+    for i in range(1, n + 1):
+        _, blocks = ref(ids[i * bs:(i + 1) * bs])
+        edges += sum(b.src.numel() for b in blocks)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same workload (oracle sampler + torch-CPU SAGE fwd/bwd + Adam + exp3), after 1 untimed step" % n,
+            "sampled_edges_per_sec": edges / dt, "host_cpu_count": cores}
+
+
+if __name__ == "__main__":
+    main()

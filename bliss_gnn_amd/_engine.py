@@ -111,5 +111,6 @@ class LayerEngine:
         blk._q = b_q[:B]
         blk._node_prob = node_prob[:K]
         blk._counts = c2
+        blk._counts_dev = counts
         blk._trace = dict(p=p[: c2.C], P=P[: c2.C], cand_nid=cand_nid[: c2.C], new_id=new_id[: c2.C])
         return blk

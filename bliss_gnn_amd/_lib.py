@@ -59,7 +59,8 @@ SIGNATURES = {
     "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],
     "bliss_spmm_fwd": [_P, _P, _P, _P, _I64, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P],
     "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P],
-    "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, _P],
+    "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
+    "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],
 }

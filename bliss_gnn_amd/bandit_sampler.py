@@ -74,6 +74,7 @@ class BanditLadiesSampler(BlockSampler):
         self.model = model
         self.eps = 0.9999
         self.delta = 0.01                      # bandit_sampler.py:233
+        self._delta_f = float(torch.tensor(self.delta, dtype=torch.float32))
         self._w_pos = None                     # exp3 weights [L, |E|] bf16 in CSC-position order
         self._row_sum = None                   # exact row sums, int64 [L, 3]
         self._engine = None
@@ -140,8 +141,12 @@ class BanditLadiesSampler(BlockSampler):
         return seed_nodes, output_nodes, blocks
 
     # -- bandit update ----------------------------------------------------------------------
-    def exp3(self, mfgs, g):
-        """bandit_sampler.py:251-267: rewards + weight update + L1 renormalisation, per block."""
+    def exp3(self, mfgs, g, apply=True, factors=None):
+        """bandit_sampler.py:251-267: rewards + weight update + L1 renormalisation, per block.
+
+        ``apply=False`` (multi-GPU replicas, bliss_gnn_amd/dist.py) only computes the rewards and, into
+        ``factors[idx]`` (bf16 [B]), the multiplicative updates; ``apply_updates`` then applies every
+        rank's updates in rank order."""
         self._bind(g)
         st = _stream()
         edge_w_pos = g.edata_by_position(self.edge_weight)
@@ -151,7 +156,7 @@ class BanditLadiesSampler(BlockSampler):
             alpha = None
             if self.model == "gat":
                 raise NotImplementedError("GAT alpha (bandit_sampler.py:146-154) lands with the GAT path")
-            n_edges = torch.tensor([B], dtype=torch.int32, device=g.device)
+            n_edges_ptr = mfg._counts_dev.data_ptr() + 16             # LayerCounts::B, already on the device
             rewards = torch.empty(B, dtype=torch.bfloat16, device=g.device)
             en = mfg.srcdata["embed_norm"]
             if en.dtype != torch.bfloat16:
@@ -161,12 +166,31 @@ class BanditLadiesSampler(BlockSampler):
                 mfg.indptr.data_ptr(), mfg.src.data_ptr(), mfg.dst.data_ptr(), mfg.pos.data_ptr(),
                 mfg.edata["q_ij"].data_ptr(), mfg.srcdata[self.node_prob].data_ptr(), en.contiguous().data_ptr(),
                 0 if alpha is None else alpha.data_ptr(), mfg.dstdata[NID].data_ptr(), mfg.num_dst_nodes(),
-                n_edges.data_ptr(), B, float(torch.tensor(self.delta, dtype=torch.float32)), rewards.data_ptr(),
-                self._err.data_ptr(), st), "bliss_exp3_update")
+                n_edges_ptr, B, self._delta_f, rewards.data_ptr(),
+                0 if factors is None else factors[idx].data_ptr(), int(apply), self._err.data_ptr(), st), "bliss_exp3_update")
             mfg.edata["rewards"] = rewards                              # :193
+            if not apply:
+                continue
             _lib.check(_lib.lib.bliss_exp3_normalize(self._w_pos[idx].data_ptr(), g.num_edges(),
                                                      self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
                                                      self._norms[idx:].data_ptr(), st), "bliss_exp3_normalize")
+
+    def apply_updates(self, idx, pos, factor, g):
+        """w[pos] *= factor on layer ``idx`` (positions unique within one call), bandit_sampler.py:248."""
+        n = int(pos.numel())
+        if n == 0:
+            return
+        n_dev = torch.tensor([n], dtype=torch.int32, device=pos.device)
+        _lib.check(_lib.lib.bliss_exp3_apply(self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr(), pos.data_ptr(),
+                                             factor.data_ptr(), n_dev.data_ptr(), n, self._err.data_ptr(), _stream()),
+                   "bliss_exp3_apply")
+
+    def normalize(self, idx, g):
+        """F.normalize(self.exp3_weights[idx], p=1, dim=0), bandit_sampler.py:249 (bit-exact, skipped on the
+        device when the bf16 norm is 1.0)."""
+        _lib.check(_lib.lib.bliss_exp3_normalize(self._w_pos[idx].data_ptr(), g.num_edges(), self._row_sum[idx].data_ptr(),
+                                                 self._scratch[idx].data_ptr(), self._norms[idx:].data_ptr(), _stream()),
+                   "bliss_exp3_normalize")
 
     def check_errors(self):
         """Raise if any exp3 kernel flagged a non-finite weight (one sync; call off the hot path)."""

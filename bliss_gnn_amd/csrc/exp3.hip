@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restric
                                                        const bf16_t* __restrict__ node_prob, const bf16_t* __restrict__ embed_norm,
                                                        const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
                                                        const int* __restrict__ n_edges_dev, float delta_f,
-                                                       bf16_t* __restrict__ rewards_out, int* err) {
+                                                       bf16_t* __restrict__ rewards_out, bf16_t* __restrict__ factor_out,
+                                                       int apply, int* err) {
   const int B = *n_edges_dev;
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
@@ -106,6 +107,8 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restric
       float dr = rbf(r_hat * rbf(rbf(1.0f / n_i) * delta_f));
       if (dr > 1.0f) dr = 1.0f;                                                        // :244
       const float ex = rbf((float)exp((double)dr));                                    // :246 torch.exp on bf16
+      if (factor_out) factor_out[e] = f2bf(ex);
+      if (!apply) continue;
       const bf16_t w_old = w_row[pos];
       const bf16_t w_new = f2bf(bf2f(w_old) * ex);                                     // :248
       if (w_new != w_old) {
@@ -115,6 +118,27 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restric
         row_digits(w_old, b, &bad);
         dg[0] += a[0] - b[0]; dg[1] += a[1] - b[1]; dg[2] += a[2] - b[2];
       }
+    }
+  }
+  flush_digits(dg, row_sum);
+  if (bad) atomicOr(err, bad);
+}
+
+__global__ void __launch_bounds__(E3_TPB) k_exp3_apply(bf16_t* w_row, int64_t* row_sum, const int* __restrict__ pos,
+                                                      const bf16_t* __restrict__ factor, const int* __restrict__ n_dev, int* err) {
+  const int n = *n_dev;
+  int bad = 0;
+  int64_t dg[3] = {0, 0, 0};
+  for (int e = blockIdx.x * E3_TPB + threadIdx.x; e < n; e += gridDim.x * E3_TPB) {
+    const int p = pos[e];
+    const bf16_t w_old = w_row[p];
+    const bf16_t w_new = f2bf(bf2f(w_old) * bf2f(factor[e]));                          // :248
+    if (w_new != w_old) {
+      w_row[p] = w_new;
+      int64_t a[3], b[3];
+      row_digits(w_new, a, &bad);
+      row_digits(w_old, b, &bad);
+      dg[0] += a[0] - b[0]; dg[1] += a[1] - b[1]; dg[2] += a[2] - b[2];
     }
   }
   flush_digits(dg, row_sum);
@@ -185,7 +209,8 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
                       const int32_t* blk_indptr, const int32_t* blk_src, const int32_t* blk_dst,
                       const int32_t* blk_pos, const void* q_ij, const void* node_prob, const void* embed_norm,
                       const void* alpha_or_null, const int32_t* dst_nid, int32_t n_dst, const int32_t* n_edges_dev,
-                      int32_t edges_bound, float delta_f, void* rewards_out, int32_t* err, void* stream) {
+                      int32_t edges_bound, float delta_f, void* rewards_out, void* factor_out, int apply,
+                      int32_t* err, void* stream) {
   if (!g || !w_pos || !row_sum || !blk_indptr || !blk_src || !blk_dst || !blk_pos || !q_ij || !node_prob ||
       !embed_norm || !dst_nid || !n_edges_dev || !err || (!edge_w_pos && !alpha_or_null))
     return BLISS_EINVAL;
@@ -196,7 +221,18 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
   k_exp3_update<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(g->indptr, (const bf16_t*)edge_w_pos, (bf16_t*)w_pos, row_sum, blk_indptr,
                                                           blk_src, blk_dst, blk_pos, (const bf16_t*)q_ij, (const bf16_t*)node_prob,
                                                           (const bf16_t*)embed_norm, (const bf16_t*)alpha_or_null, dst_nid,
-                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, err);
+                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, (bf16_t*)factor_out, apply, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const void* factor, const int32_t* n_dev,
+                     int32_t n_bound, int32_t* err, void* stream) {
+  if (!w_pos || !row_sum || !n_dev || !err) return BLISS_EINVAL;
+  if (n_bound <= 0) return 0;
+  if (!pos || !factor) return BLISS_EINVAL;
+  int grid = (n_bound + E3_TPB - 1) / E3_TPB;
+  if (grid > 2048) grid = 2048;
+  k_exp3_apply<<<grid, E3_TPB, 0, (hipStream_t)stream>>>((bf16_t*)w_pos, row_sum, pos, (const bf16_t*)factor, n_dev, err);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,69 @@
+"""Multi-GPU replicas: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The reference is single-device (no collectives anywhere).  Round-1 scaling
+design, chosen because every BASELINE graph fits one 288 GB part many times over: every rank holds
+the whole graph and bandit state, samples its OWN batch (weak scaling), and two small exchanges per
+step keep the replicas in lock-step:
+
+  * gradients: ONE flat bf16 bucket (~0.45 M parameters, < 1 MB) all-reduced and averaged.  The
+    message is far below the xGMI bandwidth knee, so a single latency-bound collective beats
+    per-tensor or ring-pipelined ones;
+  * EXP3: each rank computes the multiplicative factors of its own blocks without applying them
+    (bliss_exp3_update(apply=0)); (position, factor) lists are all-gathered (padded to the longest,
+    ~6 B per sampled edge) and EVERY rank applies ALL lists in rank order, then renormalises -- so
+    the bf16 weight rows stay bit-identical on every GPU.
+
+The collective logic below is backend-agnostic and covered by world_size-2 gloo tests on CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def broadcast_parameters(model, src=0):
+    for p in model.parameters():
+        dist.broadcast(p.data, src)
+    for b in model.buffers():
+        dist.broadcast(b.data, src)
+
+
+def allreduce_gradients(model):
+    """Average all gradients with one flat-bucket all-reduce."""
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def gather_updates(pos, factor):
+    """All-gather ragged (pos int32 [n], factor bf16 [n]) lists.  Returns, identically on every rank,
+    ``[(pos_r, factor_r) for r in range(world)]``."""
+    world = dist.get_world_size()
+    n = torch.tensor([pos.numel()], dtype=torch.int64, device=pos.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    # one int32 payload: position in the low word, factor bits in a second int32 (bf16 is not a gloo dtype)
+    buf = torch.zeros(2, m, dtype=torch.int32, device=pos.device)
+    buf[0, : pos.numel()] = pos
+    buf[1, : pos.numel()] = factor.view(torch.int16).to(torch.int32)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return [(o[0, :s].contiguous(), o[1, :s].to(torch.int16).view(torch.bfloat16).contiguous()) for o, s in zip(out, sizes)]
+
+
+def exp3_all_ranks(sampler, mfgs, g):
+    """sampler.exp3 for replicas: compute locally, exchange, apply every rank's updates in rank order."""
+    factors = [torch.empty(m.num_edges(), dtype=torch.bfloat16, device=g.device) for m in mfgs]
+    sampler.exp3(mfgs, g, apply=False, factors=factors)
+    for idx, mfg in enumerate(mfgs):
+        for pos_r, fac_r in gather_updates(mfg.pos, factors[idx]):
+            sampler.apply_updates(idx, pos_r, fac_r, g)
+        sampler.normalize(idx, g)

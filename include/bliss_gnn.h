@@ -135,12 +135,20 @@ int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t
  * bandit_sampler.py:157, :180-193, :221-248.  One launch per block.
  * edge_w_pos: g.edata['w'] by CSC position.  w_pos: the layer's exp3 row (updated in place).
  * row_sum: int64[3] exact running sum of the row (32-bit limbs, value * 2^64), updated.
- * rewards_out: bf16 [n_edges] edata['rewards'] or NULL. */
+ * rewards_out: bf16 [n_edges] edata['rewards'] or NULL.  factor_out: bf16 [n_edges] exp(min(1, delta r/(P n)))
+ * or NULL.  apply == 0 computes rewards/factors only and leaves w_pos and row_sum untouched. */
 int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_pos, int64_t* row_sum,
                       const int32_t* blk_indptr, const int32_t* blk_src, const int32_t* blk_dst,
                       const int32_t* blk_pos, const void* q_ij, const void* node_prob, const void* embed_norm,
                       const void* alpha_or_null, const int32_t* dst_nid, int32_t n_dst, const int32_t* n_edges_dev,
-                      int32_t edges_bound, float delta_f, void* rewards_out, int32_t* err, void* stream);
+                      int32_t edges_bound, float delta_f, void* rewards_out, void* factor_out, int apply,
+                      int32_t* err, void* stream);
+
+/* The scatter half of update_exp3_weights (bandit_sampler.py:248) for factors computed elsewhere -- used
+ * when several ranks keep replicas of the bandit state: w_pos[pos[e]] *= factor[e] for e < *n_dev, and
+ * row_sum follows.  pos must be unique within one call; calls apply in stream order. */
+int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const void* factor, const int32_t* n_dev,
+                     int32_t n_bound, int32_t* err, void* stream);
 
 /* F.normalize(row, p=1, dim=0), bandit_sampler.py:249, bit-exact: norm = bf16(exact sum).  The pass
  * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[4]. */

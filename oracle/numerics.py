@@ -125,16 +125,16 @@ def row_exact_sum(values: torch.Tensor):
         raise FloatingPointError("row sum needs finite non-negative weights")
     m = torch.where(exp == 0, man, man | 0x80)
     e = torch.where(exp == 0, torch.ones_like(exp), exp)
-    shift = e - 134 + ROW_FRAC            # may reach ~+60 for weights near 1
-    # split: the term m * 2**shift is spread over 32-bit limbs
+    # one pass: sum of mantissas per exponent (exact in fp64: < 2^8 * 2^40), then shift in Python ints
+    msum = torch.bincount(e, weights=m.double(), minlength=256)
     total = 0
-    for s in torch.unique(shift).tolist():
-        cnt_m = int(m[shift == s].sum())
+    for ee in torch.nonzero(msum).flatten().tolist():
+        s = ee - 134 + ROW_FRAC
         if s >= 0:
-            total += cnt_m << s
+            total += int(msum[ee]) << s
         else:
-            # truncation happens per term, so shift each term separately
-            total += int((m[shift == s] >> (-s if -s < 63 else 63)).sum())
+            # below 2^-ROW_FRAC truncation happens per term
+            total += int((m[e == ee] >> min(-s, 63)).sum())
     return total
 
 

@@ -288,7 +288,7 @@ def test_exp3_update_exp_table(cuda):
     _lib.check(_lib.lib.bliss_exp3_update(C.byref(g), ones.data_ptr(), w.data_ptr(), row_sum.data_ptr(), blk_indptr.data_ptr(),
                                           ar.data_ptr(), ar.data_ptr(), ar.data_ptr(), ones.data_ptr(), cand.to(dev).data_ptr(),
                                           ones.data_ptr(), 0, ar.data_ptr(), n, nE.data_ptr(), n, 1.0, rewards.data_ptr(),
-                                          err.data_ptr(), 0), "exp3_update")
+                                          0, 1, err.data_ptr(), 0), "exp3_update")
     torch.cuda.synchronize()
     d = dr.clone(); d[d > 1] = 1
     expect = torch.full((n,), 0.5, dtype=torch.bfloat16) * torch.exp(d)
@@ -324,7 +324,7 @@ def test_exp_exhaustive_over_unit_interval(cuda):
     for i, y in enumerate(ys.float().tolist()):
         _lib.check(_lib.lib.bliss_exp3_update(C.byref(g), ones.data_ptr(), w.data_ptr(), row_sum.data_ptr(), one_ptr.data_ptr(),
                                               zero.data_ptr(), zero.data_ptr(), ar[i:].data_ptr(), ones.data_ptr(), ones.data_ptr(),
-                                              ones.data_ptr(), 0, zero.data_ptr(), 1, nE.data_ptr(), 1, y, 0, err.data_ptr(), 0),
+                                              ones.data_ptr(), 0, zero.data_ptr(), 1, nE.data_ptr(), 1, y, 0, 0, 1, err.data_ptr(), 0),
                    "exp3_update")
     torch.cuda.synchronize()
     assert int(err.item()) == 0
