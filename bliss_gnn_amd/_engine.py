@@ -1,16 +1,25 @@
-"""Host-side driver of the gfx950 sampler kernels (one layer = three C-ABI calls).
+"""Host-side driver of the gfx950 sampler kernels.
 
-Shared by the four sampler classes.  Owns the dense per-node maps and the per-layer workspaces;
-PyTorch is used for device memory and the current stream only.
+One ``sample_blocks`` call = L x (frontier_prob, mt19937, poisson_select, build_block) enqueued on
+the current stream with NO host round trip in between: every size (S, E, C, K, B) stays on the
+device and the next layer reads its seed count from the previous layer's counts record.  A single
+device->host copy at the end returns all sizes, the error words and the advanced generator state
+(the reference syncs >= 24 times per step).
+
+Buffers are sized by per-layer capacities; if a capacity is exceeded the kernels clamp, flag it,
+and the whole call is repeated with larger buffers from the same generator snapshot (steady state:
+never).  PyTorch is used for device memory and the current stream only.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
 from .graph import Block, Graph
 
 _CHUNK = 1024
+_CAP_ERRS = 1 | 2 | 4 | 8 | 64
 
 
 def _ptr(t):
@@ -19,6 +28,24 @@ def _ptr(t):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def _up8(n):
+    return (int(n) + 7) & ~7
+
+
+class _LayerWs:
+    """Persistent per-layer scratch (internal to the sampler, reused every call)."""
+
+    def __init__(self, dev, cap_s, cap_c):
+        self.cap_s, self.cap_c = cap_s, cap_c
+        self.seg_ptr = torch.empty(cap_s + 1, dtype=torch.int32, device=dev)
+        self.seed_acc = torch.empty(32 * cap_s, dtype=torch.uint8, device=dev)
+        self.cand_nid = torch.empty(cap_c, dtype=torch.int32, device=dev)
+        self.new_id = torch.empty(cap_c, dtype=torch.int32, device=dev)
+        self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
+        self.P = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
+        self.uniforms = torch.empty(cap_c, dtype=torch.float32, device=dev)
 
 
 class LayerEngine:
@@ -41,76 +68,169 @@ class LayerEngine:
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
-        self.counts_host = torch.empty(40, dtype=torch.uint8).pin_memory()
+        self.mt_dev = torch.empty(626, dtype=torch.int32, device=dev)
+        self.mt_host = torch.empty(626, dtype=torch.int32).pin_memory()
+        self.caps = None
+        self.ws = None
+        self.counts_host = None
+        self.retries = 0
 
-    def _read_counts(self, counts_dev):
-        """One device->host sync: the sizes the reference obtains through .item()/boolean masks."""
-        self.counts_host.copy_(counts_dev, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        c = _lib.LayerCounts.from_buffer_copy(self.counts_host.numpy().tobytes())
-        if c.err:
-            raise RuntimeError(f"sampler kernel error 0x{c.err:x}: {_lib.err_string(c.err)}")
-        return c
+    # ------------------------------------------------------------------ capacities
+    def _init_caps(self, S0, fanouts_sampling_order):
+        caps, s = [], int(S0)
+        for f in fanouts_sampling_order:
+            k = min(self.V, int(1.25 * (f + s)) + 64)
+            caps.append(dict(S=s, C=self.V, K=k, B=int(min(self.Eg, max(1 << 16, 48 * k)))))
+            s = k
+        return caps
 
-    def sample_layer(self, w_pos, seeds, fanout, mode, eta, poisson=True, eps=0.9999, uniforms=None, chooser=None):
-        """One iteration of the ``for block_id in reversed(range(L))`` loop of
-        bandit_sampler.py:350-366 / ladies_sampler.py:112-122.
+    def _ensure(self, S0, fan):
+        if self.caps is None or len(self.caps) != len(fan):
+            self.caps = self._init_caps(S0, fan)
+            self.ws = None
+        elif self.caps[0]["S"] < S0:
+            fresh = self._init_caps(S0, fan)
+            self.caps = [{k: max(a[k], b[k]) for k in a} for a, b in zip(self.caps, fresh)]
+            self.ws = None
+        if self.ws is None:
+            dev = self.g.device
+            self.ws = [_LayerWs(dev, c["S"], c["C"]) for c in self.caps]
+            self.counts_host = torch.empty(len(fan) * 10, dtype=torch.int32).pin_memory()
 
-        ``uniforms``: optional fp32 CPU/GPU tensor replacing ``torch.rand(C)`` from the global CPU
+    def _grow(self, errs):
+        for n, e in enumerate(errs):
+            c = self.caps[n]
+            if e & 64:
+                c["S"] = min(self.V, 2 * c["S"])
+            if e & 4:
+                c["K"] = min(self.V, 2 * c["K"])
+            if e & 8:
+                c["B"] = int(min(self.Eg, 2 * c["B"]))
+        for n in range(len(self.caps) - 1):                       # a layer's seeds are the previous layer's kept nodes
+            self.caps[n + 1]["S"] = max(self.caps[n + 1]["S"], self.caps[n]["K"])
+        self.ws = None
+        self.retries += 1
+
+    # ------------------------------------------------------------------ torch CPU generator <-> device
+    @staticmethod
+    def _rng_fields(state_bytes):
+        a = state_bytes.numpy()
+        return a[8:12].view(np.int32), a[16:24].view(np.int64), a[24:24 + 624 * 8].view(np.uint64)
+
+    def _upload_rng(self, snapshot):
+        left, nxt, st = self._rng_fields(snapshot)
+        h = self.mt_host.numpy()
+        h[:624] = st.astype(np.uint32).view(np.int32)
+        h[624], h[625] = int(left[0]), int(nxt[0])
+        self.mt_dev.copy_(self.mt_host, non_blocking=True)
+
+    def _commit_rng(self, snapshot):
+        """Make the global CPU generator continue after the numbers the device consumed."""
+        left, nxt, st = self._rng_fields(snapshot)
+        h = self.mt_host.numpy()
+        st[:] = h[:624].view(np.uint32).astype(np.uint64)
+        left[0], nxt[0] = int(h[624]), int(h[625])
+        torch.set_rng_state(snapshot)
+
+    # ------------------------------------------------------------------ one sample_blocks call
+    def sample_blocks(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, uniforms=None):
+        """The ``for block_id in reversed(range(L))`` loop of bandit_sampler.py:350-366 /
+        ladies_sampler.py:112-122.  ``w_rows[n]`` / ``fanouts[n]`` are in SAMPLING order (last block
+        first).  Returns the blocks in sampling order.
+
+        ``uniforms``: optional list of fp32 vectors replacing the draws from torch's global CPU
         generator (the stream ATen's CPU ``torch.bernoulli`` consumes)."""
-        g, dev = self.g, self.g.device
-        st = _stream()
-        S = int(seeds.numel())
         seeds = seeds.to(torch.int32).contiguous()
-        V = self.V
-        counts = torch.empty(40, dtype=torch.uint8, device=dev)
-        seg_ptr = torch.empty(S + 1, dtype=torch.int32, device=dev)
-        seed_acc = torch.empty(32 * S, dtype=torch.uint8, device=dev)
-        cand_nid = torch.empty(V, dtype=torch.int32, device=dev)
-        p = torch.empty(V, dtype=torch.bfloat16, device=dev)
-        P = torch.empty(V, dtype=torch.bfloat16, device=dev)
-        new_id = torch.empty(V, dtype=torch.int32, device=dev)
-        kept_nid = torch.empty(V, dtype=torch.int32, device=dev)
-        node_prob = torch.empty(V, dtype=torch.bfloat16, device=dev)
-        ws = _lib.LayerWs(counts.data_ptr(), seg_ptr.data_ptr(), seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
-                          cand_nid.data_ptr(), p.data_ptr(), P.data_ptr(), new_id.data_ptr(), kept_nid.data_ptr(),
-                          node_prob.data_ptr(), V, V)
-        eta_f = float(torch.tensor(eta, dtype=torch.float32))
-        ome_f = float(torch.tensor(1.0 - eta, dtype=torch.float32))
-        _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
-                                                seeds.data_ptr(), S, mode, eta_f, ome_f, self.Eg, C.byref(ws), st),
-                   "bliss_frontier_prob")
-        c1 = self._read_counts(counts)                     # E, C  (the reference syncs here many times)
-        if poisson:
+        L = len(fanouts)
+        self._ensure(int(seeds.numel()), fanouts)
+        snapshot = torch.get_rng_state() if uniforms is None else None
+        while True:
+            out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot)
+            counts_dev = out[0]
+            self.counts_host.copy_(counts_dev, non_blocking=True)
+            if snapshot is not None:
+                self.mt_host.copy_(self.mt_dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()                 # the ONE sync of the step's sampling
+            raw = self.counts_host.numpy().tobytes()
+            cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
+            errs = [c.err for c in cnts]
+            bad = 0
+            for e in errs:
+                bad |= e
+            if bad & ~_CAP_ERRS:
+                raise RuntimeError(f"sampler kernel error 0x{bad:x}: {_lib.err_string(bad)}")
+            if bad & 2:
+                raise RuntimeError("candidate capacity exceeded / seed id out of range")
+            if bad == 0:
+                break
+            self._grow(errs)
+            self._ensure(int(seeds.numel()), fanouts)
+        if snapshot is not None:
+            self._commit_rng(snapshot)
+        return self._finish(out, cnts)
+
+    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot):
+        dev, st = self.g.device, _stream()
+        L = len(fanouts)
+        if snapshot is not None:
+            self._upload_rng(snapshot)
+        counts = torch.empty(L * 10, dtype=torch.int32, device=dev)
+        eta_f = float(np.float32(eta))
+        ome_f = float(np.float32(1.0 - eta))
+        layers = []
+        cur_seeds, n_seeds, n_seeds_dev = seeds, int(seeds.numel()), 0
+        for n in range(L):
+            cap, ws = self.caps[n], self.ws[n]
+            cs, ck, cb = cap["S"], cap["K"], cap["B"]
+            # caller-owned outputs: one int32 and one bf16 allocation per layer, sliced
+            ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck), dtype=torch.int32, device=dev)
+            hbuf = torch.empty(2 * _up8(cb) + _up8(ck), dtype=torch.bfloat16, device=dev)
+            o = 0
+            b_indptr = ibuf[o:o + cs + 1]; o += _up8(cs + 1)
+            b_src = ibuf[o:o + cb]; o += _up8(cb)
+            b_dst = ibuf[o:o + cb]; o += _up8(cb)
+            b_pos = ibuf[o:o + cb]; o += _up8(cb)
+            b_eid = ibuf[o:o + cb]; o += _up8(cb)
+            kept_nid = ibuf[o:o + ck]
+            b_w = hbuf[0:cb]
+            b_q = hbuf[_up8(cb):_up8(cb) + cb]
+            node_prob = hbuf[2 * _up8(cb):2 * _up8(cb) + ck]
+            cnt_ptr = counts.data_ptr() + 40 * n
+            c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
+                                ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
+                                kept_nid.data_ptr(), node_prob.data_ptr(), cap["C"], ck)
+            w_pos = w_rows[n]
+            _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
+                                                    cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
+                                                    self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
             if uniforms is None:
-                u = torch.rand(c1.C).pin_memory().to(dev, non_blocking=True)
+                _lib.check(_lib.lib.bliss_mt19937_uniform(self.mt_dev.data_ptr(), cnt_ptr, 2, ws.uniforms.data_ptr(),
+                                                          cap["C"], st), "bliss_mt19937_uniform")
             else:
-                u = uniforms[: c1.C].to(dev, torch.float32).contiguous()
-                assert u.numel() >= c1.C, "not enough uniforms supplied"
-            _lib.check(_lib.lib.bliss_poisson_select(C.byref(ws), int(fanout), float(eps), u.data_ptr(), c1.C, st),
-                       "bliss_poisson_select")
-        else:
-            raise NotImplementedError("multinomial (non-Poisson) selection lands with SURVEY 8f rank 4")
-        cap_b = max(c1.E, 1)
-        b_indptr = torch.empty(S + 1, dtype=torch.int32, device=dev)
-        b_src = torch.empty(cap_b, dtype=torch.int32, device=dev)
-        b_dst = torch.empty(cap_b, dtype=torch.int32, device=dev)
-        b_pos = torch.empty(cap_b, dtype=torch.int32, device=dev)
-        b_eid = torch.empty(cap_b, dtype=torch.int32, device=dev)
-        b_w = torch.empty(cap_b, dtype=torch.bfloat16, device=dev)
-        b_q = torch.empty(cap_b, dtype=torch.bfloat16, device=dev)
-        out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
-                            b_w.data_ptr(), b_q.data_ptr(), cap_b)
-        _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
-                                              seeds.data_ptr(), S, mode, eta_f, ome_f, max(c1.E, 1), C.byref(ws),
-                                              C.byref(out), st), "bliss_build_block")
-        c2 = self._read_counts(counts)                     # K, B
-        K, B = c2.K, c2.B
-        blk = Block(g, K, S, b_indptr, b_src[:B], b_dst[:B], b_pos[:B], b_eid[:B], kept_nid[:K])
-        blk._edge_weights = b_w[:B]
-        blk._q = b_q[:B]
-        blk._node_prob = node_prob[:K]
-        blk._counts = c2
-        blk._counts_dev = counts
-        blk._trace = dict(p=p[: c2.C], P=P[: c2.C], cand_nid=cand_nid[: c2.C], new_id=new_id[: c2.C])
-        return blk
+                u = uniforms[n].to(dev, torch.float32).reshape(-1)
+                m = min(u.numel(), cap["C"])
+                ws.uniforms[:m].copy_(u[:m])
+            _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
+                                                     cap["C"], st), "bliss_poisson_select")
+            c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
+                                  b_w.data_ptr(), b_q.data_ptr(), cb)
+            _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
+                                                  cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, self.Eg, C.byref(c_ws),
+                                                  C.byref(c_out), st), "bliss_build_block")
+            layers.append((b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10]))
+            cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
+        return counts, layers
+
+    def _finish(self, out, cnts):
+        _, layers = out
+        blocks = []
+        for n, (lay, c) in enumerate(zip(layers, cnts)):
+            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev = lay
+            S, K, B = c.S, c.K, c.B
+            blk = Block(self.g, K, S, b_indptr[:S + 1], b_src[:B], b_dst[:B], b_pos[:B], b_eid[:B], kept_nid[:K])
+            blk._edge_weights, blk._q, blk._node_prob = b_w[:B], b_q[:B], node_prob[:K]
+            blk._counts, blk._counts_dev = c, cdev
+            ws = self.ws[n]
+            blk._trace = dict(p=ws.p[:c.C], P=ws.P[:c.C], cand_nid=ws.cand_nid[:c.C], new_id=ws.new_id[:c.C])
+            blocks.append(blk)
+        return blocks

@@ -125,20 +125,22 @@ class BanditLadiesSampler(BlockSampler):
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """bandit_sampler.py:341-367.  ``uniforms``: optional list (sampling order, last layer first)
         of fp32 vectors used instead of the global CPU generator."""
+        if not self._poisson:
+            raise NotImplementedError("multinomial selection (bandit_sampler.py:84-99) lands with SURVEY 8f rank 4; "
+                                      "use PoissonBanditLadiesSampler")
         eng = self._bind(g)
         self._ensure_weights(g)
         output_nodes = seed_nodes
+        order = list(reversed(range(len(self.nodes_per_layer))))          # :350
+        blks = eng.sample_blocks([self._w_pos[b] for b in order], seed_nodes, [self.nodes_per_layer[b] for b in order],
+                                 _lib.MODE_BANDIT, self.eta, self.eps, uniforms)
         blocks = []
-        for n, block_id in enumerate(reversed(range(len(self.nodes_per_layer)))):
-            blk = eng.sample_layer(self._w_pos[block_id], seed_nodes, self.nodes_per_layer[block_id], _lib.MODE_BANDIT,
-                                   self.eta, poisson=self._poisson, eps=self.eps,
-                                   uniforms=None if uniforms is None else uniforms[n])
+        for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights           # :324
             blk.edata["q_ij"] = blk._q                                  # :326
             blk.srcdata[self.node_prob] = blk._node_prob                # :328
-            seed_nodes = blk.srcdata[NID]                               # :364
             blocks.insert(0, blk)                                       # :366
-        return seed_nodes, output_nodes, blocks
+        return blocks[0].srcdata[NID], output_nodes, blocks             # :364,:367
 
     # -- bandit update ----------------------------------------------------------------------
     def exp3(self, mfgs, g, apply=True, factors=None):

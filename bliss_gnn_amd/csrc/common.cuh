@@ -28,6 +28,7 @@
 #define BLISS_ERR_CAP_EDGES    8   // block-edge capacity exceeded
 #define BLISS_ERR_NONFINITE   16   // a non-finite / negative term reached an exact reduction
 #define BLISS_ERR_FIXED_RANGE 32   // an exact sum left its fixed-point range
+#define BLISS_ERR_CAP_SEEDS   64   // more seeds than the per-layer seed capacity
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits
 

@@ -461,8 +461,10 @@ __global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __
   for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) local_id[cand_nid[id]] = -1;
 }
 
-__global__ void k_init_counts(LayerCounts* cnt, int S) {
-  cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = 0; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+__global__ void k_init_counts(LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s) {
+  int S = S_host >= 0 ? S_host : *S_dev, err = 0;
+  if (S > cap_s) { S = cap_s; err = BLISS_ERR_CAP_SEEDS; }     // clamp: results invalid but in bounds
+  cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
 }
 
 inline int grid_for(int64_t n, int per_block, int max_blocks = 2048) {
@@ -481,20 +483,21 @@ extern "C" {
 int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
 
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
-                        int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
-                        const bliss_layer_ws_t* ws, void* stream_) {
-  if (!g || !m || !seeds || !ws || n_seeds <= 0) return BLISS_EINVAL;
+                        int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode, float eta_f,
+                        float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream_) {
+  if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0) return BLISS_EINVAL;
+  if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
+  if (n_seeds > cap_s) return BLISS_EINVAL;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
-  if (!w_pos) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;
   const bf16_t* w = (const bf16_t*)w_pos;
-  unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;            // [S]
-  unsigned long long* acc_q = acc_w + n_seeds;                              // [S]
+  unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;            // [cap_s]
+  unsigned long long* acc_q = acc_w + cap_s;                                // [cap_s]
   if (frontier_bound < 1) frontier_bound = 1;
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
-  k_init_counts<<<1, 1, 0, st>>>(cnt, n_seeds);
-  CK(hipMemsetAsync(ws->seed_acc, 0, (size_t)n_seeds * 32, st));            // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
+  k_init_counts<<<1, 1, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s);
+  CK(hipMemsetAsync(ws->seed_acc, 0, (size_t)cap_s * 32, st));              // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
   k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes);
   if (mode == BLISS_MODE_BANDIT) {
     k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w);
@@ -508,7 +511,7 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c);
   else
     k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c);
-  k_cand_finalize<<<grid_for(ws->cap_c < frontier_bound + n_seeds ? ws->cap_c : frontier_bound + n_seeds, TPB), TPB, 0, st>>>(
+  k_cand_finalize<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(
       seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->cap_c);
   return (int)hipGetLastError();
 }
@@ -530,16 +533,16 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
 }
 
 int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
-                      int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
+                      int32_t cap_s, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
                       const bliss_layer_ws_t* ws, const bliss_block_out_t* out, void* stream_) {
-  if (!g || !m || !seeds || !ws || !out || !w_pos || n_seeds <= 0) return BLISS_EINVAL;
+  if (!g || !m || !seeds || !ws || !out || !w_pos || cap_s <= 0) return BLISS_EINVAL;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;
   const bf16_t* w = (const bf16_t*)w_pos;
   unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;
-  unsigned long long* acc_wt = acc_w + 2 * (size_t)n_seeds;
-  int* deg_blk = (int*)(acc_w + 3 * (size_t)n_seeds);
+  unsigned long long* acc_wt = acc_w + 2 * (size_t)cap_s;
+  int* deg_blk = (int*)(acc_w + 3 * (size_t)cap_s);
   if (frontier_bound < 1) frontier_bound = 1;
   const int gc = grid_for(frontier_bound, CHUNK);
   if (mode == BLISS_MODE_BANDIT)
@@ -552,9 +555,7 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
     k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b);
   else
     k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b);
-  int64_t cb = frontier_bound + n_seeds;
-  if (cb > ws->cap_c) cb = ws->cap_c;
-  k_cleanup<<<grid_for(cb, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c);
+  k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c);
   return (int)hipGetLastError();
 }
 

@@ -182,7 +182,8 @@ class Block:
         int32 [n_src+1], t_edge int32 [B])``.  Only the SpMM backward needs it; index plumbing."""
         if self._transposed is None:
             order = torch.argsort(self.src, stable=True).to(torch.int32)
-            cnt = torch.bincount(self.src, minlength=self._n_src)
+            cnt = torch.zeros(self._n_src, dtype=torch.int32, device=self.device)      # (bincount would sync)
+            cnt.index_add_(0, self.src, torch.ones_like(self.src))
             t_indptr = torch.zeros(self._n_src + 1, dtype=torch.int32, device=self.device)
             t_indptr[1:] = torch.cumsum(cnt, 0)
             self._transposed = (t_indptr, order)

@@ -31,19 +31,21 @@ class LadiesSampler(BlockSampler):
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """ladies_sampler.py:109-123."""
+        if not self._poisson:
+            raise NotImplementedError("multinomial selection (ladies_sampler.py:54-69) lands with SURVEY 8f rank 4; "
+                                      "use PoissonLadiesSampler")
         if self._engine is None or self._engine.g is not g:
             self._engine = LayerEngine(g)
         w_pos = g.edata_by_position(self.edge_weight)                    # :114
         output_nodes = seed_nodes
+        order = list(reversed(range(len(self.nodes_per_layer))))         # :112
+        blks = self._engine.sample_blocks([w_pos] * len(order), seed_nodes, [self.nodes_per_layer[b] for b in order],
+                                          _lib.MODE_LADIES, 0.0, self.eps, uniforms)
         blocks = []
-        for n, block_id in enumerate(reversed(range(len(self.nodes_per_layer)))):
-            blk = self._engine.sample_layer(w_pos, seed_nodes, self.nodes_per_layer[block_id], _lib.MODE_LADIES, 0.0,
-                                            poisson=self._poisson, eps=self.eps,
-                                            uniforms=None if uniforms is None else uniforms[n])
+        for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights            # :100
-            seed_nodes = blk.srcdata[NID]                                # :121
             blocks.insert(0, blk)
-        return seed_nodes, output_nodes, blocks
+        return blocks[0].srcdata[NID], output_nodes, blocks              # :121,:123
 
 
 class PoissonLadiesSampler(LadiesSampler):

@@ -61,8 +61,8 @@ typedef struct {
 /* Per-layer workspace (all device memory, caller allocated). */
 typedef struct {
   void* counts;             /* bliss_layer_counts_t */
-  int32_t* seg_ptr;         /* [n_seeds + 1] start of every seed's column in the frontier */
-  void* seed_acc;           /* [32 * n_seeds bytes] exact per-seed accumulators */
+  int32_t* seg_ptr;         /* [cap_s + 1] start of every seed's column in the frontier */
+  void* seed_acc;           /* [32 * cap_s bytes] exact per-seed accumulators */
   int32_t* chunk_cnt;       /* [max(frontier_bound, cap_c) / 1024 + 2] */
   int32_t* cand_nid;        /* [cap_c] global id of every candidate, seeds first (ndata[NID]) */
   void* p;                  /* bf16 [cap_c] LADIES importance p_j */
@@ -75,7 +75,7 @@ typedef struct {
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
 typedef struct {
-  int32_t* indptr;          /* [n_seeds + 1] */
+  int32_t* indptr;          /* [cap_s + 1] */
   int32_t* src;             /* [cap_b] block-local source id */
   int32_t* dst;             /* [cap_b] block-local destination id (= seed index) */
   int32_t* pos;             /* [cap_b] CSC position in g of every block edge */
@@ -89,14 +89,17 @@ int bliss_layer_counts_bytes(void);
 
 /* exp3_probabilities + BanditLadiesSampler.compute_prob      bandit_sampler.py:101-138, :47-82
  * LadiesSampler.compute_prob                                 ladies_sampler.py:34-52
- * In: seeds [n_seeds] (unique).  w_pos: bf16 [num_edges] in CSC-position order -- the layer's
+ * In: seeds (unique); their count is n_seeds if >= 0, else *n_seeds_dev (e.g. the K of the previous
+ * layer's counts record, so that consecutive layers need no host round trip); cap_s >= count sizes
+ * seg_ptr / seed_acc.  w_pos: bf16 [num_edges] in CSC-position order -- the layer's
  * exp3_weights row (BANDIT) or g.edata['w'] (LADIES).  eta_f = (float)eta,
  * one_minus_eta_f = (float)(1.0 - eta).  frontier_bound >= number of in-edges of the seeds
  * (num_edges is always valid).  Out (in ws): counts{S,E,C}, seg_ptr, cand_nid, p; the node maps
  * hold local ids of all candidates until bliss_build_block cleans them. */
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* maps, const void* w_pos,
-                        const int32_t* seeds, int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f,
-                        int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream);
+                        const int32_t* seeds, int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode,
+                        float eta_f, float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws,
+                        void* stream);
 
 /* PoissonBanditLadiesSampler.compute_prob (scale c, :391-406) + select_neighbors (:408-425).
  * uniforms: fp32 [>= C], the values torch.rand(C) draws from the CPU generator (ATen's serial
@@ -109,8 +112,13 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
  * Same g, maps, w_pos, seeds, eta as the matching bliss_frontier_prob call.  Out: counts{B}, the block;
  * leaves the node maps clean. */
 int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* maps, const void* w_pos,
-                      const int32_t* seeds, int32_t n_seeds, int mode, float eta_f, float one_minus_eta_f,
+                      const int32_t* seeds, int32_t cap_s, int mode, float eta_f, float one_minus_eta_f,
                       int64_t frontier_bound, const bliss_layer_ws_t* ws, const bliss_block_out_t* out, void* stream);
+
+/* at::mt19937 on the device: n = n_dev[n_word_offset] uniforms u = (r & 0xFFFFFF) * 2^-24 from the
+ * generator state (uint32[626]: 624 state words, left, next -- the fields torch.get_rng_state()
+ * exposes), advanced in place.  Same numbers as torch.rand(n) / torch.bernoulli draw on the CPU. */
+int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offset, float* out, int32_t cap, void* stream);
 
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);

@@ -331,3 +331,29 @@ def test_exp_exhaustive_over_unit_interval(cuda):
     expect = torch.full((n,), 0.75, dtype=torch.bfloat16) * torch.exp(ys)
     bad = (w.cpu().view(torch.int16) != expect.view(torch.int16))
     assert not bad.any(), f"exp differs from torch CPU for {bad.sum().item()} inputs, first y={ys[bad][0].item()}"
+
+
+def test_device_mt19937_continues_the_torch_cpu_stream(cuda):
+    """The device generator consumes exactly sum(C) numbers of torch's global CPU stream and hands the
+    advanced state back: whatever torch draws next on the CPU is what it would have drawn after
+    torch.bernoulli(P) in the reference (bandit_sampler.py:422-424)."""
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(6000, 90000, seed=6)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    sampler = bg.PoissonBanditLadiesSampler([300, 200, 100], eta=0.1)
+    seeds = torch.arange(50, 114, dtype=torch.int32, device=cuda)
+    for start in (0, 1, 623, 624, 625, 5000):          # generator positions around the 624-word block edge
+        torch.manual_seed(77)
+        torch.rand(start)
+        _, _, blocks = sampler.sample_blocks(g, seeds)
+        after = torch.rand(7)
+        n_drawn = sum(b._counts.C for b in blocks)
+        torch.manual_seed(77)
+        torch.rand(start)
+        us = [torch.rand(b._counts.C) for b in reversed(blocks)]       # sampling order: last block first
+        expect_after = torch.rand(7)
+        assert torch.equal(after, expect_after), f"generator out of step after {n_drawn} draws (start {start})"
+        _, _, blocks2 = sampler.sample_blocks(g, seeds, uniforms=us)
+        for b1, b2 in zip(blocks, blocks2):
+            assert torch.equal(b1.srcdata[bg.NID], b2.srcdata[bg.NID]) and torch.equal(b1.src, b2.src)
