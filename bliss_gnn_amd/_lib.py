@@ -65,6 +65,10 @@ SIGNATURES = {
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],
+    "bliss_prof_enable": [C.c_int],
+    "bliss_prof_reset": [],
+    "bliss_prof_read": [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "bliss_prof_kernel_count": [],
 }
 
 
@@ -78,6 +82,8 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.bliss_prof_kernel_name.argtypes = [C.c_int]
+    lib.bliss_prof_kernel_name.restype = C.c_char_p
     assert lib.bliss_layer_counts_bytes() == C.sizeof(LayerCounts), "LayerCounts layout mismatch"
     return lib
 

@@ -12,6 +12,7 @@
 //   on the device with identical bits.
 #include "common.cuh"
 #include "bliss_gnn.h"
+#include "prof.h"
 
 namespace {
 
@@ -218,10 +219,11 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
   if (edges_bound <= 0) return 0;
   int grid = (edges_bound + E3_TPB - 1) / E3_TPB;
   if (grid > 2048) grid = 2048;
-  k_exp3_update<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(g->indptr, (const bf16_t*)edge_w_pos, (bf16_t*)w_pos, row_sum, blk_indptr,
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_EXP3_UPDATE, st, k_exp3_update<<<grid, E3_TPB, 0, st>>>(g->indptr, (const bf16_t*)edge_w_pos, (bf16_t*)w_pos, row_sum, blk_indptr,
                                                           blk_src, blk_dst, blk_pos, (const bf16_t*)q_ij, (const bf16_t*)node_prob,
                                                           (const bf16_t*)embed_norm, (const bf16_t*)alpha_or_null, dst_nid,
-                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, (bf16_t*)factor_out, apply, err);
+                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, (bf16_t*)factor_out, apply, err));
   return (int)hipGetLastError();
 }
 
@@ -232,7 +234,8 @@ int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const vo
   if (!pos || !factor) return BLISS_EINVAL;
   int grid = (n_bound + E3_TPB - 1) / E3_TPB;
   if (grid > 2048) grid = 2048;
-  k_exp3_apply<<<grid, E3_TPB, 0, (hipStream_t)stream>>>((bf16_t*)w_pos, row_sum, pos, (const bf16_t*)factor, n_dev, err);
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_EXP3_APPLY, st, k_exp3_apply<<<grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, row_sum, pos, (const bf16_t*)factor, n_dev, err));
   return (int)hipGetLastError();
 }
 
@@ -243,7 +246,7 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, scratch);
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, scratch));
   k_norm_commit<<<1, 1, 0, st>>>(row_sum, scratch);
   return (int)hipGetLastError();
 }
@@ -255,7 +258,7 @@ int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* 
   if (e != hipSuccess) return (int)e;
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   if (grid > 4096) grid = 4096;
-  k_row_sum<<<(int)grid, E3_TPB, 0, st>>>((const bf16_t*)w_pos, num_edges, row_sum, nullptr);
+  PROF_LAUNCH(BK_ROW_SUM, st, k_row_sum<<<(int)grid, E3_TPB, 0, st>>>((const bf16_t*)w_pos, num_edges, row_sum, nullptr));
   return (int)hipGetLastError();
 }
 

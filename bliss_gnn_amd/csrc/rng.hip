@@ -12,6 +12,7 @@
 // one word per thread per phase, LDS resident; tempering and the coalesced store use all lanes.
 #include "common.cuh"
 #include "bliss_gnn.h"
+#include "prof.h"
 
 namespace {
 
@@ -77,6 +78,7 @@ __global__ void __launch_bounds__(256) k_mt19937_uniform(uint32_t* state, const 
 extern "C" int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offset, float* out, int32_t cap,
                                      void* stream) {
   if (!state || !n_dev || !out || cap < 0) return BLISS_EINVAL;
-  k_mt19937_uniform<<<1, 256, 0, (hipStream_t)stream>>>((uint32_t*)state, n_dev, n_word_offset, out, cap);
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_MT19937, st, k_mt19937_uniform<<<1, 256, 0, st>>>((uint32_t*)state, n_dev, n_word_offset, out, cap));
   return (int)hipGetLastError();
 }

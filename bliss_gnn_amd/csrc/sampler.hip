@@ -16,6 +16,7 @@
 // relative order, so the block comes out CSR-by-destination with no sort anywhere.
 #include "common.cuh"
 #include "bliss_gnn.h"
+#include "prof.h"
 
 #define TPB 256
 #define ITEMS 4
@@ -498,21 +499,21 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
   k_init_counts<<<1, 1, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s);
   CK(hipMemsetAsync(ws->seed_acc, 0, (size_t)cap_s * 32, st));              // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
-  k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes);
+  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes));
   if (mode == BLISS_MODE_BANDIT) {
-    k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w);
-    k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f);
+    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
+    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
   } else {
-    k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w);
-    k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f);
+    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
+    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
   }
-  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 0, ws->cap_c);
+  PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 0, ws->cap_c));
   if (mode == BLISS_MODE_BANDIT)
-    k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c);
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c));
   else
-    k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c);
-  k_cand_finalize<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(
-      seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->cap_c);
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c));
+  PROF_LAUNCH(BK_CAND_FINALIZE, st, k_cand_finalize<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(
+      seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->cap_c));
   return (int)hipGetLastError();
 }
 
@@ -524,11 +525,11 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   if (cand_bound < 1) cand_bound = 1;
   if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
   const int gc = grid_for(cand_bound, CHUNK);
-  k_poisson_scale<<<1, 1024, 0, st>>>((const bf16_t*)ws->p, cnt, fanout, eps);
-  k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c);
-  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k);
-  k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
-                                     ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k);
+  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>((const bf16_t*)ws->p, cnt, fanout, eps));
+  PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
+  PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
+  PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
+                                     ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k));
   return (int)hipGetLastError();
 }
 
@@ -546,16 +547,16 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   if (frontier_bound < 1) frontier_bound = 1;
   const int gc = grid_for(frontier_bound, CHUNK);
   if (mode == BLISS_MODE_BANDIT)
-    k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f);
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
   else
-    k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f);
-  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 2, out->cap_b);
-  k_indptr_scan<<<1, 1024, 0, st>>>(deg_blk, cnt, out->indptr);
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
+  PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 2, out->cap_b));
+  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_indptr_scan<<<1, 1024, 0, st>>>(deg_blk, cnt, out->indptr));
   if (mode == BLISS_MODE_BANDIT)
-    k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b);
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b));
   else
-    k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b);
-  k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c);
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b));
+  PROF_LAUNCH(BK_CLEANUP, st, k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c));
   return (int)hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 // by-source transposed index), so it is deterministic and needs no float atomics.
 #include "common.cuh"
 #include "bliss_gnn.h"
+#include "prof.h"
 
 namespace {
 
@@ -143,7 +144,7 @@ int launch_spmm(const int* row_ptr, const int* idx, const int* dst, const int* b
   const bool vec4 = (dim % 4 == 0) && (h_stride % 4 == 0) && (out_stride % 4 == 0) &&
                     (((uintptr_t)h) % 8 == 0) && (((uintptr_t)out) % (out_fp32 ? 16 : 8) == 0);
   dim3 grid((n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64)), block(SP_TPB);
-#define GO(V, F) k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, idx, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, dim, mean, out, out_stride)
+#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, idx, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, dim, mean, out, out_stride))
   if (vec4) { if (out_fp32) GO(true, true); else GO(true, false); }
   else      { if (out_fp32) GO(false, true); else GO(false, false); }
 #undef GO
@@ -171,7 +172,8 @@ int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_str
   if (!h || !out) return BLISS_EINVAL;
   if (n_rows <= 0) return 0;
   const int vec4 = (dim % 4 == 0) && (row_stride % 4 == 0) && (((uintptr_t)h) % 8 == 0);
-  k_embed_norm<<<(n_rows + 3) / 4, SP_TPB, 0, (hipStream_t)stream>>>((const bf16_t*)h, n_rows, dim, row_stride, (bf16_t*)out, vec4);
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_EMBED_NORM, st, k_embed_norm<<<(n_rows + 3) / 4, SP_TPB, 0, st>>>((const bf16_t*)h, n_rows, dim, row_stride, (bf16_t*)out, vec4));
   return (int)hipGetLastError();
 }
 

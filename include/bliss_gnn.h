@@ -166,6 +166,16 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
 /* Exact row sum from scratch (initialisation / verification): row_sum int64[3]. */
 int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the launching stream (bench.py's roofline object).
+ * bliss_prof_enable(id): -2 off (default), -1 every kernel, >= 0 one kernel id; names via
+ * bliss_prof_kernel_name(id), id < bliss_prof_kernel_count().  bliss_prof_read synchronises on the
+ * recorded events and returns the summed duration and the number of launches since the last reset. */
+int bliss_prof_enable(int kernel_id);
+int bliss_prof_reset(void);
+int bliss_prof_read(int kernel_id, double* total_ms, int64_t* launches);
+int bliss_prof_kernel_count(void);
+const char* bliss_prof_kernel_name(int kernel_id);
+
 #ifdef __cplusplus
 }
 #endif
