@@ -68,6 +68,7 @@ class LayerEngine:
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
+        self.hist = torch.zeros(32768, dtype=torch.int32, device=dev)      # self-cleaning (k_poisson_scale)
         self.mt_dev = torch.empty(626, dtype=torch.int32, device=dev)
         self.mt_host = torch.empty(626, dtype=torch.int32).pin_memory()
         self.caps = None
@@ -198,7 +199,7 @@ class LayerEngine:
             cnt_ptr = counts.data_ptr() + 40 * n
             c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
                                 ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
-                                kept_nid.data_ptr(), node_prob.data_ptr(), cap["C"], ck)
+                                kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(), cap["C"], ck)
             w_pos = w_rows[n]
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,

@@ -40,7 +40,7 @@ class LayerCounts(C.Structure):
 class LayerWs(C.Structure):
     _fields_ = [("counts", C.c_void_p), ("seg_ptr", C.c_void_p), ("seed_acc", C.c_void_p), ("chunk_cnt", C.c_void_p),
                 ("cand_nid", C.c_void_p), ("p", C.c_void_p), ("P", C.c_void_p), ("new_id", C.c_void_p),
-                ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32)]
+                ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("hist", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32)]
 
 
 class BlockOut(C.Structure):
@@ -59,8 +59,8 @@ SIGNATURES = {
     "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],
     "bliss_normalized_edata": [C.POINTER(Graph), _P, _P],
     "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],
-    "bliss_spmm_fwd": [_P, _P, _P, _P, _I64, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P],
-    "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P],
+    "bliss_spmm_fwd": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
+    "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],

@@ -153,5 +153,40 @@ __device__ __forceinline__ int find_segment(const int* __restrict__ seg_ptr, int
   return lo;
 }
 
+// Segment (= seed column) of 64 CONSECUTIVE frontier positions base .. base+63, one per lane, without a
+// per-lane binary search: the wave loads the next 64 column boundaries once (coalesced) and every lane
+// counts the boundaries at or before its position with 6 shuffles.  k_hint (wave-uniform): a segment
+// known to start at or before `base` (carried from the previous 64 positions), or -1.
+// Returns the lane's segment; lanes at or past seg_ptr[S] (= E) get S.  Updates k_hint for base+64.
+__device__ __forceinline__ int wave_segment(const int* __restrict__ seg_ptr, int S, int base, int* k_hint) {
+  const int lane = lane_id();
+  int k0;
+  if (*k_hint < 0) {
+    k0 = find_segment(seg_ptr, S + 1, base);          // uniform address: one broadcast transaction per step
+  } else {
+    const int idx = *k_hint + 1 + lane;
+    const int b = idx <= S ? seg_ptr[idx] : 0x7fffffff;
+    const int adv = __popcll(__ballot(b <= base));
+    k0 = adv < 64 ? *k_hint + adv : find_segment(seg_ptr, S + 1, base);
+  }
+  const int idx = k0 + 1 + lane;
+  const int d = (idx <= S ? seg_ptr[idx] : 0x7fffffff) - base;   // > 0, non-decreasing over lanes
+  int k;
+  if (__shfl(d, 63) > 63) {                           // the window covers every boundary inside this span
+    int pos = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+      const int v = __shfl(d, pos + step - 1);
+      if (v <= lane) pos += step;
+    }
+    k = k0 + pos;
+  } else {                                            // > 64 boundaries in 64 positions (runs of empty columns)
+    k = find_segment(seg_ptr, S + 1, base + lane);
+  }
+  *k_hint = __shfl(k, 63);
+  if (*k_hint >= S) *k_hint = S - 1 >= 0 ? S - 1 : 0;
+  return k;
+}
+
 // Per-layer sizes kept on the device (the S/E/C/K/B symbols of SURVEY.md); layout = the ABI's.
 typedef bliss_layer_counts_t LayerCounts;

@@ -24,20 +24,44 @@
 
 namespace {
 
+// Work decomposition of every frontier pass: a workgroup (4 waves) owns a CHUNK of 1024 consecutive
+// frontier positions, a wave owns a SPAN of 256 consecutive positions inside it and walks it as 4
+// items of 64 (one position per lane).  Consecutive items let the segment lookup carry its hint, and
+// ordered ranks come from ballots + one 4-entry LDS exchange per chunk instead of a block scan per item.
+#define SPAN (64 * ITEMS)
+
 struct EdgeAt {
-  int k;          // seed index (local destination id)
+  int k;          // seed index (local destination id); valid iff e < E
   int64_t pos;    // CSC position
   int src;        // global source id
 };
 
-__device__ __forceinline__ EdgeAt decode(int e, int S, const int* __restrict__ seg_ptr,
+// lane's edge at frontier position e = base + lane (base wave-uniform)
+__device__ __forceinline__ EdgeAt decode(int base, int E, int S, const int* __restrict__ seg_ptr,
                                          const int* __restrict__ seeds, const int64_t* __restrict__ indptr,
-                                         const int* __restrict__ indices) {
+                                         const int* __restrict__ indices, int* k_hint) {
   EdgeAt r;
-  r.k = find_segment(seg_ptr, S, e);
-  r.pos = indptr[seeds[r.k]] + (e - seg_ptr[r.k]);
-  r.src = indices[r.pos];
+  const int e = base + lane_id();
+  r.k = wave_segment(seg_ptr, S, base, k_hint);
+  r.pos = 0; r.src = 0;
+  if (e < E) {
+    r.pos = indptr[seeds[r.k]] + (e - seg_ptr[r.k]);
+    r.src = indices[r.pos];
+  } else r.k = -1;
   return r;
+}
+
+// exclusive rank of this wave's span inside its chunk + chunk total, from per-wave totals (one barrier)
+__device__ __forceinline__ int chunk_wave_offset(int wave_total, int* sh4, int* chunk_total) {
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();                                   // sh4 free again
+  if (lane_id() == 0) sh4[wave] = wave_total;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < TPB / 64; ++w) { const int v = sh4[w]; tot += v; if (w < wave) off += v; }
+  *chunk_total = tot;
+  return off;
 }
 
 // q_ij = eta/n_i + (1-eta) * w_ij / sum_j w_ij        bandit_sampler.py:131-137
@@ -88,20 +112,28 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restric
                                                         const int* __restrict__ local_id, unsigned* first_pos,
                                                         unsigned long long* acc_w) {
   const int S = cnt->S, E = cnt->E;
+  const int nspans = (E + SPAN - 1) / SPAN;
   int bad = 0;
-  for (int base = blockIdx.x * TPB + (threadIdx.x & ~63); base < E; base += gridDim.x * TPB) {
-    int e = base + lane_id();
-    int k = -1;
-    int64_t term = 0;
-    if (e < E) {
-      EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
-      k = a.k;
-      if (local_id[a.src] < 0) {                       // not a seed: seeds are numbered already
-        if (first_pos[a.src] > (unsigned)e) atomicMin(first_pos + a.src, (unsigned)e);
+  for (int sp = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); sp < nspans; sp += gridDim.x * (TPB / 64)) {
+    int hint = -1;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int base = sp * SPAN + i * 64;
+      if (base >= E) break;                                 // wave-uniform
+      const int e = base + lane_id();
+      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      int64_t term = 0;
+      if (a.k >= 0) {
+        if (local_id[a.src] < 0) {                          // not a seed: seeds are numbered already
+          // the atomics execute at the memory side and leave nothing in L2, so a plain pre-check would keep
+          // reading a stale 0xFFFFFFFF line; an agent-scope (sc1) load sees the current minimum
+          if (__hip_atomic_load(first_pos + a.src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)e)
+            atomicMin(first_pos + a.src, (unsigned)e);
+        }
+        if (BANDIT) term = bf_to_fixed(w[a.pos], FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
       }
-      if (BANDIT) term = bf_to_fixed(w[a.pos], FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
+      if (BANDIT) wave_segsum_atomic_i64(a.k, term, acc_w);
     }
-    if (BANDIT) wave_segsum_atomic_i64(k, term, acc_w);
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -115,31 +147,33 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restric
                                                         const unsigned long long* __restrict__ acc_w,
                                                         unsigned long long* acc_q, int* __restrict__ chunk_cnt,
                                                         float eta_f, float ome_f) {
-  __shared__ int sh[17];
+  __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int nfirst = 0;
+    int nfirst = 0, hint = -1;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      int e = chunk * CHUNK + i * TPB + threadIdx.x;
-      int k = -1;
+      const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
+      if (base >= E) break;
+      const int e = base + lane_id();
+      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
       int64_t term = 0;
-      if (e < E) {
-        EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
-        k = a.k;
-        nfirst += (first_pos[a.src] == (unsigned)e);
+      bool first = false;
+      if (a.k >= 0) {
+        first = first_pos[a.src] == (unsigned)e;
         if (BANDIT) {
-          bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
-          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
+          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           term = bf_to_fixed(q, FRAC_DST, &bad);       // :67 copy_e_sum(insg, edge_prob)
         }
       }
-      if (BANDIT) wave_segsum_atomic_i64(k, term, acc_q);
+      nfirst += __popcll(__ballot(first));
+      if (BANDIT) wave_segsum_atomic_i64(a.k, term, acc_q);
     }
     int tot;
-    block_excl_scan(nfirst, sh, &tot);
+    chunk_wave_offset(nfirst, sh4, &tot);
     if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
   }
   if (bad) atomicOr(&cnt->err, bad);
@@ -178,20 +212,25 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
                                                         const int* __restrict__ chunk_off, int* local_id,
                                                         int* __restrict__ cand_nid, unsigned long long* acc_p2,
                                                         float eta_f, float ome_f, int cap_c) {
-  __shared__ int sh[17];
+  __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int run = chunk_off[chunk];
+    int hint = -1, wave_total = 0;
+    unsigned long long mask[ITEMS];
+    int srcs[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      int e = chunk * CHUNK + i * TPB + threadIdx.x;
-      int flag = 0, src = 0;
-      if (e < E) {
-        EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
-        src = a.src;
-        flag = (first_pos[src] == (unsigned)e);
+      mask[i] = 0; srcs[i] = 0;
+      const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
+      if (base >= E) continue;
+      const int e = base + lane_id();
+      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      bool first = false;
+      if (a.k >= 0) {
+        srcs[i] = a.src;
+        first = first_pos[a.src] == (unsigned)e;
         bf16_t t;
         if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
@@ -204,33 +243,55 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
           t = f2bf(x * x);
         }
         int64_t fx = bf_to_fixed(t, FRAC_SRC, &bad);
-        if (fx) atomicAdd(acc_p2 + src, (unsigned long long)fx);   // :73 copy_e_sum by SOURCE
+        if (fx) atomicAdd(acc_p2 + a.src, (unsigned long long)fx);   // :73 copy_e_sum by SOURCE
       }
-      int tot, rank = block_excl_scan(flag, sh, &tot);
-      if (flag) {
-        int id = S + run + rank;
-        if (id < cap_c) { local_id[src] = id; cand_nid[id] = src; }
+      mask[i] = __ballot(first);
+      wave_total += __popcll(mask[i]);
+    }
+    int tot;
+    int run = S + chunk_off[chunk] + chunk_wave_offset(wave_total, sh4, &tot);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if ((mask[i] >> lane_id()) & 1ull) {
+        const int id = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
+        if (id < cap_c) { local_id[srcs[i]] = id; cand_nid[id] = srcs[i]; }
       }
-      run += tot;
+      run += __popcll(mask[i]);
     }
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
 
-// ---------------------------------------------------------------- K_g: p_j = sqrt(sum), reset the dense maps
-__global__ void __launch_bounds__(TPB) k_cand_finalize(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
-                                                       unsigned long long* acc_p2, unsigned* first_pos,
-                                                       bf16_t* __restrict__ p, int cap_c) {
+// ---------------------------------------------------------------- K_g: p_j = sqrt(sum), reset the dense maps,
+// and histogram the bf16 bit patterns of p (32768 non-negative values) for the Poisson scale: the
+// reference evaluates sum_j min(c p_j, 1) up to 50 times over all C candidates with a host sync each
+// (bandit_sampler.py:396-401); with counts per distinct p the same sum costs 32 bins per thread.
+#define HIST_BINS 32768
+#define FIN_TPB 512
+__global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
+                                                           unsigned long long* acc_p2, unsigned* first_pos,
+                                                           bf16_t* __restrict__ p, int* hist, int cap_c) {
+  __shared__ int lh[HIST_BINS];                       // 128 KiB static LDS (one workgroup per CU; gfx950 has 160 KiB)
   const int S = cnt->S;
   const int C = min(cnt->C, cap_c);
+  if ((int)blockIdx.x * FIN_TPB >= C) return;         // surplus workgroups: nothing to zero, nothing to flush
+  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) lh[b] = 0;
+  __syncthreads();
   int bad = 0;
-  for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) {
+  for (int id = blockIdx.x * FIN_TPB + threadIdx.x; id < C; id += gridDim.x * FIN_TPB) {
     int g;
     if (id < S) { g = seeds[id]; cand_nid[id] = g; } else g = cand_nid[id];
     bf16_t p2 = fixed_to_bf((int64_t)acc_p2[g], FRAC_SRC, &bad);
     acc_p2[g] = 0;
     first_pos[g] = 0xffffffffu;
-    p[id] = f2bf(sqrtf(bf2f(p2)));                    // :75 torch.sqrt(prob)
+    const bf16_t pj = f2bf(sqrtf(bf2f(p2)));          // :75 torch.sqrt(prob)
+    p[id] = pj;
+    if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;   // sign bit set = negative / -0 cannot occur
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) {
+    int v = lh[b];
+    if (v) atomicAdd(hist + b, v);
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -250,9 +311,18 @@ __device__ __forceinline__ double block_sum_f64(double v, double* shd) {
   return t;
 }
 
-__global__ void __launch_bounds__(1024) k_poisson_scale(const bf16_t* __restrict__ p, LayerCounts* cnt, int num, double eps) {
+__global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps) {
   __shared__ double shd[16];
   const int C = cnt->C;
+  // every thread owns 32 bins; load the counts and leave the histogram zero for the next layer
+  int n[HIST_BINS / 1024];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < HIST_BINS / 1024; ++i) {
+    const int b = i * 1024 + threadIdx.x;
+    n[i] = hist[b];
+    if (n[i]) { hist[b] = 0; any = true; }
+  }
   if (C <= num) {                                     // :392-393 everything is kept
     if (threadIdx.x == 0) { cnt->c = 1.0; cnt->all_one = 1; cnt->iters = 0; }
     return;
@@ -262,9 +332,15 @@ __global__ void __launch_bounds__(1024) k_poisson_scale(const bf16_t* __restrict
   for (; it < 50; ++it) {                             // :396
     const float c32 = (float)c;                       // torch multiplies a bf16 tensor by a Python float in fp32
     double loc = 0;
-    for (int j = threadIdx.x; j < C; j += blockDim.x) {
-      float v = rbf(bf2f(p[j]) * c32);
-      loc += (double)(v < 1.0f ? v : (v != v ? v : 1.0f));   // torch.minimum propagates NaN
+    if (any) {
+#pragma unroll
+      for (int i = 0; i < HIST_BINS / 1024; ++i) {
+        if (n[i]) {
+          float v = rbf(bf2f((bf16_t)(i * 1024 + threadIdx.x)) * c32);
+          v = v < 1.0f ? v : (v != v ? v : 1.0f);     // torch.minimum propagates NaN
+          loc += (double)n[i] * (double)v;            // count * bf16 value: exact in fp64
+        }
+      }
     }
     double Ssum = block_sum_f64(loc, shd);            // :397, exact in fp64 (bf16 terms, < 2^24 of them)
     double lo = Ssum < (double)num ? Ssum : (double)num, hi = Ssum < (double)num ? (double)num : Ssum;
@@ -283,7 +359,7 @@ __device__ __forceinline__ bf16_t incl_prob(const bf16_t* __restrict__ p, int j,
 // ---------------------------------------------------------------- K_i: P_j, Bernoulli compare, count per chunk
 __global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__ p, const float* __restrict__ uniforms,
                                                       LayerCounts* cnt, bf16_t* __restrict__ P, int* __restrict__ chunk_cnt, int cap_c) {
-  __shared__ int sh[17];
+  __shared__ int sh4[TPB / 64];
   const int S = cnt->S, C = min(cnt->C, cap_c), all_one = cnt->all_one;
   const float c32 = (float)cnt->c;
   const int nchunks = (C + CHUNK - 1) / CHUNK;
@@ -291,15 +367,17 @@ __global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__
     int kept = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      int j = chunk * CHUNK + i * TPB + threadIdx.x;
+      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
+      bool keep = false;
       if (j < C) {
         bf16_t Pj = incl_prob(p, j, S, all_one, c32);
         P[j] = Pj;
-        kept += (uniforms[j] < bf2f(Pj));             // :422-424  ATen CPU bernoulli: u24 < float(P)
+        keep = uniforms[j] < bf2f(Pj);                // :422-424  ATen CPU bernoulli: u24 < float(P)
       }
+      kept += __popcll(__ballot(keep));
     }
     int tot;
-    block_excl_scan(kept, sh, &tot);
+    chunk_wave_offset(kept, sh4, &tot);
     if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
   }
 }
@@ -310,24 +388,34 @@ __global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ 
                                                       const int* __restrict__ cand_nid, int* __restrict__ new_id,
                                                       int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
                                                       int cap_c, int cap_k) {
-  __shared__ int sh[17];
+  __shared__ int sh4[TPB / 64];
   const int C = min(cnt->C, cap_c);
   const int nchunks = (C + CHUNK - 1) / CHUNK;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int run = chunk_off[chunk];
+    unsigned long long mask[ITEMS];
+    bf16_t Pv[ITEMS];
+    int wave_total = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      int j = chunk * CHUNK + i * TPB + threadIdx.x;
-      int flag = 0;
-      bf16_t Pj = 0;
-      if (j < C) { Pj = P[j]; flag = (uniforms[j] < bf2f(Pj)); }
-      int tot, rank = block_excl_scan(flag, sh, &tot);
+      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
+      bool keep = false;
+      Pv[i] = 0;
+      if (j < C) { Pv[i] = P[j]; keep = uniforms[j] < bf2f(Pv[i]); }
+      mask[i] = __ballot(keep);
+      wave_total += __popcll(mask[i]);
+    }
+    int tot;
+    int run = chunk_off[chunk] + chunk_wave_offset(wave_total, sh4, &tot);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
       if (j < C) {
-        int r = run + rank;
-        if (flag && r < cap_k) { kept_nid[r] = cand_nid[j]; node_prob[r] = Pj; new_id[j] = r; }   // :306,:309
+        const bool keep = (mask[i] >> lane_id()) & 1ull;
+        const int r = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
+        if (keep && r < cap_k) { kept_nid[r] = cand_nid[j]; node_prob[r] = Pv[i]; new_id[j] = r; }   // :306,:309
         else new_id[j] = -1;
       }
-      run += tot;
+      run += __popcll(mask[i]);
     }
   }
 }
@@ -341,38 +429,35 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      const int* __restrict__ local_id, const int* __restrict__ new_id,
                                                      const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
                                                      int* __restrict__ chunk_cnt, float eta_f, float ome_f) {
-  __shared__ int sh[17];
+  __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int nkept = 0;
+    int nkept = 0, hint = -1;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      int e = chunk * CHUNK + i * TPB + threadIdx.x;
-      int k = -1, kept = 0;
+      const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
+      if (base >= E) break;
+      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      int kept = 0;
       int64_t term = 0;
-      if (e < E) {
-        EdgeAt a = decode(e, S, seg_ptr, seeds, indptr, indices);
-        k = a.k;
-        int lid = local_id[a.src];
+      if (a.k >= 0) {
+        const int lid = local_id[a.src];
         kept = new_id[lid] >= 0;                       // :289-298 source was drawn (seeds always are)
-        if (kept) {
-          bf16_t q;
-          if (BANDIT) {
-            bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
-            q = edge_q(w[a.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
-          } else q = w[a.pos];
+        if (kept && BANDIT) {
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
+          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           bf16_t wt = f2bf(bf2f(q) / bf2f(P[lid]));    // :314 e_div_u(sg, W, P)
           term = bf_to_fixed(wt, FRAC_BLK, &bad);      // :316 copy_e_sum
         }
-        nkept += kept;
       }
-      wave_segsum_atomic_i32(k, kept, deg_blk);        // :318 sg.in_degrees()
-      if (BANDIT) wave_segsum_atomic_i64(k, term, acc_wt);
+      nkept += __popcll(__ballot(kept));
+      wave_segsum_atomic_i32(a.k, kept, deg_blk);      // :318 sg.in_degrees()
+      if (BANDIT) wave_segsum_atomic_i64(a.k, term, acc_wt);
     }
     int tot;
-    block_excl_scan(nkept, sh, &tot);
+    chunk_wave_offset(nkept, sh4, &tot);
     if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
   }
   if (bad) atomicOr(&cnt->err, bad);
@@ -406,34 +491,42 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      int* __restrict__ out_dst, int* __restrict__ out_pos,
                                                      int* __restrict__ out_eid, bf16_t* __restrict__ out_w,
                                                      bf16_t* __restrict__ out_q, float eta_f, float ome_f, int cap_b) {
-  __shared__ int sh[17];
+  __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int run = chunk_off[chunk];
+    int hint = -1, wave_total = 0;
+    unsigned long long mask[ITEMS];
+    EdgeAt ed[ITEMS];
+    int nids[ITEMS], lids[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      int e = chunk * CHUNK + i * TPB + threadIdx.x;
-      int kept = 0, nid = -1, lid = 0;
-      EdgeAt a;
-      a.k = 0; a.pos = 0; a.src = 0;
-      if (e < E) {
-        a = decode(e, S, seg_ptr, seeds, indptr, indices);
-        lid = local_id[a.src];
-        nid = new_id[lid];
-        kept = nid >= 0;
+      mask[i] = 0; nids[i] = -1; lids[i] = 0; ed[i].k = -1; ed[i].pos = 0; ed[i].src = 0;
+      const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
+      if (base >= E) continue;
+      ed[i] = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      if (ed[i].k >= 0) {
+        lids[i] = local_id[ed[i].src];
+        nids[i] = new_id[lids[i]];
       }
-      int tot, rank = block_excl_scan(kept, sh, &tot);
-      int idx = run + rank;
-      if (kept && idx < cap_b) {
-        const int k = a.k;
+      mask[i] = __ballot(nids[i] >= 0);
+      wave_total += __popcll(mask[i]);
+    }
+    int tot;
+    int run = chunk_off[chunk] + chunk_wave_offset(wave_total, sh4, &tot);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
+      if (nids[i] >= 0 && idx < cap_b) {
+        const int k = ed[i].k;
+        const int64_t pos = ed[i].pos;
         bf16_t q;
         if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
-          q = edge_q(w[a.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
-        } else q = w[a.pos];
-        float wt = rbf(bf2f(q) / bf2f(P[lid]));                        // :314
+          q = edge_q(w[pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+        } else q = w[pos];
+        float wt = rbf(bf2f(q) / bf2f(P[lids[i]]));                    // :314
         float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
         float out;
         if (BANDIT) {
@@ -443,14 +536,14 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
         } else {
           out = wt * d;                                                // ladies_sampler.py:97
         }
-        out_src[idx] = nid;
+        out_src[idx] = nids[i];
         out_dst[idx] = k;
-        out_pos[idx] = (int)a.pos;
-        out_eid[idx] = eid_map ? eid_map[a.pos] : (int)a.pos;          // :335-337
+        out_pos[idx] = (int)pos;
+        out_eid[idx] = eid_map ? eid_map[pos] : (int)pos;              // :335-337
         out_w[idx] = f2bf(out);                                        // :324 edge_weights
         out_q[idx] = q;                                                // :326 q_ij
       }
-      run += tot;
+      run += __popcll(mask[i]);
     }
   }
   if (bad) atomicOr(&cnt->err, bad);
@@ -486,7 +579,7 @@ int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
                         int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode, float eta_f,
                         float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream_) {
-  if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0) return BLISS_EINVAL;
+  if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0 || !ws->hist) return BLISS_EINVAL;
   if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
   if (n_seeds > cap_s) return BLISS_EINVAL;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
@@ -512,8 +605,13 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c));
   else
     PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c));
-  PROF_LAUNCH(BK_CAND_FINALIZE, st, k_cand_finalize<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(
-      seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->cap_c));
+  {
+    int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);          // ~8 candidates per thread: amortise the 128 KiB LDS zero/flush
+    if (gf < 1) gf = 1;
+    if (gf > 256) gf = 256;
+    PROF_LAUNCH(BK_CAND_FINALIZE, st, k_cand_finalize<<<gf, FIN_TPB, 0, st>>>(
+        seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->hist, ws->cap_c));
+  }
   return (int)hipGetLastError();
 }
 
@@ -525,7 +623,7 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   if (cand_bound < 1) cand_bound = 1;
   if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
   const int gc = grid_for(cand_bound, CHUNK);
-  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>((const bf16_t*)ws->p, cnt, fanout, eps));
+  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps));
   PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
   PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,

@@ -4,11 +4,11 @@
 // (dglnn.SAGEConv.forward, called from model.py:321-329) and its autograd backward, plus
 // th.norm(h, dim=1) of model.py:318-320.
 //
-// HBM-bound gather kernels: one 64-lane wave owns one output row; a lane owns 4 consecutive bf16
-// features (8-byte loads, 512 B per wave-instruction for a 256-wide row); the row's (src, w) pairs
-// are fetched 64 at a time, coalesced, and broadcast by lane; 4 neighbour rows are kept in flight.
-// fp32 accumulation, one rounding to bf16 at the store.  The backward is a gather too (through the
-// by-source transposed index), so it is deterministic and needs no float atomics.
+// HBM-bound gather kernels: a 64-lane wave owns 64 consecutive edges; a lane owns 4 consecutive bf16
+// features (8-byte loads, 512 B per wave-instruction for a 256-wide row); the (neighbour, coefficient)
+// pairs are fetched coalesced and broadcast by lane; 4 neighbour rows are kept in flight.  fp32
+// accumulation, one rounding to bf16 at the store.  The backward is a gather too (through the by-source
+// transposed index), so it is deterministic and needs no float atomics.
 #include "common.cuh"
 #include "bliss_gnn.h"
 #include "prof.h"
@@ -39,81 +39,126 @@ __device__ __forceinline__ void store4(void* out, int64_t off, f4 a) {
   }
 }
 
-// FWD: row = destination i, edge list = CSR row, neighbour = src[e], coefficient = w[e]
-// BWD: row = source j, edge list = t_edge[t_indptr[j]..], neighbour = dst[e], coefficient = w[e]/deg(dst[e])
+// Balanced ("merge-style") traversal: a wave owns EC = 64 consecutive entries of the edge list, whatever
+// rows they belong to, so a 30 000-edge hub row and a 3-edge row cost the same per wave.  Rows that lie
+// inside one chunk are finished and stored by that wave; a row cut by chunk boundaries leaves fp32
+// partials (one "head" and one "tail" slot per chunk) that k_spmm_fixup adds IN CHUNK ORDER -- the sum
+// order is fixed, so results are bitwise reproducible without float atomics.
+// FWD: row = destination (CSR row), neighbour = src[e], coefficient = w[e]            (x 1/deg at the store)
+// BWD: row = source (t_edge groups the edges by source), neighbour = dst[e], coefficient = w[e]/deg(dst[e])
+#define EC 64
+
+template <bool VEC4, bool OUT_F32>
+__device__ __forceinline__ void store_row(void* out, int64_t off, f4 a, float scale) {
+  a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+  if (VEC4) store4<OUT_F32>(out, off, a);
+  else if (OUT_F32) ((float*)out)[off] = a.x;
+  else ((bf16_t*)out)[off] = f2bf(a.x);
+}
+
 template <bool VEC4, bool OUT_F32, bool BWD>
-__global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr, const int* __restrict__ nbr_or_tedge,
-                                                const int* __restrict__ dst, const int* __restrict__ blk_indptr,
-                                                const bf16_t* __restrict__ w, const bf16_t* __restrict__ h, int64_t h_stride,
-                                                int n_rows, int dim, int mean, void* out, int64_t out_stride) {
+__global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr, const int* __restrict__ t_edge,
+                                                const int* __restrict__ src, const int* __restrict__ dst,
+                                                const int* __restrict__ blk_indptr, const bf16_t* __restrict__ w,
+                                                const bf16_t* __restrict__ h, int64_t h_stride, int n_rows, int nnz, int dim,
+                                                int mean, void* out, int64_t out_stride, float* __restrict__ part) {
   const int lane = lane_id();
-  const int row = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
-  if (row >= n_rows) return;
-  const int beg = row_ptr[row], end = row_ptr[row + 1];
-  float inv = 1.0f;
-  if (!BWD && mean) inv = 1.0f / (float)max(end - beg, 1);
+  const int chunk = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
+  const int nchunks = nnz > 0 ? (nnz + EC - 1) / EC : 1;
+  if (chunk >= nchunks) return;
+  const int c0 = chunk * EC, c1 = min(nnz, c0 + EC), cnt = c1 - c0;
+  int my_row = -1, my_n = 0;
+  float my_c = 0.f;
+  if (lane < cnt) {
+    const int e = BWD ? t_edge[c0 + lane] : c0 + lane;
+    my_row = BWD ? src[e] : dst[e];
+    my_n = BWD ? dst[e] : src[e];
+    float c = w ? bf2f(w[e]) : 1.0f;
+    if (BWD && mean) { const int d = dst[e]; c = c / (float)max(blk_indptr[d + 1] - blk_indptr[d], 1); }
+    my_c = c;
+  }
   constexpr int W = VEC4 ? 4 : 1;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int col0 = 0; col0 < dim; col0 += 64 * W) {
     const int col = col0 + lane * W;
     const bool act = col < dim;
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int base = beg; base < end; base += 64) {
-      // coalesced fetch of up to 64 (neighbour, coefficient) pairs
-      int my_n = 0;
-      float my_c = 0.f;
-      if (base + lane < end) {
-        int e = base + lane;
-        if (BWD) {
-          e = nbr_or_tedge[e];
-          int d = dst[e];
-          my_n = d;
-          float c = w ? bf2f(w[e]) : 1.0f;
-          if (mean) c = c / (float)max(blk_indptr[d + 1] - blk_indptr[d], 1);
-          my_c = c;
-        } else {
-          my_n = nbr_or_tedge[e];
-          my_c = w ? bf2f(w[e]) : 1.0f;
-        }
+    // finish row r with the accumulated value: store, or leave a partial for the fix-up pass
+    auto flush = [&](int r, f4 acc) {
+      const int rb = row_ptr[r], re = row_ptr[r + 1];
+      const bool starts = rb >= c0, ends = re <= c1;
+      if (!act) return;
+      if (starts && ends) {
+        const float scale = (!BWD && mean) ? 1.0f / (float)max(re - rb, 1) : 1.0f;
+        store_row<VEC4, OUT_F32>(out, r * out_stride + col, acc, scale);
+      } else {
+        float* q = part + ((int64_t)chunk * 2 + (starts ? 1 : 0)) * dim + col;
+        q[0] = acc.x;
+        if (VEC4) { q[1] = acc.y; q[2] = acc.z; q[3] = acc.w; }
       }
-      const int cnt = min(64, end - base);
-      int j = 0;
-      for (; j + 4 <= cnt; j += 4) {
+    };
+    auto zero_rows = [&](int ra, int rb_) {                 // rows ra .. rb_-1 have no edges
+      if (act) for (int r = ra; r < rb_; ++r) store_row<VEC4, OUT_F32>(out, r * out_stride + col, zero, 1.0f);
+    };
+    if (cnt == 0) { zero_rows(0, n_rows); continue; }       // nnz == 0: chunk 0 clears the output
+    int cur = __shfl(my_row, 0);
+    { int r = cur - 1; while (r >= 0 && row_ptr[r] == c0) --r; zero_rows(r + 1, cur); }   // empty rows parked at c0
+    f4 acc = zero;
+    for (int j = 0; j < cnt;) {
+      const int r = __shfl(my_row, j);
+      if (r != cur) { flush(cur, acc); zero_rows(cur + 1, r); acc = zero; cur = r; }
+      const int run = __popcll(__ballot(my_row == r && lane >= j));
+      const int end = j + run;
+      for (; j + 4 <= end; j += 4) {
         int n0 = __shfl(my_n, j), n1 = __shfl(my_n, j + 1), n2 = __shfl(my_n, j + 2), n3 = __shfl(my_n, j + 3);
-        float c0 = __shfl(my_c, j), c1 = __shfl(my_c, j + 1), c2 = __shfl(my_c, j + 2), c3 = __shfl(my_c, j + 3);
+        float k0 = __shfl(my_c, j), k1 = __shfl(my_c, j + 1), k2 = __shfl(my_c, j + 2), k3 = __shfl(my_c, j + 3);
         if (act) {
           if (VEC4) {
             f4 a0 = load4(h + n0 * h_stride + col), a1 = load4(h + n1 * h_stride + col);
             f4 a2 = load4(h + n2 * h_stride + col), a3 = load4(h + n3 * h_stride + col);
-            acc.x += c0 * a0.x; acc.y += c0 * a0.y; acc.z += c0 * a0.z; acc.w += c0 * a0.w;
-            acc.x += c1 * a1.x; acc.y += c1 * a1.y; acc.z += c1 * a1.z; acc.w += c1 * a1.w;
-            acc.x += c2 * a2.x; acc.y += c2 * a2.y; acc.z += c2 * a2.z; acc.w += c2 * a2.w;
-            acc.x += c3 * a3.x; acc.y += c3 * a3.y; acc.z += c3 * a3.z; acc.w += c3 * a3.w;
+            acc.x += k0 * a0.x; acc.y += k0 * a0.y; acc.z += k0 * a0.z; acc.w += k0 * a0.w;
+            acc.x += k1 * a1.x; acc.y += k1 * a1.y; acc.z += k1 * a1.z; acc.w += k1 * a1.w;
+            acc.x += k2 * a2.x; acc.y += k2 * a2.y; acc.z += k2 * a2.z; acc.w += k2 * a2.w;
+            acc.x += k3 * a3.x; acc.y += k3 * a3.y; acc.z += k3 * a3.z; acc.w += k3 * a3.w;
           } else {
             float a0 = bf2f(h[n0 * h_stride + col]), a1 = bf2f(h[n1 * h_stride + col]);
             float a2 = bf2f(h[n2 * h_stride + col]), a3 = bf2f(h[n3 * h_stride + col]);
-            acc.x += c0 * a0; acc.x += c1 * a1; acc.x += c2 * a2; acc.x += c3 * a3;
+            acc.x += k0 * a0; acc.x += k1 * a1; acc.x += k2 * a2; acc.x += k3 * a3;
           }
         }
       }
-      for (; j < cnt; ++j) {
+      for (; j < end; ++j) {
         int n0 = __shfl(my_n, j);
-        float c0 = __shfl(my_c, j);
+        float k0 = __shfl(my_c, j);
         if (act) {
           if (VEC4) {
             f4 a0 = load4(h + n0 * h_stride + col);
-            acc.x += c0 * a0.x; acc.y += c0 * a0.y; acc.z += c0 * a0.z; acc.w += c0 * a0.w;
-          } else {
-            acc.x += c0 * bf2f(h[n0 * h_stride + col]);
-          }
+            acc.x += k0 * a0.x; acc.y += k0 * a0.y; acc.z += k0 * a0.z; acc.w += k0 * a0.w;
+          } else acc.x += k0 * bf2f(h[n0 * h_stride + col]);
         }
       }
     }
-    if (act) {
-      acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-      if (VEC4) store4<OUT_F32>(out, row * out_stride + col, acc);
-      else if (OUT_F32) ((float*)out)[row * out_stride + col] = acc.x;
-      else ((bf16_t*)out)[row * out_stride + col] = f2bf(acc.x);
-    }
+    flush(cur, acc);
+    if (c1 == nnz) zero_rows(cur + 1, n_rows);              // trailing empty rows belong to the last chunk
+  }
+}
+
+// rows cut by chunk boundaries: tail partial of the chunk they start in + head partials of the following chunks
+template <bool OUT_F32, bool BWD>
+__global__ void __launch_bounds__(SP_TPB) k_spmm_fixup(const int* __restrict__ row_ptr, int n_rows, int dim, int mean,
+                                                      const float* __restrict__ part, void* out, int64_t out_stride) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int rb = row_ptr[r], re = row_ptr[r + 1];
+  if (re <= rb) return;
+  const int c = rb / EC, c_end = (re - 1) / EC;
+  if (c_end == c) return;                                   // finished by its chunk
+  const float scale = (!BWD && mean) ? 1.0f / (float)(re - rb) : 1.0f;
+  for (int col = lane; col < dim; col += 64) {
+    float sum = part[((int64_t)c * 2 + 1) * dim + col];
+    for (int cc = c + 1; cc <= c_end; ++cc) sum += part[((int64_t)cc * 2) * dim + col];
+    sum *= scale;
+    if (OUT_F32) ((float*)out)[r * out_stride + col] = sum; else ((bf16_t*)out)[r * out_stride + col] = f2bf(sum);
   }
 }
 
@@ -138,16 +183,23 @@ __global__ void __launch_bounds__(SP_TPB) k_embed_norm(const bf16_t* __restrict_
 }
 
 template <bool BWD>
-int launch_spmm(const int* row_ptr, const int* idx, const int* dst, const int* blk_indptr, const void* w, const void* h,
-                int64_t h_stride, int n_rows, int dim, int mean, void* out, int64_t out_stride, int out_fp32, hipStream_t st) {
+int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int* dst, const int* blk_indptr, const void* w,
+                const void* h, int64_t h_stride, int n_rows, int nnz, int dim, int mean, void* out, int64_t out_stride,
+                int out_fp32, float* part, hipStream_t st) {
   if (n_rows <= 0 || dim <= 0) return 0;
+  if (nnz > 0 && !part) return BLISS_EINVAL;
   const bool vec4 = (dim % 4 == 0) && (h_stride % 4 == 0) && (out_stride % 4 == 0) &&
                     (((uintptr_t)h) % 8 == 0) && (((uintptr_t)out) % (out_fp32 ? 16 : 8) == 0);
-  dim3 grid((n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64)), block(SP_TPB);
-#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, idx, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, dim, mean, out, out_stride))
+  const int nchunks = nnz > 0 ? (nnz + EC - 1) / EC : 1;
+  dim3 grid((nchunks + SP_TPB / 64 - 1) / (SP_TPB / 64)), block(SP_TPB), gfix((n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64));
+#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, t_edge, src, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, nnz, dim, mean, out, out_stride, part))
   if (vec4) { if (out_fp32) GO(true, true); else GO(true, false); }
   else      { if (out_fp32) GO(false, true); else GO(false, false); }
 #undef GO
+  if (nnz > EC) {
+    if (out_fp32) PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<true, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride));
+    else PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<false, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride));
+  }
   return (int)hipGetLastError();
 }
 
@@ -155,17 +207,20 @@ int launch_spmm(const int* row_ptr, const int* idx, const int* dst, const int* b
 
 extern "C" {
 
-int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const void* w, const void* h, int64_t h_stride,
-                   int32_t n_dst, int32_t dim, int mean, void* out, int64_t out_stride, int out_fp32, void* stream) {
-  if (!indptr || !h || !out) return BLISS_EINVAL;   // src may be NULL for an edgeless block
-  return launch_spmm<false>(indptr, src, nullptr, nullptr, w, h, h_stride, n_dst, dim, mean, out, out_stride, out_fp32, (hipStream_t)stream);
+int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const int32_t* dst, const void* w, const void* h,
+                   int64_t h_stride, int32_t n_dst, int32_t nnz, int32_t dim, int mean, void* out, int64_t out_stride,
+                   int out_fp32, float* partials, void* stream) {
+  if (!indptr || !h || !out || nnz < 0 || (nnz > 0 && (!src || !dst))) return BLISS_EINVAL;
+  return launch_spmm<false>(indptr, nullptr, src, dst, nullptr, w, h, h_stride, n_dst, nnz, dim, mean, out, out_stride, out_fp32,
+                            partials, (hipStream_t)stream);
 }
 
-int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* dst, const int32_t* indptr,
-                   const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t dim, int mean,
-                   void* gh, int64_t gh_stride, int out_fp32, void* stream) {
-  if (!t_indptr || !indptr || !gout || !gh) return BLISS_EINVAL;   // t_edge/dst may be NULL for an edgeless block
-  return launch_spmm<true>(t_indptr, t_edge, dst, indptr, w, gout, gout_stride, n_src, dim, mean, gh, gh_stride, out_fp32, (hipStream_t)stream);
+int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
+                   const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t nnz,
+                   int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32, float* partials, void* stream) {
+  if (!t_indptr || !indptr || !gout || !gh || nnz < 0 || (nnz > 0 && (!t_edge || !src || !dst))) return BLISS_EINVAL;
+  return launch_spmm<true>(t_indptr, t_edge, src, dst, indptr, w, gout, gout_stride, n_src, nnz, dim, mean, gh, gh_stride,
+                           out_fp32, partials, (hipStream_t)stream);
 }
 
 int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_stride, void* out, void* stream) {

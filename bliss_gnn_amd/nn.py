@@ -44,9 +44,12 @@ class _WeightedAggregate(torch.autograd.Function):
                 w = w.bfloat16()
             w = w.contiguous()
             assert w.numel() == block.num_edges()
-        _lib.check(_lib.lib.bliss_spmm_fwd(block.indptr.data_ptr(), block.src.data_ptr(), 0 if w is None else w.data_ptr(),
-                                           h.data_ptr(), h.stride(0), S, D, int(mean), out.data_ptr(), out.stride(0),
-                                           int(out_fp32), _stream()), "bliss_spmm_fwd")
+        B = block.num_edges()
+        part = torch.empty(2 * ((B + 63) // 64) * D, dtype=torch.float32, device=h.device) if B > 0 else None
+        _lib.check(_lib.lib.bliss_spmm_fwd(block.indptr.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
+                                           0 if w is None else w.data_ptr(), h.data_ptr(), h.stride(0), S, B, D, int(mean),
+                                           out.data_ptr(), out.stride(0), int(out_fp32), 0 if part is None else part.data_ptr(),
+                                           _stream()), "bliss_spmm_fwd")
         ctx.block, ctx.w, ctx.mean, ctx.n_src = block, w, mean, h.shape[0]
         return out
 
@@ -59,10 +62,12 @@ class _WeightedAggregate(torch.autograd.Function):
         D = gout.shape[1]
         t_indptr, t_edge = block.transposed()
         gh = torch.empty(ctx.n_src, D, dtype=torch.bfloat16, device=gout.device)
-        _lib.check(_lib.lib.bliss_spmm_bwd(t_indptr.data_ptr(), t_edge.data_ptr(), block.dst.data_ptr(),
+        B = block.num_edges()
+        part = torch.empty(2 * ((B + 63) // 64) * D, dtype=torch.float32, device=gout.device) if B > 0 else None
+        _lib.check(_lib.lib.bliss_spmm_bwd(t_indptr.data_ptr(), t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
                                            block.indptr.data_ptr(), 0 if w is None else w.data_ptr(), gout.data_ptr(),
-                                           gout.stride(0), ctx.n_src, D, int(ctx.mean), gh.data_ptr(), gh.stride(0), 0,
-                                           _stream()), "bliss_spmm_bwd")
+                                           gout.stride(0), ctx.n_src, B, D, int(ctx.mean), gh.data_ptr(), gh.stride(0), 0,
+                                           0 if part is None else part.data_ptr(), _stream()), "bliss_spmm_bwd")
         return gh, None, None, None, None
 
 

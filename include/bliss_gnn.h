@@ -70,6 +70,7 @@ typedef struct {
   int32_t* new_id;          /* [cap_c] block-local id of a kept candidate, -1 otherwise */
   int32_t* kept_nid;        /* [cap_k] global id of every kept node (block srcdata[NID]) */
   void* node_prob;          /* bf16 [cap_k] srcdata['node_prob'] */
+  int32_t* hist;            /* [32768] counts per bf16 bit pattern of p; zero on entry, left zero */
   int32_t cap_c, cap_k;
 } bliss_layer_ws_t;
 
@@ -129,15 +130,18 @@ int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_str
 /* SAGEConv 'mean' message passing with edge weights [DGL-recalled: update_all(u_mul_e, mean)],
  * model.py:321-329.  out[i,:] = (1/max(deg_i,1)) * sum_{e in row i} w_e * h[src_e,:]  (mean != 0)
  * or the plain weighted sum (mean == 0).  h bf16 [n_src, dim] (row stride in elements), w bf16
- * [nnz] or NULL (= 1), out bf16 (out_fp32 == 0) or fp32 [n_dst, dim]. */
-int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const void* w, const void* h, int64_t h_stride,
-                   int32_t n_dst, int32_t dim, int mean, void* out, int64_t out_stride, int out_fp32, void* stream);
+ * [nnz] or NULL (= 1), out bf16 (out_fp32 == 0) or fp32 [n_dst, dim]; src/dst [nnz] = the block's edges
+ * (CSR order: dst non-decreasing). */
+int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const int32_t* dst, const void* w, const void* h,
+                   int64_t h_stride, int32_t n_dst, int32_t nnz, int32_t dim, int mean, void* out, int64_t out_stride,
+                   int out_fp32, float* partials, void* stream);
 
 /* Backward of the above w.r.t. h: gh[j,:] = sum_{e: src_e = j} (w_e / max(deg_dst(e),1)) * gout[dst_e,:].
- * t_indptr [n_src+1], t_edge [nnz]: the block's edges grouped by SOURCE (bliss_block_transpose). */
-int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* dst, const int32_t* indptr,
-                   const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t dim, int mean,
-                   void* gh, int64_t gh_stride, int out_fp32, void* stream);
+ * t_indptr [n_src+1], t_edge [nnz]: the block's edges grouped by SOURCE in ascending edge order.
+ * partials (both calls): fp32 scratch [2 * ceil(nnz/64) * dim] for rows cut by the 64-edge work chunks. */
+int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
+                   const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t nnz,
+                   int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32, float* partials, void* stream);
 
 /* calculate_alpha (SAGE/GCN) + calculate_rewards + update_exp3_weights up to the scatter,
  * bandit_sampler.py:157, :180-193, :221-248.  One launch per block.
