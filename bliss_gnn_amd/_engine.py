@@ -70,7 +70,9 @@ class LayerEngine:
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
         self.hist = torch.zeros(32768, dtype=torch.int32, device=dev)      # self-cleaning (k_poisson_scale)
         self.mt_dev = torch.empty(626, dtype=torch.int32, device=dev)
-        self.mt_host = torch.empty(626, dtype=torch.int32).pin_memory()
+        self.mt_host = torch.empty(626, dtype=torch.int32).pin_memory()        # state handed to the device
+        self.mt_back = torch.empty(626, dtype=torch.int32).pin_memory()        # state handed back
+        self._static = None
         self.caps = None
         self.ws = None
         self.counts_host = None
@@ -118,17 +120,17 @@ class LayerEngine:
         a = state_bytes.numpy()
         return a[8:12].view(np.int32), a[16:24].view(np.int64), a[24:24 + 624 * 8].view(np.uint64)
 
-    def _upload_rng(self, snapshot):
+    def _stage_rng(self, snapshot):
+        """Host half of the hand-over: put the generator state where the (possibly graph-captured) H2D copy reads it."""
         left, nxt, st = self._rng_fields(snapshot)
         h = self.mt_host.numpy()
         h[:624] = st.astype(np.uint32).view(np.int32)
         h[624], h[625] = int(left[0]), int(nxt[0])
-        self.mt_dev.copy_(self.mt_host, non_blocking=True)
 
     def _commit_rng(self, snapshot):
         """Make the global CPU generator continue after the numbers the device consumed."""
         left, nxt, st = self._rng_fields(snapshot)
-        h = self.mt_host.numpy()
+        h = self.mt_back.numpy()
         st[:] = h[:624].view(np.uint32).astype(np.uint64)
         left[0], nxt[0] = int(h[624]), int(h[625])
         torch.set_rng_state(snapshot)
@@ -150,7 +152,7 @@ class LayerEngine:
             counts_dev = out[0]
             self.counts_host.copy_(counts_dev, non_blocking=True)
             if snapshot is not None:
-                self.mt_host.copy_(self.mt_dev, non_blocking=True)
+                self.mt_back.copy_(self.mt_dev, non_blocking=True)
             torch.cuda.current_stream().synchronize()                 # the ONE sync of the step's sampling
             raw = self.counts_host.numpy().tobytes()
             cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
@@ -170,11 +172,69 @@ class LayerEngine:
             self._commit_rng(snapshot)
         return self._finish(out, cnts)
 
+    # ------------------------------------------------------------------ static-shape (graph-capturable) variant
+    def set_static_caps(self, S0, fanouts, max_sizes, k_margin=1.5, b_margin=3.0):
+        """Fix the capacities from sizes observed in exact mode (``max_sizes[n] = dict(K=, B=)`` in sampling
+        order).  Static shapes mean no host round trip inside a step and a step that can be captured in a HIP graph;
+        the price is that a step whose true sizes exceed these capacities is detected only afterwards."""
+        caps, s = [], int(S0)
+        for n, f in enumerate(fanouts):
+            k = min(self.V, int(k_margin * max_sizes[n]["K"]) + 256)
+            b = int(min(self.Eg, int(b_margin * max_sizes[n]["B"]) + 4096))
+            caps.append(dict(S=s, C=self.V, K=k, B=b))
+            s = k
+        self.caps, self.ws = caps, None
+        self._ensure(S0, fanouts)
+
+    def stage_rng_from_torch(self):
+        """Host side, before enqueueing / replaying a static step: snapshot torch's CPU generator for the device."""
+        self._static_snapshot = torch.get_rng_state()
+        self._stage_rng(self._static_snapshot)
+
+    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999):
+        """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
+        blocks (sampling order); sizes, errors and the generator state are read back by finish()."""
+        L = len(fanouts)
+        out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True)
+        counts_dev, layers = out
+        self.counts_host.copy_(counts_dev, non_blocking=True)
+        self.mt_back.copy_(self.mt_dev, non_blocking=True)
+        blocks = []
+        for n, lay in enumerate(layers):
+            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev = lay
+            cap = self.caps[n]
+            blk = Block(self.g, cap["K"], cap["S"], b_indptr, b_src, b_dst, b_pos, b_eid, kept_nid)
+            blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
+            blk._counts, blk._counts_dev = None, cdev
+            blk._nnz_ptr = counts_dev.data_ptr() + 40 * n + 16
+            blk._trace = {}
+            blocks.append(blk)
+        self._static = (blocks, L)          # kept: a captured graph replays this enqueue without re-running it
+        return blocks
+
+    def finish(self):
+        """After the stream has been synchronised: true sizes, error check, generator hand-back."""
+        blocks, L = self._static
+        raw = self.counts_host.numpy().tobytes()
+        cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
+        bad = 0
+        for c in cnts:
+            bad |= c.err
+        for b, c in zip(blocks, cnts):
+            b._counts = c
+        self._commit_rng(self._static_snapshot)
+        if bad:
+            raise RuntimeError(f"static-shape step exceeded its capacities or hit a kernel error 0x{bad:x} "
+                               f"({_lib.err_string(bad)}); the step's results are invalid -- raise the margins")
+        return cnts
+
     def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
         if snapshot is not None:
-            self._upload_rng(snapshot)
+            if snapshot is not True:
+                self._stage_rng(snapshot)
+            self.mt_dev.copy_(self.mt_host, non_blocking=True)
         counts = torch.empty(L * 10, dtype=torch.int32, device=dev)
         eta_f = float(np.float32(eta))
         ome_f = float(np.float32(1.0 - eta))

@@ -59,8 +59,9 @@ SIGNATURES = {
     "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],
     "bliss_normalized_edata": [C.POINTER(Graph), _P, _P],
     "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],
-    "bliss_spmm_fwd": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
-    "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
+    "bliss_spmm_fwd": [_P, _P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
+    "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
+    "bliss_block_transpose": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
@@ -70,6 +71,9 @@ SIGNATURES = {
     "bliss_prof_read": [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "bliss_prof_kernel_count": [],
 }
+
+
+SPECIAL_SIGNATURES = ("bliss_prof_kernel_name", "bliss_block_transpose_temp_bytes")   # non-int return types, set in _load()
 
 
 def _load():
@@ -82,6 +86,8 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.bliss_block_transpose_temp_bytes.argtypes = [_I32, _I32]
+    lib.bliss_block_transpose_temp_bytes.restype = C.c_int64
     lib.bliss_prof_kernel_name.argtypes = [C.c_int]
     lib.bliss_prof_kernel_name.restype = C.c_char_p
     assert lib.bliss_layer_counts_bytes() == C.sizeof(LayerCounts), "LayerCounts layout mismatch"

@@ -142,6 +142,28 @@ class BanditLadiesSampler(BlockSampler):
             blocks.insert(0, blk)                                       # :366
         return blocks[0].srcdata[NID], output_nodes, blocks             # :364,:367
 
+    def sample_blocks_static(self, g, seed_nodes):
+        """sample_blocks with capacity-padded (static-shape) blocks and no host round trip: everything is only
+        ENQUEUED, so the whole train step can be recorded into a HIP graph.  Call ``engine.stage_rng_from_torch()``
+        before and ``finish_static()`` after the stream has been synchronised.  Padded rows / edges are inert:
+        ids past the true K point at node 0 and no edge references them; edges past the true B are ignored by
+        every kernel (the true counts live on the device)."""
+        eng = self._bind(g)
+        self._ensure_weights(g)
+        order = list(reversed(range(len(self.nodes_per_layer))))
+        blks = eng.enqueue_static([self._w_pos[b] for b in order], seed_nodes, [self.nodes_per_layer[b] for b in order],
+                                  _lib.MODE_BANDIT, self.eta, self.eps)
+        blocks = []
+        for blk in blks:
+            blk.edata[self.output_weight] = blk._edge_weights
+            blk.edata["q_ij"] = blk._q
+            blk.srcdata[self.node_prob] = blk._node_prob
+            blocks.insert(0, blk)
+        return blocks[0].srcdata[NID], seed_nodes, blocks
+
+    def finish_static(self):
+        return self._engine.finish()
+
     # -- bandit update ----------------------------------------------------------------------
     def exp3(self, mfgs, g, apply=True, factors=None):
         """bandit_sampler.py:251-267: rewards + weight update + L1 renormalisation, per block.

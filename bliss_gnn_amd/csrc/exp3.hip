@@ -158,6 +158,8 @@ __global__ void __launch_bounds__(E3_TPB) k_row_sum(const bf16_t* __restrict__ w
   if (bad && err) atomicOr(err, bad);
 }
 
+__global__ void k_zero_i64(int64_t* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0; }
+
 // scratch: [0] = norm bits | (skip << 16) | (err << 20), [1..3] = limbs of the renormalised row
 __global__ void k_norm_decide(const int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
   int bad = 0;
@@ -254,8 +256,7 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
 int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream) {
   if (!w_pos || !row_sum || num_edges <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(row_sum, 0, 3 * sizeof(int64_t), st);
-  if (e != hipSuccess) return (int)e;
+  k_zero_i64<<<1, 64, 0, st>>>(row_sum, 3);          // not hipMemsetAsync: see k_init_counts in sampler.hip
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   if (grid > 4096) grid = 4096;
   PROF_LAUNCH(BK_ROW_SUM, st, k_row_sum<<<(int)grid, E3_TPB, 0, st>>>((const bf16_t*)w_pos, num_edges, row_sum, nullptr));

@@ -418,6 +418,9 @@ __global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ 
       run += __popcll(mask[i]);
     }
   }
+  // capacity padding: ids past K stay valid node ids (0) so that padded feature gathers are harmless
+  const int K = min(cnt->K, cap_k);
+  for (int r = K + blockIdx.x * TPB + threadIdx.x; r < cap_k; r += gridDim.x * TPB) { kept_nid[r] = 0; node_prob[r] = 0x3f80; }
 }
 
 // ---------------------------------------------------------------- K_l: kept in-degree, sum of q/P per destination
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
 }
 
 // ---------------------------------------------------------------- block CSR indptr from kept in-degrees
-__global__ void __launch_bounds__(1024) k_indptr_scan(const int* __restrict__ deg_blk, LayerCounts* cnt, int* __restrict__ blk_indptr) {
+__global__ void __launch_bounds__(1024) k_indptr_scan(const int* __restrict__ deg_blk, LayerCounts* cnt, int* __restrict__ blk_indptr, int cap_s) {
   __shared__ int sh[17];
   const int S = cnt->S;
   int run = 0;
@@ -475,7 +478,8 @@ __global__ void __launch_bounds__(1024) k_indptr_scan(const int* __restrict__ de
     if (k < S) blk_indptr[k] = run + ex;
     run += tot;
   }
-  if (threadIdx.x == 0) blk_indptr[S] = run;
+  // rows S .. cap_s are empty: capacity-padded consumers (static shapes, HIP-graph replay) may walk them
+  for (int k = S + threadIdx.x; k <= cap_s; k += blockDim.x) blk_indptr[k] = run;
 }
 
 // ---------------------------------------------------------------- K_n: emit the block's edges in frontier order
@@ -555,10 +559,16 @@ __global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __
   for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) local_id[cand_nid[id]] = -1;
 }
 
-__global__ void k_init_counts(LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s) {
-  int S = S_host >= 0 ? S_host : *S_dev, err = 0;
-  if (S > cap_s) { S = cap_s; err = BLISS_ERR_CAP_SEEDS; }     // clamp: results invalid but in bounds
-  cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+// also zeroes the per-seed accumulators (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph
+// were observed to leave this buffer stale on replay -- ROCm 7.2)
+__global__ void __launch_bounds__(256) k_init_counts(LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
+                                                     unsigned long long* __restrict__ seed_acc, int n_words) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) seed_acc[i] = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int S = S_host >= 0 ? S_host : *S_dev, err = 0;
+    if (S > cap_s) { S = cap_s; err = BLISS_ERR_CAP_SEEDS; }     // clamp: results invalid but in bounds
+    cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+  }
 }
 
 inline int grid_for(int64_t n, int per_block, int max_blocks = 2048) {
@@ -590,8 +600,12 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   unsigned long long* acc_q = acc_w + cap_s;                                // [cap_s]
   if (frontier_bound < 1) frontier_bound = 1;
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
-  k_init_counts<<<1, 1, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s);
-  CK(hipMemsetAsync(ws->seed_acc, 0, (size_t)cap_s * 32, st));              // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
+  {
+    const int n_words = cap_s * 4;                                          // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
+    int gi = (n_words + 255) / 256;
+    if (gi > 1024) gi = 1024;
+    k_init_counts<<<gi, 256, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s, acc_w, n_words);
+  }
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes));
   if (mode == BLISS_MODE_BANDIT) {
     PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
@@ -649,7 +663,7 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   else
     PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 2, out->cap_b));
-  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_indptr_scan<<<1, 1024, 0, st>>>(deg_blk, cnt, out->indptr));
+  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_indptr_scan<<<1, 1024, 0, st>>>(deg_blk, cnt, out->indptr, cap_s));
   if (mode == BLISS_MODE_BANDIT)
     PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b));
   else

@@ -60,8 +60,10 @@ template <bool VEC4, bool OUT_F32, bool BWD>
 __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr, const int* __restrict__ t_edge,
                                                 const int* __restrict__ src, const int* __restrict__ dst,
                                                 const int* __restrict__ blk_indptr, const bf16_t* __restrict__ w,
-                                                const bf16_t* __restrict__ h, int64_t h_stride, int n_rows, int nnz, int dim,
+                                                const bf16_t* __restrict__ h, int64_t h_stride, int n_rows,
+                                                const int* __restrict__ nnz_dev, int nnz_host, int dim,
                                                 int mean, void* out, int64_t out_stride, float* __restrict__ part) {
+  const int nnz = nnz_dev ? min(*nnz_dev, nnz_host) : nnz_host;
   const int lane = lane_id();
   const int chunk = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
   const int nchunks = nnz > 0 ? (nnz + EC - 1) / EC : 1;
@@ -184,15 +186,15 @@ __global__ void __launch_bounds__(SP_TPB) k_embed_norm(const bf16_t* __restrict_
 
 template <bool BWD>
 int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int* dst, const int* blk_indptr, const void* w,
-                const void* h, int64_t h_stride, int n_rows, int nnz, int dim, int mean, void* out, int64_t out_stride,
-                int out_fp32, float* part, hipStream_t st) {
+                const void* h, int64_t h_stride, int n_rows, const int* nnz_dev, int nnz, int dim, int mean, void* out,
+                int64_t out_stride, int out_fp32, float* part, hipStream_t st) {
   if (n_rows <= 0 || dim <= 0) return 0;
   if (nnz > 0 && !part) return BLISS_EINVAL;
   const bool vec4 = (dim % 4 == 0) && (h_stride % 4 == 0) && (out_stride % 4 == 0) &&
                     (((uintptr_t)h) % 8 == 0) && (((uintptr_t)out) % (out_fp32 ? 16 : 8) == 0);
   const int nchunks = nnz > 0 ? (nnz + EC - 1) / EC : 1;
   dim3 grid((nchunks + SP_TPB / 64 - 1) / (SP_TPB / 64)), block(SP_TPB), gfix((n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64));
-#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, t_edge, src, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, nnz, dim, mean, out, out_stride, part))
+#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, t_edge, src, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, nnz_dev, nnz, dim, mean, out, out_stride, part))
   if (vec4) { if (out_fp32) GO(true, true); else GO(true, false); }
   else      { if (out_fp32) GO(false, true); else GO(false, false); }
 #undef GO
@@ -208,18 +210,19 @@ int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int
 extern "C" {
 
 int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const int32_t* dst, const void* w, const void* h,
-                   int64_t h_stride, int32_t n_dst, int32_t nnz, int32_t dim, int mean, void* out, int64_t out_stride,
-                   int out_fp32, float* partials, void* stream) {
+                   int64_t h_stride, int32_t n_dst, const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* out,
+                   int64_t out_stride, int out_fp32, float* partials, void* stream) {
   if (!indptr || !h || !out || nnz < 0 || (nnz > 0 && (!src || !dst))) return BLISS_EINVAL;
-  return launch_spmm<false>(indptr, nullptr, src, dst, nullptr, w, h, h_stride, n_dst, nnz, dim, mean, out, out_stride, out_fp32,
+  return launch_spmm<false>(indptr, nullptr, src, dst, nullptr, w, h, h_stride, n_dst, nnz_dev, nnz, dim, mean, out, out_stride, out_fp32,
                             partials, (hipStream_t)stream);
 }
 
 int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
-                   const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t nnz,
-                   int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32, float* partials, void* stream) {
+                   const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src,
+                   const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32,
+                   float* partials, void* stream) {
   if (!t_indptr || !indptr || !gout || !gh || nnz < 0 || (nnz > 0 && (!t_edge || !src || !dst))) return BLISS_EINVAL;
-  return launch_spmm<true>(t_indptr, t_edge, src, dst, indptr, w, gout, gout_stride, n_src, nnz, dim, mean, gh, gh_stride,
+  return launch_spmm<true>(t_indptr, t_edge, src, dst, indptr, w, gout, gout_stride, n_src, nnz_dev, nnz, dim, mean, gh, gh_stride,
                            out_fp32, partials, (hipStream_t)stream);
 }
 

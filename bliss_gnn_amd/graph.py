@@ -135,6 +135,7 @@ class Block:
         self.dstdata[NID] = src_nid[: self._n_dst]
         self.edata[EID] = eid
         self._transposed = None
+        self._nnz_ptr = 0            # device address of the true edge count when the arrays are capacity-padded
 
     @property
     def device(self):
@@ -178,13 +179,21 @@ class Block:
                 dict.update(f, s)
 
     def transposed(self):
-        """Edges grouped by SOURCE (stable, i.e. ascending edge index inside a source): ``(t_indptr
-        int32 [n_src+1], t_edge int32 [B])``.  Only the SpMM backward needs it; index plumbing."""
+        """Edges grouped by SOURCE (stable: ascending edge index inside a source): ``(t_indptr int32
+        [n_src+1], t_edge int32 [len(src)])``.  Only the SpMM backward needs it; built on the device
+        from the (possibly capacity-padded) edge arrays and the device-resident edge count."""
         if self._transposed is None:
-            order = torch.argsort(self.src, stable=True).to(torch.int32)
-            cnt = torch.zeros(self._n_src, dtype=torch.int32, device=self.device)      # (bincount would sync)
-            cnt.index_add_(0, self.src, torch.ones_like(self.src))
-            t_indptr = torch.zeros(self._n_src + 1, dtype=torch.int32, device=self.device)
-            t_indptr[1:] = torch.cumsum(cnt, 0)
-            self._transposed = (t_indptr, order)
+            import ctypes as C
+            from . import _lib
+            n_src, cap_b = self._n_src, int(self.src.numel())
+            t_indptr = torch.empty(n_src + 1, dtype=torch.int32, device=self.device)
+            t_edge = torch.empty(max(cap_b, 1), dtype=torch.int32, device=self.device)
+            nbytes = int(_lib.lib.bliss_block_transpose_temp_bytes(cap_b, n_src)) if cap_b else 0
+            if nbytes < 0:
+                raise RuntimeError("bliss_block_transpose_temp_bytes failed")
+            temp = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib.bliss_block_transpose(self.src.data_ptr(), self._nnz_ptr, cap_b, cap_b, n_src, t_indptr.data_ptr(),
+                                                      t_edge.data_ptr(), temp.data_ptr(), nbytes,
+                                                      torch.cuda.current_stream().cuda_stream), "bliss_block_transpose")
+            self._transposed = (t_indptr, t_edge)
         return self._transposed

@@ -47,7 +47,8 @@ class _WeightedAggregate(torch.autograd.Function):
         B = block.num_edges()
         part = torch.empty(2 * ((B + 63) // 64) * D, dtype=torch.float32, device=h.device) if B > 0 else None
         _lib.check(_lib.lib.bliss_spmm_fwd(block.indptr.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
-                                           0 if w is None else w.data_ptr(), h.data_ptr(), h.stride(0), S, B, D, int(mean),
+                                           0 if w is None else w.data_ptr(), h.data_ptr(), h.stride(0), S, block._nnz_ptr, B, D,
+                                           int(mean),
                                            out.data_ptr(), out.stride(0), int(out_fp32), 0 if part is None else part.data_ptr(),
                                            _stream()), "bliss_spmm_fwd")
         ctx.block, ctx.w, ctx.mean, ctx.n_src = block, w, mean, h.shape[0]
@@ -66,7 +67,8 @@ class _WeightedAggregate(torch.autograd.Function):
         part = torch.empty(2 * ((B + 63) // 64) * D, dtype=torch.float32, device=gout.device) if B > 0 else None
         _lib.check(_lib.lib.bliss_spmm_bwd(t_indptr.data_ptr(), t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
                                            block.indptr.data_ptr(), 0 if w is None else w.data_ptr(), gout.data_ptr(),
-                                           gout.stride(0), ctx.n_src, B, D, int(ctx.mean), gh.data_ptr(), gh.stride(0), 0,
+                                           gout.stride(0), ctx.n_src, block._nnz_ptr, B, D, int(ctx.mean), gh.data_ptr(),
+                                           gh.stride(0), 0,
                                            0 if part is None else part.data_ptr(), _stream()), "bliss_spmm_bwd")
         return gh, None, None, None, None
 

@@ -89,3 +89,85 @@ class TrainStep:
                 self.sampler.exp3(mfgs, self.g)                                          # :469-471
         self.last = dict(loss=loss, mfgs=mfgs, pred=batch_pred, labels=batch_labels)
         return loss
+
+
+class GraphedTrainStep:
+    """The same step as TrainStep, recorded ONCE into a HIP graph and replayed: sampler kernels, feature gather,
+    SAGE forward / backward, Adam and the EXP3 update with no host work in between.
+
+    The reference launches ~350 kernels and syncs >= 24 times per step from Python; the
+    eager TrainStep above still pays ~150 launches and one mid-step sync.  Replay needs static shapes, so the
+    blocks are padded to capacities learned from a few eager steps (``calibrate``); true sizes stay on the device
+    and come back with the step's single end-of-step sync.  Results are bit-identical to the eager path."""
+
+    def __init__(self, g, sampler, model, batch_size, lr=0.002, multilabel=False):
+        self.g, self.sampler, self.model, self.bs = g, sampler, model, int(batch_size)
+        self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True)
+        self.seeds = torch.zeros(self.bs, dtype=torch.int32, device=g.device)
+        self.graph = None
+        self.num_steps = 0
+        self.last_counts = None
+        self.loss = None
+
+    def calibrate(self, loader, steps=8, k_margin=1.5, b_margin=3.0):
+        """Run eager sampling to learn per-layer sizes, then fix the static capacities."""
+        L = len(self.sampler.nodes_per_layer)
+        mx = [dict(K=0, B=0) for _ in range(L)]
+        for _ in range(steps):
+            _, _, blocks = self.sampler.sample_blocks(self.g, next(loader))
+            for n, b in enumerate(reversed(blocks)):                      # sampling order
+                mx[n]["K"] = max(mx[n]["K"], b.num_src_nodes())
+                mx[n]["B"] = max(mx[n]["B"], b.num_edges())
+        fan = [self.sampler.nodes_per_layer[b] for b in reversed(range(L))]
+        self.sampler._engine.set_static_caps(self.bs, fan, mx, k_margin, b_margin)
+
+    def _body(self):
+        input_nodes, output_nodes, mfgs = self.sampler.sample_blocks_static(self.g, self.seeds)
+        x = mfgs[0].srcdata["features"]
+        y = mfgs[-1].dstdata["labels"]
+        pred = self.model(mfgs, x)
+        loss = self.loss_fn(pred, y)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self.sampler.exp3(mfgs, self.g)
+        # detach: a live autograd graph would pin the warm-up stream's AccumulateGrad nodes into the capture
+        return loss.detach()
+
+    def _finish(self):
+        torch.cuda.current_stream().synchronize()
+        self.last_counts = self.sampler.finish_static()
+        self.num_steps += 1
+
+    def capture(self, loader, warmup=3):
+        """Eager static-shape warm-up steps on a side stream (allocator + autograd warm), then capture."""
+        eng = self.sampler._engine
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.seeds.copy_(next(loader))
+                eng.stage_rng_from_torch()
+                self.loss = self._body()
+                self._finish()
+        torch.cuda.current_stream().wait_stream(side)
+        self.loss = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        self.seeds.copy_(next(loader))
+        eng.stage_rng_from_torch()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        # the capture itself executed nothing: replay once so that this batch is a real step
+        self.graph.replay()
+        self._finish()
+
+    def __call__(self, seeds):
+        self.seeds.copy_(seeds)
+        self.sampler._engine.stage_rng_from_torch()
+        self.graph.replay()
+        self._finish()
+        return self.loss

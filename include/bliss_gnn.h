@@ -131,17 +131,26 @@ int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_str
  * model.py:321-329.  out[i,:] = (1/max(deg_i,1)) * sum_{e in row i} w_e * h[src_e,:]  (mean != 0)
  * or the plain weighted sum (mean == 0).  h bf16 [n_src, dim] (row stride in elements), w bf16
  * [nnz] or NULL (= 1), out bf16 (out_fp32 == 0) or fp32 [n_dst, dim]; src/dst [nnz] = the block's edges
- * (CSR order: dst non-decreasing). */
+ * (CSR order: dst non-decreasing).  nnz_dev (optional): the true edge count on the device, with nnz an
+ * upper bound (capacity-padded arrays; rows past the true n_dst must be empty in indptr). */
 int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const int32_t* dst, const void* w, const void* h,
-                   int64_t h_stride, int32_t n_dst, int32_t nnz, int32_t dim, int mean, void* out, int64_t out_stride,
-                   int out_fp32, float* partials, void* stream);
+                   int64_t h_stride, int32_t n_dst, const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* out,
+                   int64_t out_stride, int out_fp32, float* partials, void* stream);
 
 /* Backward of the above w.r.t. h: gh[j,:] = sum_{e: src_e = j} (w_e / max(deg_dst(e),1)) * gout[dst_e,:].
  * t_indptr [n_src+1], t_edge [nnz]: the block's edges grouped by SOURCE in ascending edge order.
  * partials (both calls): fp32 scratch [2 * ceil(nnz/64) * dim] for rows cut by the 64-edge work chunks. */
 int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
-                   const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src, int32_t nnz,
-                   int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32, float* partials, void* stream);
+                   const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src,
+                   const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32,
+                   float* partials, void* stream);
+
+/* The by-source index the backward needs: t_edge [cap_b] = edge indices grouped by source, ascending
+ * inside a source; t_indptr [n_src_cap + 1].  The edge count is *nnz_dev if given (arrays padded to
+ * cap_b; how static-shape / HIP-graph callers work), else nnz.  temp: bliss_block_transpose_temp_bytes. */
+int64_t bliss_block_transpose_temp_bytes(int32_t cap_b, int32_t n_src_cap);
+int bliss_block_transpose(const int32_t* src, const int32_t* nnz_dev, int32_t nnz, int32_t cap_b, int32_t n_src_cap,
+                          int32_t* t_indptr, int32_t* t_edge, void* temp, int64_t temp_bytes, void* stream);
 
 /* calculate_alpha (SAGE/GCN) + calculate_rewards + update_exp3_weights up to the scatter,
  * bandit_sampler.py:157, :180-193, :221-248.  One launch per block.

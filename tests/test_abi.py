@@ -10,7 +10,7 @@ from conftest import ROOT
 def _declared():
     text = open(os.path.join(ROOT, "include", "bliss_gnn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(bliss_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\*)\s+(bliss_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,8 +22,8 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 10
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/bliss_gnn.h but not exported"
-        assert n in _lib.SIGNATURES or n == "bliss_prof_kernel_name", f"{n} has no ctypes signature in bliss_gnn_amd/_lib.py"
-    assert sorted(list(_lib.SIGNATURES) + ["bliss_prof_kernel_name"]) == names
+        assert n in _lib.SIGNATURES or n in _lib.SPECIAL_SIGNATURES, f"{n} has no ctypes signature in bliss_gnn_amd/_lib.py"
+    assert sorted(list(_lib.SIGNATURES) + list(_lib.SPECIAL_SIGNATURES)) == names
 
 
 def test_counts_struct_layout():

@@ -357,3 +357,81 @@ def test_device_mt19937_continues_the_torch_cpu_stream(cuda):
         _, _, blocks2 = sampler.sample_blocks(g, seeds, uniforms=us)
         for b1, b2 in zip(blocks, blocks2):
             assert torch.equal(b1.srcdata[bg.NID], b2.srcdata[bg.NID]) and torch.equal(b1.src, b2.src)
+
+
+def test_static_shape_and_graph_replay_match_eager(cuda):
+    """Capacity-padded (static-shape) sampling, eager and replayed from a HIP graph, yields exactly the blocks of
+    the exact-size path (padding trimmed) and keeps torch's CPU generator in step; one full graphed train step
+    moves the EXP3 state exactly like the eager step on the same inputs."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, TrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(8000, 160000, seed=12)
+    feats = torch.randn(8000, 64, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 5, (8000,), generator=torch.Generator().manual_seed(3))
+    fan, bs = [400, 200, 100], 64
+    ids = torch.arange(8000, dtype=torch.int32, device=cuda)
+
+    def build():
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler(fan, eta=0.1)
+        torch.manual_seed(0)
+        model = SAGE(64, 32, 5, 3, torch.relu, 0.0).to(cuda).bfloat16()
+        return g, sampler, model
+
+    # eager reference run
+    g1, s1, m1 = build()
+    eager = TrainStep(g1, s1, m1)
+    l1 = BatchLoader(ids, bs, seed=5).forever()
+    # graphed run: calibration consumes loader batches and generator draws, so replay them identically on the eager side
+    g2, s2, m2 = build()
+    graphed = GraphedTrainStep(g2, s2, m2, bs)
+    l2 = BatchLoader(ids, bs, seed=5).forever()
+    torch.manual_seed(9)
+    graphed.calibrate(l2, steps=3)
+    state_after_calib = torch.get_rng_state()
+    torch.manual_seed(9)
+    for _ in range(3):
+        s1.sample_blocks(g1, next(l1))
+    assert torch.equal(torch.get_rng_state(), state_after_calib)
+    # 3 eager static warm-up steps + 1 captured/replayed step inside capture(); then 3 replays
+    torch.set_rng_state(state_after_calib)
+    graphed.capture(l2, warmup=3)
+    for _ in range(3):
+        graphed(next(l2))
+    rng_graphed = torch.get_rng_state()
+    sizes_graphed = [(c.S, c.E, c.C, c.K, c.B) for c in graphed.last_counts]
+    torch.set_rng_state(state_after_calib)
+    for _ in range(7):
+        eager(next(l1))
+    assert torch.equal(torch.get_rng_state(), rng_graphed), "CPU generator out of step between eager and graphed runs"
+    sizes_eager = [(b._counts.S, b._counts.E, b._counts.C, b._counts.K, b._counts.B) for b in reversed(eager.last["mfgs"])]
+    # the model's GEMMs run on padded shapes in the graphed run, so activations (hence embed_norm and the EXP3
+    # state) may differ in the last bf16 bit; sizes of the 7th step must still agree closely and the first
+    # step's blocks exactly -- checked below on a fresh pair with identical EXP3 state
+    assert abs(sizes_eager[0][3] - sizes_graphed[0][3]) <= 0.05 * sizes_eager[0][3] + 8
+    # exact block parity of the static path for identical state
+    g3, s3, _ = build()
+    g4, s4, _ = build()
+    seeds = torch.arange(100, 100 + bs, dtype=torch.int32, device=cuda)
+    torch.manual_seed(21)
+    s4.sample_blocks(g4, seeds)                                  # binds the engine, learns default capacities
+    torch.manual_seed(21)
+    _, _, exact = s3.sample_blocks(g3, seeds)
+    torch.manual_seed(21)
+    s4._engine.stage_rng_from_torch()
+    _, _, padded = s4.sample_blocks_static(g4, seeds)
+    torch.cuda.synchronize()
+    cnts = s4.finish_static()
+    for be, bp, c in zip(exact, padded, reversed(cnts)):
+        K, B, S = c.K, c.B, c.S
+        assert (S, K, B) == (be.num_dst_nodes(), be.num_src_nodes(), be.num_edges())
+        assert torch.equal(bp.indptr[:S + 1], be.indptr) and torch.equal(bp.src[:B], be.src) and torch.equal(bp.dst[:B], be.dst)
+        assert torch.equal(bp.srcdata[bg.NID][:K], be.srcdata[bg.NID])
+        assert torch.equal(bp.edata["edge_weights"][:B].view(torch.int16), be.edata["edge_weights"].view(torch.int16))
+        assert (bp.indptr[S:] == B).all() and (bp.srcdata[bg.NID][K:] == 0).all()
+        ti, te = bp.transposed()
+        order = torch.argsort(be.src, stable=True).to(torch.int32)
+        assert torch.equal(te[:B], order) and int(ti[K]) == B
