@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--config", default="reddit", choices=["cora", "pubmed", "reddit", "yelp"])
     ap.add_argument("--cpu-baseline-steps", type=int, default=-1, help="-1: auto (bounded sample), 0: skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the step's HIP graph")
     return ap.parse_args()
 
 
@@ -59,7 +60,7 @@ def main():
     import bliss_gnn_amd as bg
     from bliss_gnn_amd.model import SAGE
     from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc, node_data
-    from bliss_gnn_amd.train import BatchLoader, TrainStep
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, TrainStep
     from bliss_gnn_amd import dist as bdist
 
     cfg = CONFIGS[args.config]
@@ -81,56 +82,69 @@ def main():
     if world > 1:
         bdist.broadcast_parameters(model)
         grad_sync, exp3_sync = bdist.allreduce_gradients, bdist.exp3_all_ranks
-    step = TrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"], grad_sync=grad_sync, exp3_sync=exp3_sync)
     # every rank draws its own batches (different loader seed) and its own sampler stream
     loader = BatchLoader(train_nid, cfg["batch"], shuffle=True, drop_last=True, seed=2 + rank).forever()
     torch.manual_seed(3 + rank)                                                          # sampler stream (CPU generator)
+    dims = [hidden, hidden, cfg["classes"]]
+    from bliss_gnn_amd import roofline
+    timer = roofline.KernelTimer()
+    graphed = world == 1 and not args.eager
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up; its last steps calibrate which library kernel dominates (all kernels event-bracketed) ----
-    from bliss_gnn_amd import roofline
-    timer = roofline.KernelTimer()
-    n_cal = 0 if args.no_roofline else min(5, max(args.warmup - 2, 0))
-    for _ in range(args.warmup - n_cal):
-        step(next(loader))
-    dominant, calib = None, {}
-    if n_cal:
-        torch.cuda.synchronize()
-        timer.enable("all")
-        for _ in range(n_cal):
-            step(next(loader))
-        torch.cuda.synchronize()
-        calib = timer.read()
-        hbm_kernels = {k: v for k, v in calib.items() if roofline.algorithmic_bytes(k, dict(S=1, E=1, C=1, K=1, B=1), [1, 1, 1], 0)
-                       and k != "k_mt19937_uniform"}
-        dominant = max(hbm_kernels, key=lambda k: hbm_kernels[k]["total_ms"])
-        timer.enable(dominant)                       # only this kernel carries events in the timed region
+    if graphed:
+        # whole step (sampler + gather + fwd/bwd + Adam + exp3) replayed from ONE HIP graph
+        step = GraphedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"])
+        step.calibrate(loader, steps=8)
+        step.capture(loader, warmup=3)
+        run_step, sizes_of = step, step.sizes
+    else:
+        step = TrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"], grad_sync=grad_sync, exp3_sync=exp3_sync)
+        run_step = step
+        sizes_of = lambda: [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in step.last["mfgs"]]
+
+    for _ in range(args.warmup):
+        run_step(next(loader))
     sync()
-    sizes_acc, n_edges, n_frontier, alg_dom = None, 0, 0, 0.0
-    dims = [hidden, hidden, cfg["classes"]]
+    sizes_acc, n_edges, n_frontier = None, 0, 0
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        step(next(loader))
-        mf = step.last["mfgs"]
-        n_edges += sum(b.num_edges() for b in mf)
-        n_frontier += sum(b._counts.E for b in mf)
-        sz = [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in mf]
+        run_step(next(loader))
+        sz = sizes_of()
+        n_edges += sum(x["B"] for x in sz)
+        n_frontier += sum(x["E"] for x in sz)
         sizes_acc = sz if sizes_acc is None else [{k: a[k] + b[k] for k in a} for a, b in zip(sizes_acc, sz)]
-        if dominant:
-            alg_dom += sum(roofline.algorithmic_bytes(dominant, s_, dims, l) for l, s_ in enumerate(sz))
     sync()
     dt = time.perf_counter() - t1
-    dom_timing = timer.read().get(dominant) if dominant else None
-    timer.enable("off")
     t = torch.tensor([dt, float(n_edges), float(n_frontier)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, n_edges, n_frontier = float(tmax[0]), float(tsum[1]), float(tsum[2])
+
+    # ---- roofline: the same step launched kernel by kernel, HIP events around the library kernels ----------------
+    dominant, calib, dom_timing, alg_dom = None, {}, None, 0.0
+    if rank == 0 and not args.no_roofline:
+        k_step = step.eager_step if graphed else step
+        torch.cuda.synchronize()
+        timer.enable("all")
+        for _ in range(5):
+            k_step(next(loader))
+        torch.cuda.synchronize()
+        calib = timer.read()
+        hbm_kernels = {k: v for k, v in calib.items()
+                       if roofline.algorithmic_bytes(k, dict(S=1, E=1, C=1, K=1, B=1), [1, 1, 1], 0) and k != "k_mt19937_uniform"}
+        dominant = max(hbm_kernels, key=lambda k: hbm_kernels[k]["total_ms"])
+        timer.enable(dominant)                       # only this kernel carries events now
+        for _ in range(min(args.steps, 30)):
+            k_step(next(loader))
+            alg_dom += sum(roofline.algorithmic_bytes(dominant, s_, dims, l) for l, s_ in enumerate(sizes_of()))
+        torch.cuda.synchronize()
+        dom_timing = timer.read().get(dominant)
+        timer.enable("off")
     sampler.check_errors()
     steps_total = args.steps * world
     mean_sizes = [{k: v / args.steps for k, v in s.items()} for s in sizes_acc]
@@ -145,6 +159,7 @@ def main():
                                "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"], hidden, eta,
                                                                  "/".join(map(str, fan)), cfg["batch"]),
                    "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather)" % world if world > 1 else "single GPU",
+                   "launch": "whole step replayed from one HIP graph" if graphed else "eager (kernel by kernel)",
                    "global_batch": cfg["batch"] * world},
         "sampled_edges_per_sec": n_edges / dt, "frontier_edges_per_sec": n_frontier / dt,
         "sizes_per_step": mean_sizes, "algorithmic_bytes_per_step": alg,
@@ -158,6 +173,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / roofline.HBM_PEAK_GBPS, "traffic": None,
                            "avg_launch_us": dom_timing["avg_us"], "launches": dom_timing["launches"],
+                           "measured_over": "%d kernel-by-kernel runs of the same step right after the timed region" % min(args.steps, 30),
                            "algorithmic_bytes_per_launch": per_launch,
                            "kernel_time_share_in_calibration": {k: round(v["total_ms"] / max(sum(x["total_ms"] for x in calib.values()), 1e-9), 4)
                                                                 for k, v in sorted(calib.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}

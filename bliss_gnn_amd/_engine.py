@@ -46,6 +46,7 @@ class _LayerWs:
         self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
         self.P = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
         self.uniforms = torch.empty(cap_c, dtype=torch.float32, device=dev)
+        self.rng_raw = torch.empty(624 * (cap_c // 624 + 3), dtype=torch.int32, device=dev)
 
 
 class LayerEngine:
@@ -261,13 +262,13 @@ class LayerEngine:
                                 ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
                                 kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(), cap["C"], ck)
             w_pos = w_rows[n]
+            use_rng = uniforms is None
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
-                                                    self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
-            if uniforms is None:
-                _lib.check(_lib.lib.bliss_mt19937_uniform(self.mt_dev.data_ptr(), cnt_ptr, 2, ws.uniforms.data_ptr(),
-                                                          cap["C"], st), "bliss_mt19937_uniform")
-            else:
+                                                    self.Eg, C.byref(c_ws), self.mt_dev.data_ptr() if use_rng else 0,
+                                                    ws.uniforms.data_ptr() if use_rng else 0,
+                                                    ws.rng_raw.data_ptr() if use_rng else 0, st), "bliss_frontier_prob")
+            if not use_rng:
                 u = uniforms[n].to(dev, torch.float32).reshape(-1)
                 m = min(u.numel(), cap["C"])
                 ws.uniforms[:m].copy_(u[:m])

@@ -53,7 +53,7 @@ _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 # name -> argtypes; every symbol declared in include/bliss_gnn.h must appear here (tests check)
 SIGNATURES = {
     "bliss_layer_counts_bytes": [],
-    "bliss_frontier_prob": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), _P],
+    "bliss_frontier_prob": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), _P, _P, _P, _P],
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _I64, _P],
     "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],

@@ -22,6 +22,9 @@
 #define ITEMS 4
 #define CHUNK (TPB * ITEMS)
 
+int bliss_rng_fork(void* state, const int32_t* cnt_words, float* out, uint32_t* raw, int cap, hipStream_t st, hipEvent_t* join);
+int bliss_rng_join(void* state, const int32_t* cnt_words, const uint32_t* raw, int cap, hipStream_t st, hipEvent_t join);
+
 namespace {
 
 // Work decomposition of every frontier pass: a workgroup (4 waves) owns a CHUNK of 1024 consecutive
@@ -197,7 +200,8 @@ __global__ void __launch_bounds__(1024) k_chunk_scan(int* __restrict__ chunk_cnt
     int total = which == 0 ? cnt->S + run : run;
     int errbit = which == 0 ? BLISS_ERR_CAP_CAND : (which == 1 ? BLISS_ERR_CAP_KEPT : BLISS_ERR_CAP_EDGES);
     if (total > cap) { atomicOr(&cnt->err, errbit); total = cap; }   // clamp: results invalid but in bounds
-    if (which == 0) cnt->C = total; else if (which == 1) cnt->K = total; else cnt->B = total;
+    if (which == 0) __hip_atomic_store(&cnt->C, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // polled by the generator
+    else if (which == 1) cnt->K = total; else cnt->B = total;
   }
 }
 
@@ -567,7 +571,7 @@ __global__ void __launch_bounds__(256) k_init_counts(LayerCounts* cnt, int S_hos
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int S = S_host >= 0 ? S_host : *S_dev, err = 0;
     if (S > cap_s) { S = cap_s; err = BLISS_ERR_CAP_SEEDS; }     // clamp: results invalid but in bounds
-    cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+    cnt->S = S; cnt->E = 0; cnt->C = -1; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
   }
 }
 
@@ -588,8 +592,10 @@ int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
 
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
                         int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode, float eta_f,
-                        float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream_) {
+                        float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* rng_state,
+                        float* uniforms, uint32_t* rng_raw, void* stream_) {
   if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0 || !ws->hist) return BLISS_EINVAL;
+  if (rng_state && (!uniforms || !rng_raw)) return BLISS_EINVAL;
   if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
   if (n_seeds > cap_s) return BLISS_EINVAL;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
@@ -605,6 +611,11 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     int gi = (n_words + 255) / 256;
     if (gi > 1024) gi = 1024;
     k_init_counts<<<gi, 256, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s, acc_w, n_words);
+  }
+  hipEvent_t rng_join = nullptr;
+  if (rng_state) {   // fork: the CPU-stream-compatible generator runs beside the passes below
+    int rc = bliss_rng_fork(rng_state, (const int32_t*)cnt, uniforms, rng_raw, ws->cap_c, st, &rng_join);
+    if (rc) return rc;
   }
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes));
   if (mode == BLISS_MODE_BANDIT) {
@@ -625,6 +636,10 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     if (gf > 256) gf = 256;
     PROF_LAUNCH(BK_CAND_FINALIZE, st, k_cand_finalize<<<gf, FIN_TPB, 0, st>>>(
         seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->hist, ws->cap_c));
+  }
+  if (rng_state) {   // join: hand the generator state after exactly C draws to the next layer / back to the host
+    int rc = bliss_rng_join(rng_state, (const int32_t*)cnt, rng_raw, ws->cap_c, st, rng_join);
+    if (rc) return rc;
   }
   return (int)hipGetLastError();
 }

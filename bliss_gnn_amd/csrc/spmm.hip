@@ -98,16 +98,12 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
         if (VEC4) { q[1] = acc.y; q[2] = acc.z; q[3] = acc.w; }
       }
     };
-    auto zero_rows = [&](int ra, int rb_) {                 // rows ra .. rb_-1 have no edges
-      if (act) for (int r = ra; r < rb_; ++r) store_row<VEC4, OUT_F32>(out, r * out_stride + col, zero, 1.0f);
-    };
-    if (cnt == 0) { zero_rows(0, n_rows); continue; }       // nnz == 0: chunk 0 clears the output
+    if (cnt == 0) continue;                                 // rows without edges are cleared by k_spmm_fixup
     int cur = __shfl(my_row, 0);
-    { int r = cur - 1; while (r >= 0 && row_ptr[r] == c0) --r; zero_rows(r + 1, cur); }   // empty rows parked at c0
     f4 acc = zero;
     for (int j = 0; j < cnt;) {
       const int r = __shfl(my_row, j);
-      if (r != cur) { flush(cur, acc); zero_rows(cur + 1, r); acc = zero; cur = r; }
+      if (r != cur) { flush(cur, acc); acc = zero; cur = r; }
       const int run = __popcll(__ballot(my_row == r && lane >= j));
       const int end = j + run;
       for (; j + 4 <= end; j += 4) {
@@ -140,11 +136,11 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
       }
     }
     flush(cur, acc);
-    if (c1 == nnz) zero_rows(cur + 1, n_rows);              // trailing empty rows belong to the last chunk
   }
 }
 
-// rows cut by chunk boundaries: tail partial of the chunk they start in + head partials of the following chunks
+// rows cut by chunk boundaries: tail partial of the chunk they start in + head partials of the following chunks;
+// rows without edges (isolated or capacity-padded) are cleared here, one wave per row
 template <bool OUT_F32, bool BWD>
 __global__ void __launch_bounds__(SP_TPB) k_spmm_fixup(const int* __restrict__ row_ptr, int n_rows, int dim, int mean,
                                                       const float* __restrict__ part, void* out, int64_t out_stride) {
@@ -152,7 +148,12 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm_fixup(const int* __restrict__ r
   const int r = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
   const int rb = row_ptr[r], re = row_ptr[r + 1];
-  if (re <= rb) return;
+  if (re <= rb) {                                           // no edges (incl. capacity-padded rows): the output row is zero
+    for (int col = lane; col < dim; col += 64) {
+      if (OUT_F32) ((float*)out)[r * out_stride + col] = 0.f; else ((bf16_t*)out)[r * out_stride + col] = 0;
+    }
+    return;
+  }
   const int c = rb / EC, c_end = (re - 1) / EC;
   if (c_end == c) return;                                   // finished by its chunk
   const float scale = (!BWD && mean) ? 1.0f / (float)(re - rb) : 1.0f;
@@ -189,7 +190,7 @@ int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int
                 const void* h, int64_t h_stride, int n_rows, const int* nnz_dev, int nnz, int dim, int mean, void* out,
                 int64_t out_stride, int out_fp32, float* part, hipStream_t st) {
   if (n_rows <= 0 || dim <= 0) return 0;
-  if (nnz > 0 && !part) return BLISS_EINVAL;
+  if (nnz > EC && !part) return BLISS_EINVAL;
   const bool vec4 = (dim % 4 == 0) && (h_stride % 4 == 0) && (out_stride % 4 == 0) &&
                     (((uintptr_t)h) % 8 == 0) && (((uintptr_t)out) % (out_fp32 ? 16 : 8) == 0);
   const int nchunks = nnz > 0 ? (nnz + EC - 1) / EC : 1;
@@ -198,7 +199,7 @@ int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int
   if (vec4) { if (out_fp32) GO(true, true); else GO(true, false); }
   else      { if (out_fp32) GO(false, true); else GO(false, false); }
 #undef GO
-  if (nnz > EC) {
+  {
     if (out_fp32) PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<true, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride));
     else PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<false, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride));
   }

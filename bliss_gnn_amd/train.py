@@ -171,3 +171,15 @@ class GraphedTrainStep:
         self.graph.replay()
         self._finish()
         return self.loss
+
+    def eager_step(self, seeds):
+        """The same static-shape step launched kernel by kernel (used to time individual kernels)."""
+        self.seeds.copy_(seeds)
+        self.sampler._engine.stage_rng_from_torch()
+        loss = self._body()
+        self._finish()
+        return loss
+
+    def sizes(self):
+        """Per block (input-most first): the true S, E, C, K, B of the last step."""
+        return [dict(S=c.S, E=c.E, C=c.C, K=c.K, B=c.B) for c in reversed(self.last_counts)]

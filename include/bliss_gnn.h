@@ -96,11 +96,15 @@ int bliss_layer_counts_bytes(void);
  * exp3_weights row (BANDIT) or g.edata['w'] (LADIES).  eta_f = (float)eta,
  * one_minus_eta_f = (float)(1.0 - eta).  frontier_bound >= number of in-edges of the seeds
  * (num_edges is always valid).  Out (in ws): counts{S,E,C}, seg_ptr, cand_nid, p; the node maps
- * hold local ids of all candidates until bliss_build_block cleans them. */
+ * hold local ids of all candidates until bliss_build_block cleans them.
+ * rng_state (optional, uint32[626] as for bliss_mt19937_uniform): when given, the C uniforms of this layer's
+ * Poisson draw are generated into uniforms[cap_c] on a library-owned side stream WHILE the frontier passes run
+ * (fork/join by events, also inside a captured graph) and rng_state is advanced by exactly C draws;
+ * rng_raw: uint32 scratch [624 * (cap_c / 624 + 3)]. */
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* maps, const void* w_pos,
                         const int32_t* seeds, int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode,
                         float eta_f, float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws,
-                        void* stream);
+                        void* rng_state, float* uniforms, uint32_t* rng_raw, void* stream);
 
 /* PoissonBanditLadiesSampler.compute_prob (scale c, :391-406) + select_neighbors (:408-425).
  * uniforms: fp32 [>= C], the values torch.rand(C) draws from the CPU generator (ATen's serial

@@ -11,7 +11,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bliss_gnn_amd import dist as bdist
@@ -29,22 +29,23 @@ def _worker(rank, world, port, q):
     pos = (torch.arange(n, dtype=torch.int32) * 10 + rank)
     fac = (torch.arange(n, dtype=torch.float32) * 0.01 + 1 + rank).bfloat16()
     got = bdist.gather_updates(pos, fac)
-    q.put((rank, w0, g, [(a.clone(), b.float().clone()) for a, b in got]))
+    torch.save((rank, w0, g, [(a.clone(), b.float().clone()) for a, b in got]), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gloo_world2_gradient_bucket_and_update_gather():
     world, port = 2, _free_port()
+    import tempfile
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_worker, args=(r, world, port, outdir)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0
+        res = [torch.load(os.path.join(outdir, f"r{r}.pt")) for r in range(world)]
     (_, w_a, g_a, u_a), (_, w_b, g_b, u_b) = res
     assert torch.equal(w_a, w_b)                                   # broadcast made the replicas identical
     assert torch.allclose(g_a, torch.full_like(g_a, 1.5)) and torch.equal(g_a, g_b)   # mean of 1 and 2
