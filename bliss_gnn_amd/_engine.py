@@ -19,7 +19,7 @@ from . import _lib
 from .graph import Block, Graph
 
 _CHUNK = 1024
-_CAP_ERRS = 1 | 2 | 4 | 8 | 64
+_CAP_ERRS = 1 | 2 | 4 | 8 | 64      # (128, the random stream, is fatal: the stream is sized for the worst case)
 
 
 def _ptr(t):
@@ -45,8 +45,7 @@ class _LayerWs:
         self.new_id = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
         self.P = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
-        self.uniforms = torch.empty(cap_c, dtype=torch.float32, device=dev)
-        self.rng_raw = torch.empty(624 * (cap_c // 624 + 3), dtype=torch.int32, device=dev)
+        self.uniforms = torch.empty(cap_c, dtype=torch.float32, device=dev)     # explicit-uniforms path only
 
 
 class LayerEngine:
@@ -100,6 +99,11 @@ class LayerEngine:
             dev = self.g.device
             self.ws = [_LayerWs(dev, c["S"], c["C"]) for c in self.caps]
             self.counts_host = torch.empty(len(fan) * 10, dtype=torch.int32).pin_memory()
+            # one random stream per call: the layers consume consecutive slices of it
+            self.rng_cap = sum(c["C"] for c in self.caps)
+            self.rng_out = torch.empty(self.rng_cap + 2 * 624, dtype=torch.float32, device=dev)
+            self.rng_raw = torch.empty(624 * (self.rng_cap // 624 + 3), dtype=torch.int32, device=dev)
+            self.rng_ctl = torch.zeros(8 + len(fan), dtype=torch.int32, device=dev)     # ctl[8] + per-layer offsets
 
     def _grow(self, errs):
         for n, e in enumerate(errs):
@@ -237,6 +241,10 @@ class LayerEngine:
                 self._stage_rng(snapshot)
             self.mt_dev.copy_(self.mt_host, non_blocking=True)
         counts = torch.empty(L * 10, dtype=torch.int32, device=dev)
+        use_rng = uniforms is None
+        if use_rng:      # fork the generator: it runs beside everything below
+            _lib.check(_lib.lib.bliss_rng_stream_begin(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_out.data_ptr(),
+                                                       self.rng_raw.data_ptr(), self.rng_cap, st), "bliss_rng_stream_begin")
         eta_f = float(np.float32(eta))
         ome_f = float(np.float32(1.0 - eta))
         layers = []
@@ -262,18 +270,21 @@ class LayerEngine:
                                 ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
                                 kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(), cap["C"], ck)
             w_pos = w_rows[n]
-            use_rng = uniforms is None
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
-                                                    self.Eg, C.byref(c_ws), self.mt_dev.data_ptr() if use_rng else 0,
-                                                    ws.uniforms.data_ptr() if use_rng else 0,
-                                                    ws.rng_raw.data_ptr() if use_rng else 0, st), "bliss_frontier_prob")
-            if not use_rng:
+                                                    self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
+            if use_rng:
+                off_ptr = self.rng_ctl.data_ptr() + 4 * (8 + n)
+                _lib.check(_lib.lib.bliss_rng_stream_wait(self.rng_ctl.data_ptr(), cnt_ptr, off_ptr, int(n == L - 1),
+                                                          self.rng_cap, st), "bliss_rng_stream_wait")
+                _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), self.rng_out.data_ptr(),
+                                                         off_ptr, cap["C"], st), "bliss_poisson_select")
+            else:
                 u = uniforms[n].to(dev, torch.float32).reshape(-1)
                 m = min(u.numel(), cap["C"])
                 ws.uniforms[:m].copy_(u[:m])
-            _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
-                                                     cap["C"], st), "bliss_poisson_select")
+                _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
+                                                         0, cap["C"], st), "bliss_poisson_select")
             c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
                                   b_w.data_ptr(), b_q.data_ptr(), cb)
             _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
@@ -281,6 +292,9 @@ class LayerEngine:
                                                   C.byref(c_out), st), "bliss_build_block")
             layers.append((b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10]))
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
+        if use_rng:      # join; mt_dev = generator state after exactly sum(C) draws
+            _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
+                                                     self.rng_cap, counts.data_ptr() + 20, st), "bliss_rng_stream_end")
         return counts, layers
 
     def _finish(self, out, cnts):

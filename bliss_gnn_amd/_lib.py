@@ -20,6 +20,7 @@ ERR_BITS = {
     16: "non-finite or negative weight reached an exact reduction",
     32: "exact sum left its fixed-point range",
     64: "seed capacity exceeded",
+    128: "random stream ran short / generator made no progress",
 }
 
 
@@ -53,9 +54,12 @@ _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 # name -> argtypes; every symbol declared in include/bliss_gnn.h must appear here (tests check)
 SIGNATURES = {
     "bliss_layer_counts_bytes": [],
-    "bliss_frontier_prob": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), _P, _P, _P, _P],
+    "bliss_frontier_prob": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), _P],
+    "bliss_rng_stream_begin": [_P, _P, _P, _P, _I32, _P],
+    "bliss_rng_stream_wait": [_P, _P, _P, C.c_int, _I32, _P],
+    "bliss_rng_stream_end": [_P, _P, _P, _I32, _P, _P],
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
-    "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _I64, _P],
+    "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _I64, _P],
     "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],
     "bliss_normalized_edata": [C.POINTER(Graph), _P, _P],
     "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],

@@ -29,6 +29,7 @@
 #define BLISS_ERR_NONFINITE   16   // a non-finite / negative term reached an exact reduction
 #define BLISS_ERR_FIXED_RANGE 32   // an exact sum left its fixed-point range
 #define BLISS_ERR_CAP_SEEDS   64   // more seeds than the per-layer seed capacity
+#define BLISS_ERR_RNG_STREAM 128   // the random stream ran short (capacity) or the generator did not make progress
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits
 

@@ -81,52 +81,105 @@ __global__ void __launch_bounds__(256) k_mt19937_uniform(uint32_t* state, const 
   if (tid == 0) { state[MT_N] = (uint32_t)left; state[MT_N + 1] = (uint32_t)next; }
 }
 
-// ---- speculative variant, run on a side stream BESIDE the frontier passes -----------------------------------------
-// The count C is produced by those passes, so it is unknown when this kernel starts.  It generates ahead, polls C
-// (agent-scope load of the counts record) after every 624-number block, and stops as soon as it has covered C -- or
-// at `cap` if C never shows up (no waiting anywhere: it cannot deadlock whatever the scheduler does).  Every raw
-// state block is kept so that k_mt19937_commit can hand over the generator state after EXACTLY C draws.
+// ---- streaming variant: ONE generator per sample_blocks call, on a side stream, beside everything else ------------
+// The counts C_n of the layers become known one after the other while the layers are being sampled, but the random
+// stream itself does not depend on them: layer n simply consumes the next C_n numbers.  So one 256-thread generator
+// walks the recurrence for the whole call, publishing its progress; the main stream only waits (k_rng_wait, one
+// wave) until the numbers a layer needs exist, and the exact generator state after sum(C_n) draws is read off the
+// kept raw blocks at the end (k_mt19937_commit).  The generator never waits for anyone: it stops when it has
+// covered `stop_at` (published with the last layer) or at `cap_total`, so it terminates under any scheduling.
+// ctl (device int32[8]): [0] progress = numbers generated so far, [1] stop_at (-1 = unknown), [2] pos = numbers
+// consumed by finished layers, [3] error flag, [4] base (offset of stream position 0 in `out`).
 // raw layout: block 0 = the state at entry, block i >= 1 = the i-th regenerated state.
-__global__ void __launch_bounds__(256) k_mt19937_speculate(const uint32_t* __restrict__ state, const int* n_dev, int n_off_words,
-                                                           float* __restrict__ out, uint32_t* __restrict__ raw, int cap) {
-  __shared__ uint32_t buf[2][MT_N];
-  __shared__ int n_sh;
+__device__ __forceinline__ void store_sc1_x4(float* p, float a, float b, float c, float d) {
+  // 16-byte write-through store (the consumer may read while this kernel is still running); drained by the caller
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// out layout: the numbers still unread in the entry block sit right below out[624] (base = 624 - avail), the k-th
+// regenerated block occupies out[624 k .. 624 (k+1)) -- so every regenerated block is stored with aligned 16-byte
+// stores.  Stream position p lives at out[base + p]; ctl[4] = base (set by k_rng_ctl_init).
+#define MT_PUBLISH_EVERY 4
+__global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restrict__ state, int* ctl, float* __restrict__ out,
+                                                        uint32_t* __restrict__ raw, int cap_total) {
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2][MT_N];
+  __shared__ int stop_sh;
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += 256) { const uint32_t v = state[i]; buf[0][i] = v; raw[i] = v; }
   const int left = (int)state[MT_N], next = (int)state[MT_N + 1];
   __syncthreads();
   int avail = left - 1;
   if (avail < 0) avail = 0;
-  if (avail > cap) avail = cap;
-  for (int i = tid; i < avail; i += 256) out[i] = mt_uniform(buf[0][next + i]);
-  int done = avail, cur = 0, blk = 0, n = -1;
-  while (done < cap) {
-    if (tid == 0) n_sh = __hip_atomic_load(n_dev + n_off_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (avail > MT_N) avail = MT_N;
+  const int base = MT_N - avail;
+  for (int i = tid; i < avail; i += 256)
+    __hip_atomic_store(out + base + i, mt_uniform(buf[0][next + i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int done = avail, cur = 0, blk = 0, stop = -1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(ctl + 0, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (done < cap_total) {
+    if (tid == 0) stop_sh = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    n = n_sh;
-    if (n >= 0 && done >= n) break;                    // covered
-    mt_generate(buf[cur], buf[cur ^ 1], tid);          // ends with a barrier
-    cur ^= 1; ++blk;
-    int t = (cap - done) < MT_N ? (cap - done) : MT_N;
-    for (int i = tid; i < MT_N; i += 256) {
-      const uint32_t v = buf[cur][i];
-      raw[blk * MT_N + i] = v;
-      if (i < t) out[done + i] = mt_uniform(v);
+    stop = stop_sh;
+    if (stop >= 0 && done >= stop) break;
+    for (int rep = 0; rep < MT_PUBLISH_EVERY && done < cap_total; ++rep) {
+      mt_generate(buf[cur], buf[cur ^ 1], tid);         // ends with a barrier
+      cur ^= 1; ++blk;
+      if (tid < MT_N / 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&buf[cur][tid * 4]);
+        *reinterpret_cast<uint4*>(raw + blk * MT_N + tid * 4) = v;      // read only after this kernel ended: plain store
+        store_sc1_x4(out + blk * MT_N + tid * 4, mt_uniform(v.x), mt_uniform(v.y), mt_uniform(v.z), mt_uniform(v.w));
+      }
+      done += MT_N;
     }
-    done += t;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
+    __syncthreads();                                    // ... the workgroup meets ...
+    if (tid == 0) __hip_atomic_store(ctl + 0, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... one lane publishes
   }
 }
 
-// generator state after exactly C = n_dev[n_off_words] draws (C <= cap), from the raw blocks
-__global__ void __launch_bounds__(256) k_mt19937_commit(uint32_t* state, const int* __restrict__ n_dev, int n_off_words,
-                                                        const uint32_t* __restrict__ raw, int cap) {
+// main stream, one wave: wait until the generator has produced the numbers layer `n` needs; hand the layer its offset
+__global__ void __launch_bounds__(64) k_rng_wait(int* ctl, const int* __restrict__ cnt_words, int* __restrict__ layer_off,
+                                                 int is_last, int cap_total) {
+  if (threadIdx.x != 0) return;
+  int C = cnt_words[2];
+  const int pos = ctl[2];
+  int need = pos + C;
+  if (need > cap_total) { need = cap_total; atomicOr(ctl + 3, 1); }
+  long long spins = 0;
+  while (__hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1ll << 22)) { atomicOr(ctl + 3, 2); break; }     // bounded: never hang the GPU
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  *layer_off = ctl[4] + pos;
+  ctl[2] = need;
+  if (is_last) __hip_atomic_store(ctl + 1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_rng_ctl_init(int* ctl, const uint32_t* __restrict__ state) {
+  if (threadIdx.x == 0) {
+    int avail = (int)state[MT_N] - 1;
+    if (avail < 0) avail = 0;
+    if (avail > MT_N) avail = MT_N;
+    ctl[0] = 0; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = MT_N - avail;
+  }
+}
+
+// generator state after exactly n = ctl[2] draws, from the raw blocks
+__global__ void __launch_bounds__(256) k_mt19937_commit(uint32_t* state, const int* __restrict__ ctl,
+                                                        const uint32_t* __restrict__ raw, int cap_total, int* err_word) {
   const int tid = threadIdx.x;
-  int n = n_dev[n_off_words];
-  if (n > cap) n = cap;
+  if (tid == 0 && err_word && ctl[3]) atomicOr(err_word, BLISS_ERR_RNG_STREAM);
+  int n = ctl[2];
+  if (n > cap_total) n = cap_total;
   const int left = (int)state[MT_N], next = (int)state[MT_N + 1];
   int avail = left - 1;
   if (avail < 0) avail = 0;
-  if (avail > cap) avail = cap;
+  if (avail > MT_N) avail = MT_N;
   __syncthreads();                                      // everyone has read the old fields
   if (n <= avail) {
     if (tid == 0) { state[MT_N] = (uint32_t)(left - n); state[MT_N + 1] = (uint32_t)(next + n); }
@@ -138,25 +191,26 @@ __global__ void __launch_bounds__(256) k_mt19937_commit(uint32_t* state, const i
   if (tid == 0) { state[MT_N] = (uint32_t)(MT_N + 1 - t); state[MT_N + 1] = (uint32_t)t; }
 }
 
+hipStream_t g_side = nullptr;
+hipEvent_t g_ev[16];
+int g_ev_next = 0;
+bool g_init = false;
+hipEvent_t g_join = nullptr;
+
 }  // namespace
 
-extern "C" int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offset, float* out, int32_t cap,
-                                     void* stream) {
+extern "C" {
+
+int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offset, float* out, int32_t cap, void* stream) {
   if (!state || !n_dev || !out || cap < 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   PROF_LAUNCH(BK_MT19937, st, k_mt19937_uniform<<<1, 256, 0, st>>>((uint32_t*)state, n_dev, n_word_offset, out, cap));
   return (int)hipGetLastError();
 }
 
-// Fork / join helpers used by bliss_frontier_prob (sampler.hip): the speculative generator runs on a library-owned
-// side stream between two events, so it overlaps the frontier passes both eagerly and inside a captured HIP graph.
-namespace {
-hipStream_t g_side = nullptr;
-hipEvent_t g_ev[16];
-int g_ev_next = 0;
-bool g_init = false;
-}
-int bliss_rng_fork(void* state, const int32_t* cnt_words, float* out, uint32_t* raw, int cap, hipStream_t st, hipEvent_t* join) {
+int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, void* stream) {
+  if (!state || !ctl || !out || !raw || cap_total <= 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
   if (!g_init) {
     if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return BLISS_EINVAL;
     for (int i = 0; i < 16; ++i) if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return BLISS_EINVAL;
@@ -165,16 +219,29 @@ int bliss_rng_fork(void* state, const int32_t* cnt_words, float* out, uint32_t* 
   hipEvent_t fork = g_ev[g_ev_next], jn = g_ev[g_ev_next + 1];
   g_ev_next = (g_ev_next + 2) % 16;
   hipError_t e;
+  k_rng_ctl_init<<<1, 64, 0, st>>>(ctl, (const uint32_t*)state);
   if ((e = hipEventRecord(fork, st)) != hipSuccess) return (int)e;
   if ((e = hipStreamWaitEvent(g_side, fork, 0)) != hipSuccess) return (int)e;
-  PROF_LAUNCH(BK_MT19937, g_side, k_mt19937_speculate<<<1, 256, 0, g_side>>>((const uint32_t*)state, cnt_words, 2, out, raw, cap));
+  PROF_LAUNCH(BK_MT19937, g_side, k_mt19937_stream<<<1, 256, 0, g_side>>>((const uint32_t*)state, ctl, out, raw, cap_total));
   if ((e = hipEventRecord(jn, g_side)) != hipSuccess) return (int)e;
-  *join = jn;
-  return 0;
-}
-int bliss_rng_join(void* state, const int32_t* cnt_words, const uint32_t* raw, int cap, hipStream_t st, hipEvent_t join) {
-  hipError_t e;
-  if ((e = hipStreamWaitEvent(st, join, 0)) != hipSuccess) return (int)e;
-  k_mt19937_commit<<<1, 256, 0, st>>>((uint32_t*)state, cnt_words, 2, raw, cap);
+  g_join = jn;
   return (int)hipGetLastError();
 }
+
+int bliss_rng_stream_wait(int32_t* ctl, const void* counts, int32_t* layer_off, int is_last, int32_t cap_total, void* stream) {
+  if (!ctl || !counts || !layer_off) return BLISS_EINVAL;
+  k_rng_wait<<<1, 64, 0, (hipStream_t)stream>>>(ctl, (const int*)counts, layer_off, is_last, cap_total);
+  return (int)hipGetLastError();
+}
+
+int bliss_rng_stream_end(void* state, const int32_t* ctl, const uint32_t* raw, int32_t cap_total, int32_t* err_word, void* stream) {
+  if (!state || !ctl || !raw || !g_join) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if ((e = hipStreamWaitEvent(st, g_join, 0)) != hipSuccess) return (int)e;
+  g_join = nullptr;
+  k_mt19937_commit<<<1, 256, 0, st>>>((uint32_t*)state, ctl, raw, cap_total, err_word);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

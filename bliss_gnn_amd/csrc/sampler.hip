@@ -22,9 +22,6 @@
 #define ITEMS 4
 #define CHUNK (TPB * ITEMS)
 
-int bliss_rng_fork(void* state, const int32_t* cnt_words, float* out, uint32_t* raw, int cap, hipStream_t st, hipEvent_t* join);
-int bliss_rng_join(void* state, const int32_t* cnt_words, const uint32_t* raw, int cap, hipStream_t st, hipEvent_t join);
-
 namespace {
 
 // Work decomposition of every frontier pass: a workgroup (4 waves) owns a CHUNK of 1024 consecutive
@@ -200,8 +197,7 @@ __global__ void __launch_bounds__(1024) k_chunk_scan(int* __restrict__ chunk_cnt
     int total = which == 0 ? cnt->S + run : run;
     int errbit = which == 0 ? BLISS_ERR_CAP_CAND : (which == 1 ? BLISS_ERR_CAP_KEPT : BLISS_ERR_CAP_EDGES);
     if (total > cap) { atomicOr(&cnt->err, errbit); total = cap; }   // clamp: results invalid but in bounds
-    if (which == 0) __hip_atomic_store(&cnt->C, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // polled by the generator
-    else if (which == 1) cnt->K = total; else cnt->B = total;
+    if (which == 0) cnt->C = total; else if (which == 1) cnt->K = total; else cnt->B = total;
   }
 }
 
@@ -361,9 +357,11 @@ __device__ __forceinline__ bf16_t incl_prob(const bf16_t* __restrict__ p, int j,
 }
 
 // ---------------------------------------------------------------- K_i: P_j, Bernoulli compare, count per chunk
-__global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__ p, const float* __restrict__ uniforms,
-                                                      LayerCounts* cnt, bf16_t* __restrict__ P, int* __restrict__ chunk_cnt, int cap_c) {
+__global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__ p, const float* __restrict__ uniforms_base,
+                                                      const int* __restrict__ u_off, LayerCounts* cnt, bf16_t* __restrict__ P,
+                                                      int* __restrict__ chunk_cnt, int cap_c) {
   __shared__ int sh4[TPB / 64];
+  const float* __restrict__ uniforms = uniforms_base + (u_off ? *u_off : 0);
   const int S = cnt->S, C = min(cnt->C, cap_c), all_one = cnt->all_one;
   const float c32 = (float)cnt->c;
   const int nchunks = (C + CHUNK - 1) / CHUNK;
@@ -376,7 +374,8 @@ __global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__
       if (j < C) {
         bf16_t Pj = incl_prob(p, j, S, all_one, c32);
         P[j] = Pj;
-        keep = uniforms[j] < bf2f(Pj);                // :422-424  ATen CPU bernoulli: u24 < float(P)
+        // the numbers may come from a generator kernel that is still running: agent-scope (sc1) load
+        keep = __hip_atomic_load(uniforms + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bf2f(Pj);   // :422-424  u24 < float(P)
       }
       kept += __popcll(__ballot(keep));
     }
@@ -387,12 +386,14 @@ __global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__
 }
 
 // ---------------------------------------------------------------- K_k: ordered compaction of the kept nodes
-__global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ uniforms, LayerCounts* cnt,
+__global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ uniforms_base, const int* __restrict__ u_off,
+                                                      LayerCounts* cnt,
                                                       const bf16_t* __restrict__ P, const int* __restrict__ chunk_off,
                                                       const int* __restrict__ cand_nid, int* __restrict__ new_id,
                                                       int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
                                                       int cap_c, int cap_k) {
   __shared__ int sh4[TPB / 64];
+  const float* __restrict__ uniforms = uniforms_base + (u_off ? *u_off : 0);
   const int C = min(cnt->C, cap_c);
   const int nchunks = (C + CHUNK - 1) / CHUNK;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ 
       const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
       bool keep = false;
       Pv[i] = 0;
-      if (j < C) { Pv[i] = P[j]; keep = uniforms[j] < bf2f(Pv[i]); }
+      if (j < C) { Pv[i] = P[j]; keep = __hip_atomic_load(uniforms + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bf2f(Pv[i]); }
       mask[i] = __ballot(keep);
       wave_total += __popcll(mask[i]);
     }
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(256) k_init_counts(LayerCounts* cnt, int S_hos
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int S = S_host >= 0 ? S_host : *S_dev, err = 0;
     if (S > cap_s) { S = cap_s; err = BLISS_ERR_CAP_SEEDS; }     // clamp: results invalid but in bounds
-    cnt->S = S; cnt->E = 0; cnt->C = -1; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+    cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
   }
 }
 
@@ -592,10 +593,8 @@ int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
 
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
                         int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode, float eta_f,
-                        float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* rng_state,
-                        float* uniforms, uint32_t* rng_raw, void* stream_) {
+                        float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream_) {
   if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0 || !ws->hist) return BLISS_EINVAL;
-  if (rng_state && (!uniforms || !rng_raw)) return BLISS_EINVAL;
   if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
   if (n_seeds > cap_s) return BLISS_EINVAL;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
@@ -611,11 +610,6 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     int gi = (n_words + 255) / 256;
     if (gi > 1024) gi = 1024;
     k_init_counts<<<gi, 256, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s, acc_w, n_words);
-  }
-  hipEvent_t rng_join = nullptr;
-  if (rng_state) {   // fork: the CPU-stream-compatible generator runs beside the passes below
-    int rc = bliss_rng_fork(rng_state, (const int32_t*)cnt, uniforms, rng_raw, ws->cap_c, st, &rng_join);
-    if (rc) return rc;
   }
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes));
   if (mode == BLISS_MODE_BANDIT) {
@@ -637,15 +631,11 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     PROF_LAUNCH(BK_CAND_FINALIZE, st, k_cand_finalize<<<gf, FIN_TPB, 0, st>>>(
         seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->hist, ws->cap_c));
   }
-  if (rng_state) {   // join: hand the generator state after exactly C draws to the next layer / back to the host
-    int rc = bliss_rng_join(rng_state, (const int32_t*)cnt, rng_raw, ws->cap_c, st, rng_join);
-    if (rc) return rc;
-  }
   return (int)hipGetLastError();
 }
 
 int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps, const float* uniforms,
-                         int64_t cand_bound, void* stream_) {
+                         const int32_t* uniforms_offset_dev, int64_t cand_bound, void* stream_) {
   if (!ws || !uniforms || fanout < 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;
@@ -653,9 +643,9 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
   const int gc = grid_for(cand_bound, CHUNK);
   PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps));
-  PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
+  PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
-  PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
+  PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, uniforms_offset_dev, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
                                      ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k));
   return (int)hipGetLastError();
 }

@@ -96,22 +96,19 @@ int bliss_layer_counts_bytes(void);
  * exp3_weights row (BANDIT) or g.edata['w'] (LADIES).  eta_f = (float)eta,
  * one_minus_eta_f = (float)(1.0 - eta).  frontier_bound >= number of in-edges of the seeds
  * (num_edges is always valid).  Out (in ws): counts{S,E,C}, seg_ptr, cand_nid, p; the node maps
- * hold local ids of all candidates until bliss_build_block cleans them.
- * rng_state (optional, uint32[626] as for bliss_mt19937_uniform): when given, the C uniforms of this layer's
- * Poisson draw are generated into uniforms[cap_c] on a library-owned side stream WHILE the frontier passes run
- * (fork/join by events, also inside a captured graph) and rng_state is advanced by exactly C draws;
- * rng_raw: uint32 scratch [624 * (cap_c / 624 + 3)]. */
+ * hold local ids of all candidates until bliss_build_block cleans them. */
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* maps, const void* w_pos,
                         const int32_t* seeds, int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode,
                         float eta_f, float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws,
-                        void* rng_state, float* uniforms, uint32_t* rng_raw, void* stream);
+                        void* stream);
 
 /* PoissonBanditLadiesSampler.compute_prob (scale c, :391-406) + select_neighbors (:408-425).
  * uniforms: fp32 [>= C], the values torch.rand(C) draws from the CPU generator (ATen's serial
- * Bernoulli kernel consumes the same 24-bit stream).  Out: counts{K,c,iters,all_one}, P, new_id,
+ * Bernoulli kernel consumes the same 24-bit stream); the C numbers start at uniforms[*uniforms_offset_dev]
+ * (NULL = 0).  Out: counts{K,c,iters,all_one}, P, new_id,
  * kept_nid, node_prob. */
 int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps, const float* uniforms,
-                         int64_t cand_bound, void* stream);
+                         const int32_t* uniforms_offset_dev, int64_t cand_bound, void* stream);
 
 /* generate_block      bandit_sampler.py:269-339 (BANDIT: Hajek weights) / ladies_sampler.py:71-107.
  * Same g, maps, w_pos, seeds, eta as the matching bliss_frontier_prob call.  Out: counts{B}, the block;
@@ -124,6 +121,19 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* maps, con
  * generator state (uint32[626]: 624 state words, left, next -- the fields torch.get_rng_state()
  * exposes), advanced in place.  Same numbers as torch.rand(n) / torch.bernoulli draw on the CPU. */
 int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offset, float* out, int32_t cap, void* stream);
+
+/* The same generator as ONE streaming kernel per sample_blocks call, on a library-owned side stream, so that the
+ * serial MT19937 recurrence overlaps the sampling kernels (eagerly and inside a captured HIP graph):
+ *   begin: fork the generator from `stream`; it writes uniforms into out[cap_total + 1248] in stream order, keeps the raw
+ *          state blocks in raw[624 * (cap_total / 624 + 3)] and publishes its progress in ctl (int32[8]);
+ *   wait:  (per layer, on `stream`) block `stream` until the next C numbers exist, C = the layer's counts record;
+ *          *layer_off = where they start in `out`; is_last tells the generator where to stop;
+ *   end:   join, then advance `state` by exactly the number of draws the layers consumed; a stream that ran
+ *          short or a generator that made no progress sets bit 128 in *err_word (a counts record's err). */
+int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, void* stream);
+int bliss_rng_stream_wait(int32_t* ctl, const void* counts, int32_t* layer_off, int is_last, int32_t cap_total, void* stream);
+int bliss_rng_stream_end(void* state, const int32_t* ctl, const uint32_t* raw, int32_t cap_total, int32_t* err_word,
+                         void* stream);
 
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);
