@@ -275,16 +275,15 @@ class LayerEngine:
                                                     self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
             if use_rng:
                 off_ptr = self.rng_ctl.data_ptr() + 4 * (8 + n)
-                _lib.check(_lib.lib.bliss_rng_stream_wait(self.rng_ctl.data_ptr(), cnt_ptr, off_ptr, int(n == L - 1),
-                                                          self.rng_cap, st), "bliss_rng_stream_wait")
                 _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), self.rng_out.data_ptr(),
-                                                         off_ptr, cap["C"], st), "bliss_poisson_select")
+                                                         off_ptr, self.rng_ctl.data_ptr(), int(n == L - 1), self.rng_cap,
+                                                         cap["C"], st), "bliss_poisson_select")
             else:
                 u = uniforms[n].to(dev, torch.float32).reshape(-1)
                 m = min(u.numel(), cap["C"])
                 ws.uniforms[:m].copy_(u[:m])
                 _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
-                                                         0, cap["C"], st), "bliss_poisson_select")
+                                                         0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
             c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
                                   b_w.data_ptr(), b_q.data_ptr(), cb)
             _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),

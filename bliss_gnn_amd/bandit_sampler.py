@@ -94,7 +94,7 @@ class BanditLadiesSampler(BlockSampler):
             rs = torch.zeros(L, 3, dtype=torch.int64, device=g.device)
             rs[:, 2] = E                                                # sum of E ones = E * 2^64
             self._row_sum = rs
-            self._scratch = torch.zeros(L, 4, dtype=torch.int64, device=g.device)
+            self._scratch = torch.zeros(L, 6, dtype=torch.int64, device=g.device)
             self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
             self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
 
@@ -114,7 +114,7 @@ class BanditLadiesSampler(BlockSampler):
         self._w_pos = g.by_position(value.to(torch.bfloat16)).contiguous().clone()
         L = self._w_pos.shape[0]
         self._row_sum = torch.zeros(L, 3, dtype=torch.int64, device=g.device)
-        self._scratch = torch.zeros(L, 4, dtype=torch.int64, device=g.device)
+        self._scratch = torch.zeros(L, 6, dtype=torch.int64, device=g.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
         self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
         for l in range(L):

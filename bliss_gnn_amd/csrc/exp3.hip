@@ -160,21 +160,25 @@ __global__ void __launch_bounds__(E3_TPB) k_row_sum(const bf16_t* __restrict__ w
 
 __global__ void k_zero_i64(int64_t* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0; }
 
-// scratch: [0] = norm bits | (skip << 16) | (err << 20), [1..3] = limbs of the renormalised row
-__global__ void k_norm_decide(const int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
-  int bad = 0;
-  bf16_t n = limbs_to_bf16(row_sum, &bad);
-  int skip = (n == 0x3f80);                       // x / 1.0 == x : nothing to do
-  scratch[0] = (int64_t)n | ((int64_t)skip << 16) | ((int64_t)bad << 20);
-  scratch[1] = scratch[2] = scratch[3] = 0;
-  if (norm_out) *norm_out = n;
-}
-
-__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* scratch) {
-  const int64_t s0 = scratch[0];
-  if ((s0 >> 16) & 1) return;
-  const float norm = bf2f((bf16_t)(s0 & 0xffff));
-  const float denom = rbf(fmaxf(norm, 1e-12f));    // F.normalize: norm.clamp_min(eps)
+// F.normalize(row, p=1) in ONE launch.  scratch (int64[6], zero between calls): [0] = norm bits | skip << 16 |
+// err << 20 (for the host), [1..3] limbs of the renormalised row, [4] ticket.  Every workgroup derives the norm from
+// the (read-only) exact row sum; if it is 1.0 nothing is touched.  Otherwise the last workgroup to finish installs the
+// new exact sum -- the others have all read row_sum long before (they read it first thing).
+__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
+  __shared__ int sh_norm, sh_last;
+  if (threadIdx.x == 0) {
+    int bad = 0;
+    const bf16_t nb = limbs_to_bf16(row_sum, &bad);
+    sh_norm = (int)nb | (bad << 20);
+    if (blockIdx.x == 0) {
+      scratch[0] = (int64_t)nb | ((int64_t)(nb == 0x3f80) << 16) | ((int64_t)bad << 20);
+      if (norm_out) *norm_out = nb;
+    }
+  }
+  __syncthreads();
+  const bf16_t nb = (bf16_t)(sh_norm & 0xffff);
+  if (nb == 0x3f80) return;                        // x / 1.0 == x : the row is already normalised, bit for bit
+  const float denom = rbf(fmaxf(bf2f(nb), 1e-12f));  // F.normalize: norm.clamp_min(eps)
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * E3_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * E3_TPB) {
@@ -186,11 +190,19 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
   }
   flush_digits(dg, scratch + 1);
   if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
-}
-
-__global__ void k_norm_commit(int64_t* row_sum, const int64_t* scratch) {
-  if ((scratch[0] >> 16) & 1) return;
-  row_sum[0] = scratch[1]; row_sum[1] = scratch[2]; row_sum[2] = scratch[3];
+  // last workgroup installs the new exact sum (release / ticket / acquire, cdna guide G16)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) sh_last = (atomicAdd((unsigned long long*)(scratch + 4), 1ull) == (unsigned long long)gridDim.x - 1);
+  __syncthreads();
+  if (sh_last && threadIdx.x == 0) {
+    __threadfence();
+    for (int k = 0; k < 3; ++k) {
+      row_sum[k] = (int64_t)__hip_atomic_load((unsigned long long*)(scratch + 1 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((unsigned long long*)(scratch + 1 + k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store((unsigned long long*)(scratch + 4), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // w_pos[p] = bf16(1 / bf16(indeg(dst(p))))          bandit_sampler.py:20-27
@@ -244,12 +256,10 @@ int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const vo
 int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64_t* scratch, void* norm_out_bf16, void* stream) {
   if (!w_pos || !row_sum || !scratch || num_edges <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  k_norm_decide<<<1, 1, 0, st>>>(row_sum, scratch, (bf16_t*)norm_out_bf16);
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, scratch));
-  k_norm_commit<<<1, 1, 0, st>>>(row_sum, scratch);
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16));
   return (int)hipGetLastError();
 }
 

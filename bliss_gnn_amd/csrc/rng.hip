@@ -144,20 +144,7 @@ __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restri
 // main stream, one wave: wait until the generator has produced the numbers layer `n` needs; hand the layer its offset
 __global__ void __launch_bounds__(64) k_rng_wait(int* ctl, const int* __restrict__ cnt_words, int* __restrict__ layer_off,
                                                  int is_last, int cap_total) {
-  if (threadIdx.x != 0) return;
-  int C = cnt_words[2];
-  const int pos = ctl[2];
-  int need = pos + C;
-  if (need > cap_total) { need = cap_total; atomicOr(ctl + 3, 1); }
-  long long spins = 0;
-  while (__hip_atomic_load(ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-    __builtin_amdgcn_s_sleep(8);
-    if (++spins > (1ll << 22)) { atomicOr(ctl + 3, 2); break; }     // bounded: never hang the GPU
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  *layer_off = ctl[4] + pos;
-  ctl[2] = need;
-  if (is_last) __hip_atomic_store(ctl + 1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) rng_stream_acquire(ctl, cnt_words[2], layer_off, is_last, cap_total);
 }
 
 __global__ void k_rng_ctl_init(int* ctl, const uint32_t* __restrict__ state) {

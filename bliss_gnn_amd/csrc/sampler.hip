@@ -75,13 +75,18 @@ __device__ __forceinline__ bf16_t edge_q(bf16_t w, bf16_t wsum, int n, float eta
 }
 
 // ---------------------------------------------------------------- K_a: seed columns -> seg_ptr
+// also resets the counts record and zeroes the per-seed accumulators (a kernel, not hipMemsetAsync: memset nodes
+// of a captured HIP graph were observed to leave this buffer stale on replay -- ROCm 7.2)
 __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
-                                                   LayerCounts* cnt, int* __restrict__ seg_ptr,
+                                                   LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
+                                                   unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
                                                    int* __restrict__ local_id, int num_nodes) {
   __shared__ int sh[17];
-  const int S = cnt->S;
-  long long run = 0;
+  int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
+  if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
+  for (int i = threadIdx.x; i < cap_s * 4; i += blockDim.x) seed_acc[i] = 0ull;   // acc_w, acc_q, acc_wt (u64) + deg_blk (i32)
+  long long run = 0;
   for (int base = 0; base < S; base += blockDim.x) {
     int k = base + threadIdx.x, deg = 0;
     if (k < S) {
@@ -97,10 +102,14 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
     run += tot;
     if (run > 0x7fffffffll) bad |= BLISS_ERR_CAP_FRONTIER;
   }
+  int any_bad = __syncthreads_or(bad);
   if (threadIdx.x == 0) {
     seg_ptr[S] = (int)run;
-    cnt->E = (bad & BLISS_ERR_CAP_FRONTIER) ? 0 : (int)run;
+    cnt->S = S; cnt->E = (any_bad & BLISS_ERR_CAP_FRONTIER) ? 0 : (int)run;
+    cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
+    cnt->err = 0;
   }
+  __syncthreads();
   if (bad) atomicOr(&cnt->err, bad);
 }
 
@@ -311,9 +320,12 @@ __device__ __forceinline__ double block_sum_f64(double v, double* shd) {
   return t;
 }
 
-__global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps) {
+__global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps, int* rng_ctl,
+                                                        int* layer_off, int is_last, int rng_cap_total) {
   __shared__ double shd[16];
   const int C = cnt->C;
+  // the random numbers of this layer come from the streaming generator: one lane waits for them while the others work
+  if (rng_ctl && threadIdx.x == 1023) rng_stream_acquire(rng_ctl, C, layer_off, is_last, rng_cap_total);
   // every thread owns 32 bins; load the counts and leave the histogram zero for the next layer
   int n[HIST_BINS / 1024];
   bool any = false;
@@ -472,8 +484,26 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
 }
 
 // ---------------------------------------------------------------- block CSR indptr from kept in-degrees
-__global__ void __launch_bounds__(1024) k_indptr_scan(const int* __restrict__ deg_blk, LayerCounts* cnt, int* __restrict__ blk_indptr, int cap_s) {
+// block 0: exclusive scan of the kept-edge chunk counts (-> B); block 1: block CSR indptr from the kept in-degrees
+__global__ void __launch_bounds__(1024) k_block_scans(int* __restrict__ chunk_cnt, const int* __restrict__ deg_blk, LayerCounts* cnt,
+                                                      int* __restrict__ blk_indptr, int cap_s, int cap_b) {
   __shared__ int sh[17];
+  if (blockIdx.x == 0) {
+    const int n = (cnt->E + CHUNK - 1) / CHUNK;
+    int run = 0;
+    for (int base = 0; base < n; base += blockDim.x) {
+      int i = base + threadIdx.x;
+      int v = i < n ? chunk_cnt[i] : 0;
+      int tot, ex = block_excl_scan(v, sh, &tot);
+      if (i < n) chunk_cnt[i] = run + ex;
+      run += tot;
+    }
+    if (threadIdx.x == 0) {
+      if (run > cap_b) { atomicOr(&cnt->err, BLISS_ERR_CAP_EDGES); run = cap_b; }   // clamp: results invalid but in bounds
+      cnt->B = run;
+    }
+    return;
+  }
   const int S = cnt->S;
   int run = 0;
   for (int base = 0; base < S; base += blockDim.x) {
@@ -564,18 +594,6 @@ __global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __
   for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) local_id[cand_nid[id]] = -1;
 }
 
-// also zeroes the per-seed accumulators (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph
-// were observed to leave this buffer stale on replay -- ROCm 7.2)
-__global__ void __launch_bounds__(256) k_init_counts(LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
-                                                     unsigned long long* __restrict__ seed_acc, int n_words) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) seed_acc[i] = 0ull;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int S = S_host >= 0 ? S_host : *S_dev, err = 0;
-    if (S > cap_s) { S = cap_s; err = BLISS_ERR_CAP_SEEDS; }     // clamp: results invalid but in bounds
-    cnt->S = S; cnt->E = 0; cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->err = err; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
-  }
-}
-
 inline int grid_for(int64_t n, int per_block, int max_blocks = 2048) {
   int64_t g = (n + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -605,13 +623,8 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   unsigned long long* acc_q = acc_w + cap_s;                                // [cap_s]
   if (frontier_bound < 1) frontier_bound = 1;
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
-  {
-    const int n_words = cap_s * 4;                                          // acc_w, acc_q, acc_wt (u64) + deg_blk (i32, padded)
-    int gi = (n_words + 255) / 256;
-    if (gi > 1024) gi = 1024;
-    k_init_counts<<<gi, 256, 0, st>>>(cnt, n_seeds, n_seeds_dev, cap_s, acc_w, n_words);
-  }
-  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, ws->seg_ptr, m->local_id, g->num_nodes));
+  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
+                                                            m->local_id, g->num_nodes));
   if (mode == BLISS_MODE_BANDIT) {
     PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
     PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
@@ -635,14 +648,15 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
 }
 
 int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps, const float* uniforms,
-                         const int32_t* uniforms_offset_dev, int64_t cand_bound, void* stream_) {
-  if (!ws || !uniforms || fanout < 0) return BLISS_EINVAL;
+                         int32_t* uniforms_offset_dev, int32_t* rng_ctl, int is_last, int32_t rng_cap_total,
+                         int64_t cand_bound, void* stream_) {
+  if (!ws || !uniforms || fanout < 0 || (rng_ctl && !uniforms_offset_dev)) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;
   if (cand_bound < 1) cand_bound = 1;
   if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
   const int gc = grid_for(cand_bound, CHUNK);
-  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps));
+  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps, rng_ctl, uniforms_offset_dev, is_last, rng_cap_total));
   PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
   PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, uniforms_offset_dev, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
@@ -667,8 +681,7 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
     PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
   else
     PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
-  PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 2, out->cap_b));
-  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_indptr_scan<<<1, 1024, 0, st>>>(deg_blk, cnt, out->indptr, cap_s));
+  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b));
   if (mode == BLISS_MODE_BANDIT)
     PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b));
   else

@@ -103,7 +103,8 @@ class GraphedTrainStep:
     def __init__(self, g, sampler, model, batch_size, lr=0.002, multilabel=False):
         self.g, self.sampler, self.model, self.bs = g, sampler, model, int(batch_size)
         self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True)
+        # one fused multi-tensor kernel instead of ~40 foreach launches (each >= 5 us inside a graph)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)
         self.seeds = torch.zeros(self.bs, dtype=torch.int32, device=g.device)
         self.graph = None
         self.num_steps = 0

@@ -105,10 +105,12 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* maps, c
 /* PoissonBanditLadiesSampler.compute_prob (scale c, :391-406) + select_neighbors (:408-425).
  * uniforms: fp32 [>= C], the values torch.rand(C) draws from the CPU generator (ATen's serial
  * Bernoulli kernel consumes the same 24-bit stream); the C numbers start at uniforms[*uniforms_offset_dev]
- * (NULL = 0).  Out: counts{K,c,iters,all_one}, P, new_id,
+ * (NULL = 0).  With rng_ctl (bliss_rng_stream_begin) the call itself waits for the streaming generator and
+ * writes the offset, exactly like bliss_rng_stream_wait.  Out: counts{K,c,iters,all_one}, P, new_id,
  * kept_nid, node_prob. */
 int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps, const float* uniforms,
-                         const int32_t* uniforms_offset_dev, int64_t cand_bound, void* stream);
+                         int32_t* uniforms_offset_dev, int32_t* rng_ctl, int is_last, int32_t rng_cap_total,
+                         int64_t cand_bound, void* stream);
 
 /* generate_block      bandit_sampler.py:269-339 (BANDIT: Hajek weights) / ladies_sampler.py:71-107.
  * Same g, maps, w_pos, seeds, eta as the matching bliss_frontier_prob call.  Out: counts{B}, the block;
@@ -186,7 +188,8 @@ int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const vo
                      int32_t n_bound, int32_t* err, void* stream);
 
 /* F.normalize(row, p=1, dim=0), bandit_sampler.py:249, bit-exact: norm = bf16(exact sum).  The pass
- * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[4]. */
+ * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[6], zero-initialised
+ * once by the caller and left zero ([0] afterwards holds norm bits | skip << 16 | err << 20). */
 int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64_t* scratch, void* norm_out_bf16,
                          void* stream);
 
