@@ -46,6 +46,7 @@ class _LayerWs:
         self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
         self.P = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
         self.uniforms = torch.empty(cap_c, dtype=torch.float32, device=dev)     # explicit-uniforms path only
+        self.src_cnt = None
 
 
 class LayerEngine:
@@ -206,12 +207,14 @@ class LayerEngine:
         self.mt_back.copy_(self.mt_dev, non_blocking=True)
         blocks = []
         for n, lay in enumerate(layers):
-            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev = lay
+            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev, t_indptr, t_edge = lay
             cap = self.caps[n]
             blk = Block(self.g, cap["K"], cap["S"], b_indptr, b_src, b_dst, b_pos, b_eid, kept_nid)
             blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
             blk._counts, blk._counts_dev = None, cdev
             blk._nnz_ptr = counts_dev.data_ptr() + 40 * n + 16
+            if t_indptr is not None:
+                blk._transposed = (t_indptr, t_edge)
             blk._trace = {}
             blocks.append(blk)
         self._static = (blocks, L)          # kept: a captured graph replays this enqueue without re-running it
@@ -253,7 +256,11 @@ class LayerEngine:
             cap, ws = self.caps[n], self.ws[n]
             cs, ck, cb = cap["S"], cap["K"], cap["B"]
             # caller-owned outputs: one int32 and one bf16 allocation per layer, sliced
-            ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck), dtype=torch.int32, device=dev)
+            build_t = cs <= 32768                     # by-source index built by the sampler kernels themselves
+            if ws.src_cnt is None or ws.src_cnt.numel() < ck + 1:
+                ws.src_cnt = torch.empty(ck + 1, dtype=torch.int32, device=dev)
+            ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck) + (2 * _up8(cb) + _up8(ck + 1) if build_t else 0),
+                               dtype=torch.int32, device=dev)
             hbuf = torch.empty(2 * _up8(cb) + _up8(ck), dtype=torch.bfloat16, device=dev)
             o = 0
             b_indptr = ibuf[o:o + cs + 1]; o += _up8(cs + 1)
@@ -261,14 +268,20 @@ class LayerEngine:
             b_dst = ibuf[o:o + cb]; o += _up8(cb)
             b_pos = ibuf[o:o + cb]; o += _up8(cb)
             b_eid = ibuf[o:o + cb]; o += _up8(cb)
-            kept_nid = ibuf[o:o + ck]
+            kept_nid = ibuf[o:o + ck]; o += _up8(ck)
+            t_indptr = t_edge = t_scr = None
+            if build_t:
+                t_indptr = ibuf[o:o + ck + 1]; o += _up8(ck + 1)
+                t_edge = ibuf[o:o + cb]; o += _up8(cb)
+                t_scr = ibuf[o:o + cb]
             b_w = hbuf[0:cb]
             b_q = hbuf[_up8(cb):_up8(cb) + cb]
             node_prob = hbuf[2 * _up8(cb):2 * _up8(cb) + ck]
             cnt_ptr = counts.data_ptr() + 40 * n
             c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
                                 ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
-                                kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(), cap["C"], ck)
+                                kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
+                                ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
             w_pos = w_rows[n]
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
@@ -285,11 +298,12 @@ class LayerEngine:
                 _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
                                                          0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
             c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
-                                  b_w.data_ptr(), b_q.data_ptr(), cb)
+                                  b_w.data_ptr(), b_q.data_ptr(), _ptr(t_indptr), _ptr(t_edge), _ptr(t_scr), cb)
             _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                   cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, self.Eg, C.byref(c_ws),
                                                   C.byref(c_out), st), "bliss_build_block")
-            layers.append((b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10]))
+            layers.append((b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10],
+                           t_indptr, t_edge))
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
         if use_rng:      # join; mt_dev = generator state after exactly sum(C) draws
             _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
@@ -300,11 +314,13 @@ class LayerEngine:
         _, layers = out
         blocks = []
         for n, (lay, c) in enumerate(zip(layers, cnts)):
-            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev = lay
+            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev, t_indptr, t_edge = lay
             S, K, B = c.S, c.K, c.B
             blk = Block(self.g, K, S, b_indptr[:S + 1], b_src[:B], b_dst[:B], b_pos[:B], b_eid[:B], kept_nid[:K])
             blk._edge_weights, blk._q, blk._node_prob = b_w[:B], b_q[:B], node_prob[:K]
             blk._counts, blk._counts_dev = c, cdev
+            if t_indptr is not None:
+                blk._transposed = (t_indptr[:K + 1], t_edge[:max(B, 1)])
             ws = self.ws[n]
             blk._trace = dict(p=ws.p[:c.C], P=ws.P[:c.C], cand_nid=ws.cand_nid[:c.C], new_id=ws.new_id[:c.C])
             blocks.append(blk)

@@ -41,12 +41,13 @@ class LayerCounts(C.Structure):
 class LayerWs(C.Structure):
     _fields_ = [("counts", C.c_void_p), ("seg_ptr", C.c_void_p), ("seed_acc", C.c_void_p), ("chunk_cnt", C.c_void_p),
                 ("cand_nid", C.c_void_p), ("p", C.c_void_p), ("P", C.c_void_p), ("new_id", C.c_void_p),
-                ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("hist", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32)]
+                ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("hist", C.c_void_p), ("src_cnt", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32)]
 
 
 class BlockOut(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("pos", C.c_void_p),
-                ("eid", C.c_void_p), ("edge_weights", C.c_void_p), ("q_ij", C.c_void_p), ("cap_b", C.c_int32)]
+                ("eid", C.c_void_p), ("edge_weights", C.c_void_p), ("q_ij", C.c_void_p), ("t_indptr", C.c_void_p),
+                ("t_edge", C.c_void_p), ("t_scratch", C.c_void_p), ("cap_b", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

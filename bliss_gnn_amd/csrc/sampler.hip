@@ -80,12 +80,13 @@ __device__ __forceinline__ bf16_t edge_q(bf16_t w, bf16_t wsum, int n, float eta
 __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
                                                    LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
                                                    unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
-                                                   int* __restrict__ local_id, int num_nodes) {
+                                                   int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k) {
   __shared__ int sh[17];
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
   for (int i = threadIdx.x; i < cap_s * 4; i += blockDim.x) seed_acc[i] = 0ull;   // acc_w, acc_q, acc_wt (u64) + deg_blk (i32)
+  if (src_cnt) for (int i = threadIdx.x; i <= cap_k; i += blockDim.x) src_cnt[i] = 0;
   long long run = 0;
   for (int base = 0; base < S; base += blockDim.x) {
     int k = base + threadIdx.x, deg = 0;
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      const unsigned long long* __restrict__ acc_w,
                                                      const int* __restrict__ local_id, const int* __restrict__ new_id,
                                                      const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
-                                                     int* __restrict__ chunk_cnt, float eta_f, float ome_f) {
+                                                     int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f) {
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -464,7 +465,9 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
       int64_t term = 0;
       if (a.k >= 0) {
         const int lid = local_id[a.src];
-        kept = new_id[lid] >= 0;                       // :289-298 source was drawn (seeds always are)
+        const int nid = new_id[lid];
+        kept = nid >= 0;                               // :289-298 source was drawn (seeds always are)
+        if (kept && src_cnt) atomicAdd(src_cnt + nid, 1);   // out-degree inside the block: sizes the by-source index
         if (kept && BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
           bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
@@ -486,8 +489,20 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
 // ---------------------------------------------------------------- block CSR indptr from kept in-degrees
 // block 0: exclusive scan of the kept-edge chunk counts (-> B); block 1: block CSR indptr from the kept in-degrees
 __global__ void __launch_bounds__(1024) k_block_scans(int* __restrict__ chunk_cnt, const int* __restrict__ deg_blk, LayerCounts* cnt,
-                                                      int* __restrict__ blk_indptr, int cap_s, int cap_b) {
+                                                      int* __restrict__ blk_indptr, int cap_s, int cap_b,
+                                                      int* __restrict__ src_cnt, int* __restrict__ t_indptr, int cap_k) {
   __shared__ int sh[17];
+  if (blockIdx.x == 2) {                               // by-source list starts; src_cnt becomes the fill cursor
+    int run = 0;
+    for (int base = 0; base <= cap_k; base += blockDim.x) {
+      int j = base + threadIdx.x;
+      int v = j < cap_k ? src_cnt[j] : 0;
+      int tot, ex = block_excl_scan(v, sh, &tot);
+      if (j <= cap_k) { t_indptr[j] = run + ex; if (j < cap_k) src_cnt[j] = run + ex; }
+      run += tot;
+    }
+    return;
+  }
   if (blockIdx.x == 0) {
     const int n = (cnt->E + CHUNK - 1) / CHUNK;
     int run = 0;
@@ -529,7 +544,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      const int* __restrict__ chunk_off, int* __restrict__ out_src,
                                                      int* __restrict__ out_dst, int* __restrict__ out_pos,
                                                      int* __restrict__ out_eid, bf16_t* __restrict__ out_w,
-                                                     bf16_t* __restrict__ out_q, float eta_f, float ome_f, int cap_b) {
+                                                     bf16_t* __restrict__ out_q, int* src_cursor, int* __restrict__ t_unsorted,
+                                                     float eta_f, float ome_f, int cap_b) {
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -576,6 +592,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
           out = wt * d;                                                // ladies_sampler.py:97
         }
         out_src[idx] = nids[i];
+        if (src_cursor) t_unsorted[atomicAdd(src_cursor + nids[i], 1)] = idx;   // its source's list, arbitrary order for now
         out_dst[idx] = k;
         out_pos[idx] = (int)pos;
         out_eid[idx] = eid_map ? eid_map[pos] : (int)pos;              // :335-337
@@ -586,6 +603,60 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
     }
   }
   if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ---------------------------------------------------------------- by-source lists into ascending edge order
+// One wave per source.  A source has at most one edge per destination, so an edge's rank inside its list is the
+// number of list members with a smaller destination: short lists (<= 64) rank in registers, longer ones through a
+// per-wave LDS bitmap over the destinations (popcount prefix) -- O(len + S/32) per list, no comparison sort.
+#define TSORT_MAX_S 32768
+__global__ void __launch_bounds__(TPB) k_tr_sort_lists(const int* __restrict__ t_indptr, const int* __restrict__ t_unsorted,
+                                                       const int* __restrict__ dst, LayerCounts* cnt, int cap_k, int cap_s,
+                                                       int* __restrict__ t_edge) {
+  extern __shared__ unsigned bm_all[];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int words = (cap_s + 31) / 32;
+  unsigned* bm = bm_all + (size_t)wave * (words + 1);
+  const int K = min(cnt->K, cap_k);
+  for (int j = blockIdx.x * (TPB / 64) + wave; j < K; j += gridDim.x * (TPB / 64)) {
+    const int beg = t_indptr[j], len = t_indptr[j + 1] - beg;
+    if (len <= 0) continue;
+    if (len <= 64) {
+      const int v = lane < len ? t_unsorted[beg + lane] : 0x7fffffff;
+      int rank = 0;
+      for (int k = 0; k < len; ++k) rank += (__shfl(v, k) < v);
+      if (lane < len) t_edge[beg + rank] = v;
+      continue;
+    }
+    for (int w = lane; w <= words; w += 64) bm[w] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < len; i += 64) { const int d = dst[t_unsorted[beg + i]]; atomicOr(bm + (d >> 5), 1u << (d & 31)); }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // exclusive prefix of popcounts, kept in place in a second word array would double LDS: do it in registers
+    int carry = 0;
+    for (int base = 0; base < words; base += 64) {
+      const int w = base + lane;
+      const unsigned bits = w < words ? bm[w] : 0u;
+      int c = __popc(bits), inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+      const int excl = carry + inc - c;
+      carry += __shfl(inc, 63);
+      // every list member whose destination falls in this word group finds its rank here
+      for (int i = 0; i < len; i += 64) {
+        const int idx = i + lane;
+        int e = 0, d = -1;
+        if (idx < len) { e = t_unsorted[beg + idx]; d = dst[e]; }
+        const int dw = d >> 5;
+        const bool mine = idx < len && dw >= base && dw < base + 64;
+        const int src_lane = mine ? dw - base : 0;
+        const int ex_w = __shfl(excl, src_lane);
+        const unsigned bits_w = __shfl((int)bits, src_lane);
+        if (mine) t_edge[beg + ex_w + __popc(bits_w & ((1u << (d & 31)) - 1u))] = e;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ---------------------------------------------------------------- K_o: leave the dense id map clean
@@ -624,7 +695,7 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   if (frontier_bound < 1) frontier_bound = 1;
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
-                                                            m->local_id, g->num_nodes));
+                                                            m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT) {
     PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
     PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
@@ -677,15 +748,23 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   int* deg_blk = (int*)(acc_w + 3 * (size_t)cap_s);
   if (frontier_bound < 1) frontier_bound = 1;
   const int gc = grid_for(frontier_bound, CHUNK);
+  int* src_cnt = ws->src_cnt;
+  const bool want_t = src_cnt && out->t_indptr && out->t_edge && out->t_scratch;
+  if (want_t && cap_s > TSORT_MAX_S) return BLISS_EINVAL;                    // caller falls back to bliss_block_transpose
+  int* sc = want_t ? src_cnt : nullptr;
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f));
   else
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, eta_f, one_minus_eta_f));
-  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f));
+  PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<want_t ? 3 : 2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b, src_cnt, out->t_indptr, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b));
   else
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, eta_f, one_minus_eta_f, out->cap_b));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b));
+  if (want_t) {
+    const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
+    PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge));
+  }
   PROF_LAUNCH(BK_CLEANUP, st, k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c));
   return (int)hipGetLastError();
 }

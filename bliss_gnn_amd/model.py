@@ -35,3 +35,33 @@ class SAGE(nn.Module):
                 h = self.activation(h)
                 h = self.dropout(h)
         return h
+
+
+class GCN(nn.Module):
+    """model.py:386-439: stacked ``dglnn.GraphConv(norm='both', allow_zero_in_degree=True)`` with the sampler's edge
+    weights.  (Unreachable from the reference's CLI -- ``--model gcn`` trains SAGE, train_lightning.py:597-607 -- kept
+    for API completeness.)"""
+
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout):
+        super().__init__()
+        from .nn import GraphConv
+        self.n_layers, self.n_hidden, self.n_classes = n_layers, n_hidden, n_classes
+        self.layers = nn.ModuleList()
+        if n_layers > 1:
+            self.layers.append(GraphConv(in_feats, n_hidden, activation=activation, allow_zero_in_degree=True))
+            for _ in range(1, n_layers - 1):
+                self.layers.append(GraphConv(n_hidden, n_hidden, activation=activation, allow_zero_in_degree=True))
+            self.layers.append(GraphConv(n_hidden, n_classes, allow_zero_in_degree=True))
+        else:
+            self.layers.append(GraphConv(in_feats, n_classes, allow_zero_in_degree=True))
+        self.dropout = nn.Dropout(dropout)
+        self.activation = activation
+
+    def forward(self, blocks, x):
+        h = x
+        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+            block.srcdata["embed_norm"] = embed_norm(h)                       # model.py:425-427
+            h = layer(block, h, edge_weight=(block.edata["edge_weights"] if "edge_weights" in block.edata else None))
+            if l < len(self.layers) - 1:
+                h = self.dropout(h)                                           # model.py:437-438
+        return h

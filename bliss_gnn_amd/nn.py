@@ -111,3 +111,40 @@ class SAGEConv(nn.Module):
         if self.norm is not None:
             rst = self.norm(rst)
         return rst
+
+
+class GraphConv(nn.Module):
+    """dglnn.GraphConv(in, out, norm='both', weight=True, bias=True) as built at model.py:397-417.
+
+    [DGL-recalled] forward(graph, feat, edge_weight): feat_src * out_deg^-1/2 (degrees clamped to >= 1); weight first
+    iff in > out; aggregate = update_all(u_mul_e('h','_edge_weight'), sum); then weight; * in_deg^-1/2; + bias;
+    activation.  Degrees are the block's structural degrees (edge weights do not enter the normalisation)."""
+
+    def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None, allow_zero_in_degree=False):
+        super().__init__()
+        if norm != "both" or not weight:
+            raise NotImplementedError("the reference only builds GraphConv(norm='both', weight=True)")
+        self._in_feats, self._out_feats, self._activation = in_feats, out_feats, activation
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        self.bias = nn.Parameter(torch.zeros(out_feats)) if bias else None
+        nn.init.xavier_uniform_(self.weight)
+
+    def forward(self, graph, feat, weight=None, edge_weight=None):
+        n_dst = graph.num_dst_nodes()
+        out_deg = torch.zeros(graph.num_src_nodes(), dtype=torch.int32, device=feat.device)
+        out_deg.index_add_(0, graph.src, torch.ones_like(graph.src))
+        norm_src = out_deg.clamp(min=1).to(feat.dtype).pow(-0.5)
+        feat_src = feat * norm_src[:, None]
+        w = self.weight
+        if self._in_feats > self._out_feats:
+            rst = weighted_aggregate(graph, feat_src @ w, edge_weight, mean=False)
+        else:
+            rst = weighted_aggregate(graph, feat_src, edge_weight, mean=False) @ w
+        in_deg = (graph.indptr[1:n_dst + 1] - graph.indptr[:n_dst]).clamp(min=1).to(feat.dtype).pow(-0.5)
+        rst = rst * in_deg[:, None]
+        if self.bias is not None:
+            rst = rst + self.bias
+        if self._activation is not None:
+            rst = self._activation(rst)
+        return rst

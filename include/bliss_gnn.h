@@ -71,6 +71,7 @@ typedef struct {
   int32_t* kept_nid;        /* [cap_k] global id of every kept node (block srcdata[NID]) */
   void* node_prob;          /* bf16 [cap_k] srcdata['node_prob'] */
   int32_t* hist;            /* [32768] counts per bf16 bit pattern of p; zero on entry, left zero */
+  int32_t* src_cnt;         /* [cap_k + 1] edges per block source / fill cursor of the by-source index, or NULL */
   int32_t cap_c, cap_k;
 } bliss_layer_ws_t;
 
@@ -83,6 +84,9 @@ typedef struct {
   int32_t* eid;             /* [cap_b] edata[dgl.EID] */
   void* edge_weights;       /* bf16 [cap_b] edata['edge_weights'] */
   void* q_ij;               /* bf16 [cap_b] edata['q_ij'] (bandit) / the static weight (ladies) */
+  int32_t* t_indptr;        /* [cap_k + 1] by-SOURCE index of the same edges (the SpMM backward gathers through it), */
+  int32_t* t_edge;          /* [cap_b]     ascending edge index inside a source; NULL = do not build it              */
+  int32_t* t_scratch;       /* [cap_b]     scratch for building it (needs ws->src_cnt and cap_s <= 32768)            */
   int32_t cap_b;
 } bliss_block_out_t;
 

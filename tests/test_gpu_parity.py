@@ -435,3 +435,70 @@ def test_static_shape_and_graph_replay_match_eager(cuda):
         ti, te = bp.transposed()
         order = torch.argsort(be.src, stable=True).to(torch.int32)
         assert torch.equal(te[:B], order) and int(ti[K]) == B
+
+
+def test_replica_exchange_path_single_rank(cuda):
+    """bliss_gnn_amd/dist.py end to end on the GPU with a world of one rank (RCCL): computing the EXP3 factors
+    without applying them, all-gathering the (position, factor) lists, applying them and renormalising must leave
+    exactly the bits sampler.exp3 leaves; the flat-bucket gradient all-reduce must be the identity."""
+    import os
+    import torch.distributed as dist
+    from bliss_gnn_amd import dist as bdist
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        ip, ix, ei = chung_lu_csc(4000, 60000, seed=21)
+        outs = []
+        for use_dist in (False, True):
+            g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+            g.edata["w"] = bg.normalized_edata(g)
+            s = bg.PoissonBanditLadiesSampler([200, 100, 50], eta=0.1)
+            gen = torch.Generator().manual_seed(4)
+            for step in range(3):
+                torch.manual_seed(step)
+                _, _, blocks = s.sample_blocks(g, torch.arange(10 * step, 10 * step + 32, dtype=torch.int32, device=cuda))
+                for b in blocks:
+                    b.srcdata["embed_norm"] = (torch.rand(b.num_src_nodes(), generator=gen) * 50).bfloat16().to(cuda)
+                if use_dist:
+                    bdist.exp3_all_ranks(s, blocks, g)
+                else:
+                    s.exp3(blocks, g)
+            s.check_errors()
+            outs.append(s.exp3_weights.cpu().view(torch.int16).clone())
+        assert torch.equal(outs[0], outs[1])
+        lin = torch.nn.Linear(8, 4).to(cuda).bfloat16()
+        lin(torch.randn(3, 8, device=cuda).bfloat16()).float().sum().backward()
+        g0 = [p.grad.clone() for p in lin.parameters()]
+        bdist.allreduce_gradients(lin)
+        assert all(torch.equal(a, p.grad) for a, p in zip(g0, lin.parameters()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gcn_layer_vs_fp32(cuda):
+    """a20: GraphConv(norm='both') with sampler edge weights vs an fp32 restatement of [DGL-recalled] GraphConv."""
+    from bliss_gnn_amd.nn import GraphConv
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(3000, 40000, seed=31)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    sampler = bg.PoissonBanditLadiesSampler([150], eta=0.1)
+    torch.manual_seed(1)
+    _, _, (blk,) = sampler.sample_blocks(g, torch.arange(40, dtype=torch.int32, device=cuda))
+    K, S = blk.num_src_nodes(), blk.num_dst_nodes()
+    for fin, fout in ((48, 16), (16, 48)):
+        torch.manual_seed(2)
+        layer = GraphConv(fin, fout, allow_zero_in_degree=True).to(cuda).bfloat16()
+        h = torch.randn(K, fin, generator=torch.Generator().manual_seed(3)).bfloat16().to(cuda)
+        out = layer(blk, h, edge_weight=blk.edata["edge_weights"]).float().cpu()
+        src, dst, w = blk.src.cpu().long(), blk.dst.cpu().long(), blk.edata["edge_weights"].float().cpu()
+        od = torch.bincount(src, minlength=K).clamp(min=1).float().pow(-0.5)
+        idg = torch.bincount(dst, minlength=S).clamp(min=1).float().pow(-0.5)
+        W = layer.weight.float().cpu()
+        x = h.float().cpu() * od[:, None]
+        agg = lambda z: torch.zeros(S, z.shape[1]).index_add_(0, dst, z[src] * w[:, None])
+        ref = (agg(x @ W) if fin > fout else agg(x) @ W) * idg[:, None] + layer.bias.float().cpu()
+        assert (out - ref).abs().max() <= 4 * ref.abs().max() * 2 ** -8
