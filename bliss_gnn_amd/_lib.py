@@ -71,6 +71,11 @@ SIGNATURES = {
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],
+    "bliss_gat_logits": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
+    "bliss_gat_edge_dot": [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _P, _P],
+    "bliss_gat_edge_softmax": [_P, _I32, _P, _P, _I32, C.c_int, _P, _P],
+    "bliss_gat_rows": [C.c_int, _P, _I32, _P, _P, _P, _P, _I32, _P, _P, _I64, _P, _I32, _I32, _F, _P, _I64, _P, _P, _P],
+    "bliss_gat_alpha": [_P, _I32, _P, _P, _P, _P, _P],
     "bliss_prof_enable": [C.c_int],
     "bliss_prof_reset": [],
     "bliss_prof_read": [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

@@ -178,8 +178,12 @@ class BanditLadiesSampler(BlockSampler):
         for idx, mfg in enumerate(mfgs):
             B = mfg.num_edges()
             alpha = None
-            if self.model == "gat":
-                raise NotImplementedError("GAT alpha (bandit_sampler.py:146-154) lands with the GAT path")
+            if self.model == "gat":                                    # calculate_alpha, bandit_sampler.py:146-154
+                a_ij = mfg.edata["a_ij"].detach()
+                a_ij = a_ij.bfloat16().contiguous() if a_ij.dtype != torch.bfloat16 else a_ij.contiguous()
+                alpha = torch.empty(B, dtype=torch.bfloat16, device=g.device)
+                _lib.check(_lib.lib.bliss_gat_alpha(mfg.indptr.data_ptr(), mfg.num_dst_nodes(), mfg.edata["q_ij"].data_ptr(),
+                                                    a_ij.data_ptr(), alpha.data_ptr(), self._err.data_ptr(), st), "bliss_gat_alpha")
             n_edges_ptr = mfg._counts_dev.data_ptr() + 16             # LayerCounts::B, already on the device
             rewards = torch.empty(B, dtype=torch.bfloat16, device=g.device)
             en = mfg.srcdata["embed_norm"]

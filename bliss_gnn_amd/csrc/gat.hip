@@ -1,0 +1,278 @@
+// GATv2 attention path for gfx950 -- the message-passing part of custom_GATv2Conv.forward (model.py:48-112):
+//   e_ij[h]   = attn[h,:] . leaky_relu(el[src_j,h,:] + er[dst_i,h,:])           model.py:82-86  (returned as "attention", :108-110)
+//   a_ij[h]   = softmax over the in-edges of i                                    model.py:88-90  (dglnn.functional.edge_softmax)
+//   out[i,h,:] = sum_j a_ij[h] * el[src_j,h,:]                                    model.py:98     (update_all(u_mul_e, sum))
+// and their backward passes, plus calculate_alpha's GAT branch (bandit_sampler.py:146-154).
+//
+// DGL materialises the [B, H, D'] edge tensor (363 MB at layer 0 of the Reddit config); here every
+// kernel recomputes el+er on the fly from the two gathered rows, so only [B, H] logits/attention ever touch HBM.
+// Balanced traversal: a wave owns a fixed number of consecutive edges (like csrc/spmm.hip); row sums that cross
+// chunk boundaries go through fp32 partials and the shared fix-up kernel, so everything is deterministic.
+// fp32 math, bf16 storage (compared with an fp32 torch reference in tests/, tolerance stated there).
+#include "common.cuh"
+#include "bliss_gnn.h"
+#include "prof.h"
+
+namespace {
+
+#define GAT_TPB 256
+#define GAT_EC 16          // edges per wave in the per-edge dot kernels
+#define GAT_MAXH 8
+
+__device__ __forceinline__ float lrelu(float x, float s) { return x > 0.f ? x : s * x; }
+
+// per-edge, per-head dot product of two gathered rows.
+//   MODE 0 (logits):  e[e,h]  = sum_d attn[h,d] * lrelu(feat[src_e,h,d] + feat[dst_e,h,d])
+//   MODE 1 (d_a):     out[e,h] = sum_d g[dst_e,h,d] * feat[src_e,h,d]
+template <int MODE>
+__global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict__ src, const int* __restrict__ dst,
+                                                         const int* __restrict__ nnz_dev, int nnz_host,
+                                                         const bf16_t* __restrict__ feat, int64_t feat_stride,
+                                                         const bf16_t* __restrict__ g, int64_t g_stride,
+                                                         const bf16_t* __restrict__ attn, int H, int D, float slope,
+                                                         bf16_t* __restrict__ out) {
+  const int nnz = nnz_dev ? min(*nnz_dev, nnz_host) : nnz_host;
+  const int lane = lane_id();
+  const int chunk = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
+  const int e0 = chunk * GAT_EC, e1 = min(nnz, e0 + GAT_EC);
+  const int HD = H * D;
+  for (int e = e0; e < e1; ++e) {
+    const bf16_t* a = feat + (int64_t)src[e] * feat_stride;
+    const bf16_t* b = (MODE == 0 ? feat + (int64_t)dst[e] * feat_stride : g + (int64_t)dst[e] * g_stride);
+    float part[GAT_MAXH];
+#pragma unroll
+    for (int h = 0; h < GAT_MAXH; ++h) part[h] = 0.f;
+    for (int idx = lane; idx < HD; idx += 64) {
+      const float x = bf2f(a[idx]), y = bf2f(b[idx]);
+      const float v = MODE == 0 ? bf2f(attn[idx]) * lrelu(x + y, slope) : x * y;
+      const int hd = idx / D;
+#pragma unroll
+      for (int h = 0; h < GAT_MAXH; ++h) if (h == hd) part[h] += v;
+    }
+#pragma unroll
+    for (int h = 0; h < GAT_MAXH; ++h) {
+      if (h < H) {
+        float s = part[h];
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) out[(int64_t)e * H + h] = f2bf(s);
+      }
+    }
+  }
+}
+
+// edge softmax over the in-edges of every destination (one wave per destination), forward and backward
+//   FWD: a = exp(e - max) / sum                      BWD: de = a * (da - sum_e' a da)
+template <bool BWD>
+__global__ void __launch_bounds__(GAT_TPB) k_gat_softmax(const int* __restrict__ indptr, int n_dst, const bf16_t* __restrict__ x,
+                                                        const bf16_t* __restrict__ a_in, int H, bf16_t* __restrict__ out) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
+  if (row >= n_dst) return;
+  const int beg = indptr[row], end = indptr[row + 1];
+  for (int h = 0; h < H; ++h) {
+    if (!BWD) {
+      float m = -__builtin_inff();
+      for (int e = beg + lane; e < end; e += 64) m = fmaxf(m, bf2f(x[(int64_t)e * H + h]));
+      for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+      float s = 0.f;
+      for (int e = beg + lane; e < end; e += 64) s += __expf(bf2f(x[(int64_t)e * H + h]) - m);
+      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+      for (int e = beg + lane; e < end; e += 64) out[(int64_t)e * H + h] = f2bf(__expf(bf2f(x[(int64_t)e * H + h]) - m) / s);
+    } else {
+      float t = 0.f;                                   // x = d_a, a_in = a
+      for (int e = beg + lane; e < end; e += 64) t += bf2f(a_in[(int64_t)e * H + h]) * bf2f(x[(int64_t)e * H + h]);
+      for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+      for (int e = beg + lane; e < end; e += 64) {
+        const float a = bf2f(a_in[(int64_t)e * H + h]);
+        out[(int64_t)e * H + h] = f2bf(a * (bf2f(x[(int64_t)e * H + h]) - t));
+      }
+    }
+  }
+}
+
+// Row sums of per-edge vectors that are never materialised:
+//   val(e, col) = coef[e, h(col)] * feat[nbr_e, col]                                   (LBWD == false: aggregation fwd / bwd)
+//   val(e, col) = de[e, h(col)] * attn[col] * lrelu'(feat[src_e, col] + feat[dst_e, col])   (LBWD == true: logits backward)
+// rows = destinations (BY_SRC == false, CSR order) or sources (BY_SRC == true, through t_edge).  Merge-style chunks of
+// 64 edges per wave; rows cut by chunk boundaries leave partials for k_gat_fixup (same scheme as csrc/spmm.hip).
+// With LBWD && !BY_SRC the kernel also accumulates d_attn[col] = sum_e de[e,h] * lrelu(x) (fp32 atomics per workgroup).
+#define GEC 64
+template <bool LBWD, bool BY_SRC>
+__global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ row_ptr, const int* __restrict__ t_edge,
+                                                     const int* __restrict__ src, const int* __restrict__ dst,
+                                                     const int* __restrict__ nnz_dev, int nnz_host,
+                                                     const bf16_t* __restrict__ coef, const bf16_t* __restrict__ feat,
+                                                     int64_t feat_stride, const bf16_t* __restrict__ attn, int H, int D,
+                                                     float slope, bf16_t* __restrict__ out, int64_t out_stride,
+                                                     float* __restrict__ part, float* __restrict__ d_attn) {
+  __shared__ float sh_attn[LBWD && !BY_SRC ? 2048 : 1];
+  const int nnz = nnz_dev ? min(*nnz_dev, nnz_host) : nnz_host;
+  const int lane = lane_id();
+  const int chunk = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
+  const int nchunks = nnz > 0 ? (nnz + GEC - 1) / GEC : 1;
+  const int HD = H * D;
+  const bool do_attn = LBWD && !BY_SRC && d_attn != nullptr;
+  if (do_attn) { for (int i = threadIdx.x; i < HD && i < 2048; i += GAT_TPB) sh_attn[i] = 0.f; __syncthreads(); }
+  if (chunk < nchunks && nnz > 0) {
+    const int c0 = chunk * GEC, c1 = min(nnz, c0 + GEC), cnt = c1 - c0;
+    int my_row = -1, my_e = 0;
+    if (lane < cnt) {
+      my_e = BY_SRC ? t_edge[c0 + lane] : c0 + lane;
+      my_row = BY_SRC ? src[my_e] : dst[my_e];
+    }
+    for (int col0 = 0; col0 < HD; col0 += 64) {
+      const int col = col0 + lane;
+      const bool act = col < HD;
+      const int hd = act ? col / D : 0;
+      const float at = (LBWD && act) ? bf2f(attn[col]) : 0.f;
+      float attn_acc = 0.f, acc = 0.f;
+      int cur = __shfl(my_row, 0);
+      auto flush = [&](int r, float v) {
+        const int rb = row_ptr[r], re = row_ptr[r + 1];
+        const bool starts = rb >= c0, ends = re <= c1;
+        if (!act) return;
+        if (starts && ends) out[r * out_stride + col] = f2bf(v);
+        else part[((int64_t)chunk * 2 + (starts ? 1 : 0)) * HD + col] = v;
+      };
+      for (int j = 0; j < cnt; ++j) {
+        const int r = __shfl(my_row, j), e = __shfl(my_e, j);
+        if (r != cur) { flush(cur, acc); acc = 0.f; cur = r; }
+        if (act) {
+          const int s_ = src[e], d_ = dst[e];
+          if (LBWD) {
+            const float x = bf2f(feat[(int64_t)s_ * feat_stride + col]) + bf2f(feat[(int64_t)d_ * feat_stride + col]);
+            const float de = bf2f(coef[(int64_t)e * H + hd]);
+            acc += de * at * (x > 0.f ? 1.f : slope);
+            if (do_attn) attn_acc += de * lrelu(x, slope);
+          } else {
+            const int nb = BY_SRC ? d_ : s_;
+            acc += bf2f(coef[(int64_t)e * H + hd]) * bf2f(feat[(int64_t)nb * feat_stride + col]);
+          }
+        }
+      }
+      flush(cur, acc);
+      if (do_attn && act && col < 2048) atomicAdd(&sh_attn[col], attn_acc);
+    }
+  }
+  if (do_attn) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HD && i < 2048; i += GAT_TPB) { const float v = sh_attn[i]; if (v != 0.f) atomicAdd(d_attn + i, v); }
+  }
+}
+
+// rows without edges -> 0; rows cut by chunk boundaries -> tail partial of their first chunk + head partials of the rest
+__global__ void __launch_bounds__(GAT_TPB) k_gat_fixup(const int* __restrict__ row_ptr, int n_rows, int HD,
+                                                      const float* __restrict__ part, bf16_t* __restrict__ out, int64_t out_stride) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int rb = row_ptr[r], re = row_ptr[r + 1];
+  if (re <= rb) { for (int col = lane; col < HD; col += 64) out[r * out_stride + col] = 0; return; }
+  const int c = rb / GEC, c_end = (re - 1) / GEC;
+  if (c_end == c) return;
+  for (int col = lane; col < HD; col += 64) {
+    float sum = part[((int64_t)c * 2 + 1) * HD + col];
+    for (int cc = c + 1; cc <= c_end; ++cc) sum += part[((int64_t)cc * 2) * HD + col];
+    out[r * out_stride + col] = f2bf(sum);
+  }
+}
+
+// calculate_alpha, model == 'gat' (bandit_sampler.py:148-154): exact per-destination sums of q_ij and a_ij (the
+// arithmetic contract of common.cuh), alpha = nan_to_num(a / sum a) * sum q.  One wave per destination.
+__global__ void __launch_bounds__(GAT_TPB) k_gat_alpha(const int* __restrict__ indptr, int n_dst, const bf16_t* __restrict__ q,
+                                                      const bf16_t* __restrict__ a, bf16_t* __restrict__ alpha, int* err) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
+  if (row >= n_dst) return;
+  const int beg = indptr[row], end = indptr[row + 1];
+  int bad = 0;
+  int64_t sq = 0, sa = 0;
+  for (int e = beg + lane; e < end; e += 64) { sq += bf_to_fixed(q[e], FRAC_DST, &bad); sa += bf_to_fixed(a[e], FRAC_DST, &bad); }
+  for (int d = 32; d >= 1; d >>= 1) {
+    int lo = __shfl_xor((int)(sq & 0xffffffffll), d), hi = __shfl_xor((int)(sq >> 32), d);
+    sq += ((int64_t)hi << 32) | (uint32_t)lo;
+    lo = __shfl_xor((int)(sa & 0xffffffffll), d); hi = __shfl_xor((int)(sa >> 32), d);
+    sa += ((int64_t)hi << 32) | (uint32_t)lo;
+  }
+  const float qsum = bf2f(fixed_to_bf(sq, FRAC_DST, &bad));       // :150 copy_e_sum(mfg, q_ij)
+  const float asum = bf2f(fixed_to_bf(sa, FRAC_DST, &bad));       // :151 copy_e_sum(mfg, attention)
+  for (int e = beg + lane; e < end; e += 64) {
+    float f = rbf(bf2f(a[e]) / asum);                             // :152 e_div_v
+    if (f != f) f = 0.f;                                          // :153 torch.nan_to_num (nan -> 0, +-inf -> +-max bf16)
+    else if (f == __builtin_inff()) f = 3.3895313892515355e38f;
+    else if (f == -__builtin_inff()) f = -3.3895313892515355e38f;
+    alpha[e] = f2bf(f * qsum);                                    // :154 e_dot_v on scalars
+  }
+  if (bad) atomicOr(err, bad);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                     int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
+                     void* stream) {
+  if (!feat || !attn || !e_out || heads <= 0 || heads > GAT_MAXH || head_dim <= 0 || nnz < 0) return BLISS_EINVAL;
+  if (nnz == 0) return 0;
+  if (!src || !dst) return BLISS_EINVAL;
+  const int chunks = (nnz + GAT_EC - 1) / GAT_EC;
+  k_gat_edge_dot<0><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0,
+                                                                        (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)e_out);
+  return (int)hipGetLastError();
+}
+
+int bliss_gat_edge_dot(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                       int64_t feat_stride, const void* g, int64_t g_stride, int32_t heads, int32_t head_dim, void* out, void* stream) {
+  if (!feat || !g || !out || heads <= 0 || heads > GAT_MAXH || head_dim <= 0 || nnz < 0) return BLISS_EINVAL;
+  if (nnz == 0) return 0;
+  if (!src || !dst) return BLISS_EINVAL;
+  const int chunks = (nnz + GAT_EC - 1) / GAT_EC;
+  k_gat_edge_dot<1><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
+                                                                        g_stride, nullptr, heads, head_dim, 0.f, (bf16_t*)out);
+  return (int)hipGetLastError();
+}
+
+int bliss_gat_edge_softmax(const int32_t* indptr, int32_t n_dst, const void* x, const void* a_or_null, int32_t heads, int backward,
+                           void* out, void* stream) {
+  if (!indptr || !x || !out || heads <= 0 || (backward && !a_or_null)) return BLISS_EINVAL;
+  if (n_dst <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (backward) k_gat_softmax<true><<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const bf16_t*)x, (const bf16_t*)a_or_null, heads, (bf16_t*)out);
+  else k_gat_softmax<false><<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const bf16_t*)x, nullptr, heads, (bf16_t*)out);
+  return (int)hipGetLastError();
+}
+
+int bliss_gat_rows(int which, const int32_t* row_ptr, int32_t n_rows, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
+                   const int32_t* nnz_dev, int32_t nnz, const void* coef, const void* feat, int64_t feat_stride, const void* attn,
+                   int32_t heads, int32_t head_dim, float negative_slope, void* out, int64_t out_stride, float* partials,
+                   float* d_attn, void* stream) {
+  if (!row_ptr || !coef || !feat || !out || heads <= 0 || heads > GAT_MAXH || head_dim <= 0 || n_rows <= 0 || nnz < 0) return BLISS_EINVAL;
+  if (nnz > 0 && (!src || !dst || !partials)) return BLISS_EINVAL;
+  if ((which & 1) && nnz > 0 && !t_edge) return BLISS_EINVAL;
+  if ((which & 2) && (!attn || heads * head_dim > 2048)) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int HD = heads * head_dim;
+  const int chunks = nnz > 0 ? (nnz + GEC - 1) / GEC : 1;
+  dim3 grid((chunks + 3) / 4), block(GAT_TPB);
+#define ARGS row_ptr, t_edge, src, dst, nnz_dev, nnz, (const bf16_t*)coef, (const bf16_t*)feat, feat_stride, (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)out, out_stride, partials, d_attn
+  switch (which) {             // bit 0: rows are sources (through t_edge); bit 1: logits backward
+    case 0: k_gat_rows<false, false><<<grid, block, 0, st>>>(ARGS); break;
+    case 1: k_gat_rows<false, true><<<grid, block, 0, st>>>(ARGS); break;
+    case 2: k_gat_rows<true, false><<<grid, block, 0, st>>>(ARGS); break;
+    case 3: k_gat_rows<true, true><<<grid, block, 0, st>>>(ARGS); break;
+    default: return BLISS_EINVAL;
+  }
+#undef ARGS
+  k_gat_fixup<<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
+  return (int)hipGetLastError();
+}
+
+int bliss_gat_alpha(const int32_t* indptr, int32_t n_dst, const void* q_ij, const void* a_ij, void* alpha_out, int32_t* err, void* stream) {
+  if (!indptr || !q_ij || !a_ij || !alpha_out || !err) return BLISS_EINVAL;
+  if (n_dst <= 0) return 0;
+  k_gat_alpha<<<(n_dst + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(indptr, n_dst, (const bf16_t*)q_ij, (const bf16_t*)a_ij, (bf16_t*)alpha_out, err);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

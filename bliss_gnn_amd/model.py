@@ -65,3 +65,35 @@ class GCN(nn.Module):
             if l < len(self.layers) - 1:
                 h = self.dropout(h)                                           # model.py:437-438
         return h
+
+
+class GATv2(nn.Module):
+    """model.py:115-234.  ``forward`` stores embed_norm (srcdata) and the head-mean pre-softmax logits ``a_ij`` (edata)
+    that the bandit's calculate_alpha consumes (model.py:211-213, 224-227)."""
+
+    def __init__(self, num_layers, in_dim, num_hidden, num_classes, heads, activation, feat_drop, attn_drop, negative_slope,
+                 residual):
+        super().__init__()
+        from .nn import GATv2Conv
+        self.num_layers, self.activation = num_layers, activation
+        self.num_hidden, self.num_classes, self.heads = num_hidden, num_classes, heads
+        mk = lambda i, o, h, res, act: GATv2Conv(i, o, h, feat_drop, attn_drop, negative_slope, res, act, bias=False,
+                                                 share_weights=True, allow_zero_in_degree=True)
+        self.gatv2_layers = nn.ModuleList()
+        if num_layers > 1:
+            self.gatv2_layers.append(mk(in_dim, num_hidden, heads[0], False, activation))                     # :141-155
+            for l in range(1, num_layers - 1):
+                self.gatv2_layers.append(mk(num_hidden * heads[l - 1], num_hidden, heads[l], residual, activation))
+            self.gatv2_layers.append(mk(num_hidden * heads[-2], num_classes, heads[-1], residual, None))       # :175-189
+        else:
+            self.gatv2_layers.append(mk(in_dim, num_classes, heads[-1], residual, None))
+
+    def forward(self, blocks, inputs):
+        h = inputs.bfloat16()
+        for l, block in enumerate(blocks):
+            block.srcdata["embed_norm"] = embed_norm(h)                                                        # :211-213
+            h, a = self.gatv2_layers[l](block, h, edge_weight=(block.edata["edge_weights"] if "edge_weights" in block.edata else None),
+                                        get_attention=True)
+            block.edata["a_ij"] = a.squeeze(-1).mean(dim=1)                                                    # :224-227
+            h = h.flatten(1) if l < len(blocks) - 1 else h.mean(1)                                             # :228-232
+        return h

@@ -148,3 +148,153 @@ class GraphConv(nn.Module):
         if self._activation is not None:
             rst = self._activation(rst)
         return rst
+
+
+# ------------------------------------------------------------------------------------------------ GATv2
+def _nnz(block):
+    return block._nnz_ptr, int(block.src.numel())
+
+
+class _GatLogits(torch.autograd.Function):
+    """e[e,h] = attn[h,:] . leaky_relu(feat[src_e,h,:] + feat[dst_e,h,:])   (model.py:82-86)."""
+
+    @staticmethod
+    def forward(ctx, feat, attn, block, H, D, slope):
+        feat, attn = feat.contiguous(), attn.reshape(-1).contiguous()
+        nnz_ptr, B = _nnz(block)
+        e = torch.empty(B, H, dtype=torch.bfloat16, device=feat.device)
+        _lib.check(_lib.lib.bliss_gat_logits(block.src.data_ptr(), block.dst.data_ptr(), nnz_ptr, B, feat.data_ptr(), feat.stride(0),
+                                             attn.data_ptr(), H, D, float(slope), e.data_ptr(), _stream()), "bliss_gat_logits")
+        ctx.save_for_backward(feat, attn)
+        ctx.block, ctx.H, ctx.D, ctx.slope = block, H, D, slope
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        feat, attn = ctx.saved_tensors
+        block, H, D, slope = ctx.block, ctx.H, ctx.D, ctx.slope
+        de = de.contiguous().bfloat16()
+        nnz_ptr, B = _nnz(block)
+        K, S, HD = feat.shape[0], block.num_dst_nodes(), H * D
+        part = torch.empty(max(2 * ((B + 63) // 64) * HD, 1), dtype=torch.float32, device=feat.device)
+        d_attn = torch.zeros(HD, dtype=torch.float32, device=feat.device)
+        d_el = torch.empty(K, HD, dtype=torch.bfloat16, device=feat.device)
+        d_er = torch.empty(S, HD, dtype=torch.bfloat16, device=feat.device)
+        t_indptr, t_edge = block.transposed()
+        for which, rp, n_rows, out, da in ((3, t_indptr, K, d_el, 0), (2, block.indptr, S, d_er, d_attn.data_ptr())):
+            _lib.check(_lib.lib.bliss_gat_rows(which, rp.data_ptr(), n_rows, t_edge.data_ptr(), block.src.data_ptr(),
+                                               block.dst.data_ptr(), nnz_ptr, B, de.data_ptr(), feat.data_ptr(), feat.stride(0),
+                                               attn.data_ptr(), H, D, float(slope), out.data_ptr(), out.stride(0),
+                                               part.data_ptr(), da, _stream()), "bliss_gat_rows")
+        d_feat = d_el
+        d_feat[:S] += d_er                                  # shared weights: the destinations are the first S source rows
+        return d_feat, d_attn.to(attn.dtype).view(1, H, D), None, None, None, None
+
+
+class _EdgeSoftmax(torch.autograd.Function):
+    """dglnn.functional.edge_softmax over the in-edges of every destination (model.py:88-90)."""
+
+    @staticmethod
+    def forward(ctx, e, block, H):
+        e = e.contiguous()
+        a = torch.empty_like(e)
+        _lib.check(_lib.lib.bliss_gat_edge_softmax(block.indptr.data_ptr(), block.num_dst_nodes(), e.data_ptr(), 0, H, 0,
+                                                   a.data_ptr(), _stream()), "bliss_gat_edge_softmax")
+        ctx.save_for_backward(a)
+        ctx.block, ctx.H = block, H
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (a,) = ctx.saved_tensors
+        da = da.contiguous().bfloat16()
+        de = torch.empty_like(a)
+        _lib.check(_lib.lib.bliss_gat_edge_softmax(ctx.block.indptr.data_ptr(), ctx.block.num_dst_nodes(), da.data_ptr(),
+                                                   a.data_ptr(), ctx.H, 1, de.data_ptr(), _stream()), "bliss_gat_edge_softmax")
+        return de, None, None
+
+
+class _GatAggregate(torch.autograd.Function):
+    """out[i,h,:] = sum_{e -> i} a[e,h] * feat[src_e,h,:]   (update_all(u_mul_e('el','a'), sum), model.py:98)."""
+
+    @staticmethod
+    def forward(ctx, a, feat, block, H, D):
+        a, feat = a.contiguous(), feat.contiguous()
+        nnz_ptr, B = _nnz(block)
+        S, HD = block.num_dst_nodes(), H * D
+        out = torch.empty(S, HD, dtype=torch.bfloat16, device=feat.device)
+        part = torch.empty(max(2 * ((B + 63) // 64) * HD, 1), dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib.bliss_gat_rows(0, block.indptr.data_ptr(), S, 0, block.src.data_ptr(), block.dst.data_ptr(), nnz_ptr, B,
+                                           a.data_ptr(), feat.data_ptr(), feat.stride(0), 0, H, D, 0.0, out.data_ptr(),
+                                           out.stride(0), part.data_ptr(), 0, _stream()), "bliss_gat_rows")
+        ctx.save_for_backward(a, feat)
+        ctx.block, ctx.H, ctx.D = block, H, D
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, feat = ctx.saved_tensors
+        block, H, D = ctx.block, ctx.H, ctx.D
+        dout = dout.contiguous().bfloat16()
+        nnz_ptr, B = _nnz(block)
+        K, HD = feat.shape[0], H * D
+        da = torch.empty(B, H, dtype=torch.bfloat16, device=feat.device)
+        _lib.check(_lib.lib.bliss_gat_edge_dot(block.src.data_ptr(), block.dst.data_ptr(), nnz_ptr, B, feat.data_ptr(), feat.stride(0),
+                                               dout.data_ptr(), dout.stride(0), H, D, da.data_ptr(), _stream()), "bliss_gat_edge_dot")
+        t_indptr, t_edge = block.transposed()
+        d_feat = torch.empty(K, HD, dtype=torch.bfloat16, device=feat.device)
+        part = torch.empty(max(2 * ((B + 63) // 64) * HD, 1), dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib.bliss_gat_rows(1, t_indptr.data_ptr(), K, t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
+                                           nnz_ptr, B, a.data_ptr(), dout.data_ptr(), dout.stride(0), 0, H, D, 0.0,
+                                           d_feat.data_ptr(), d_feat.stride(0), part.data_ptr(), 0, _stream()), "bliss_gat_rows")
+        return da, d_feat, None, None, None
+
+
+class GATv2Conv(nn.Module):
+    """The reference's ``custom_GATv2Conv`` (model.py:13-112): dglnn.GATv2Conv with the forward that returns the
+    PRE-softmax logits as "attention" (:108-110) and ignores ``edge_weight`` (:91-96 are commented out).
+
+    [DGL-recalled] parameters: fc_src Linear(in, H*D, bias), shared with fc_dst when share_weights; attn (1,H,D);
+    res_fc Linear(in, H*D, bias) when residual and in != H*D, identity when equal; xavier_normal(gain('relu'))."""
+
+    def __init__(self, in_feats, out_feats, num_heads, feat_drop=0.0, attn_drop=0.0, negative_slope=0.2, residual=False,
+                 activation=None, allow_zero_in_degree=False, bias=True, share_weights=False):
+        super().__init__()
+        if not share_weights:
+            raise NotImplementedError("the reference always builds share_weights=True (model.py:152,170,186,202)")
+        self._num_heads, self._out_feats, self._in = num_heads, out_feats, in_feats
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self.fc_src = nn.Linear(in_feats, out_feats * num_heads, bias=bias)
+        self.fc_dst = self.fc_src
+        self.attn = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.feat_drop, self.attn_drop = nn.Dropout(feat_drop), nn.Dropout(attn_drop)
+        self.negative_slope = negative_slope
+        if residual:
+            self.res_fc = nn.Linear(in_feats, num_heads * out_feats, bias=bias) if in_feats != out_feats * num_heads else nn.Identity()
+        else:
+            self.res_fc = None
+        self.activation = activation
+        self.share_weights = share_weights
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc_src.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn, gain=gain)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+        if bias:
+            nn.init.constant_(self.fc_src.bias, 0)
+
+    def forward(self, graph, feat, edge_weight=None, get_attention=False):
+        H, D, S = self._num_heads, self._out_feats, graph.num_dst_nodes()
+        if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
+            raise RuntimeError("There are 0-in-degree nodes in the graph (model.py:49-61); build the layer with "
+                               "allow_zero_in_degree=True or add self loops")
+        h_src = self.feat_drop(feat)
+        feat_src = self.fc_src(h_src)                                            # :66-72, [K, H*D]; feat_dst = feat_src[:S]
+        e = _GatLogits.apply(feat_src, self.attn, graph, H, D, self.negative_slope)           # :82-86
+        a = self.attn_drop(_EdgeSoftmax.apply(e, graph, H))                      # :88-90
+        rst = _GatAggregate.apply(a, feat_src, graph, H, D).view(S, H, D)        # :98-99
+        if self.res_fc is not None:
+            rst = rst + self.res_fc(h_src[:S]).view(S, -1, D)                    # :101-103
+        if self.activation:
+            rst = self.activation(rst)
+        return (rst, e.view(-1, H, 1)) if get_attention else rst                 # :108-112

@@ -200,6 +200,33 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
 /* Exact row sum from scratch (initialisation / verification): row_sum int64[3]. */
 int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream);
 
+/* ---- GATv2 attention path (custom_GATv2Conv.forward, model.py:48-112) ------------------------------------------
+ * feat: bf16 [n_src, heads*head_dim] = fc_src(h) (shared weights: the destinations are its first n_dst rows);
+ * edge arrays src/dst [nnz] of the block (CSR order); nnz_dev optional as for bliss_spmm_fwd.
+ *   bliss_gat_logits        e[e,h] = attn[h,:] . leaky_relu(feat[src_e,h,:] + feat[dst_e,h,:])   -> bf16 [nnz, heads]  (:82-86)
+ *   bliss_gat_edge_softmax  a = softmax of x over the in-edges of every destination (:88-90), or with backward != 0
+ *                           de = a * (x - sum_{e'} a x) where x = d_a
+ *   bliss_gat_rows          row sums of per-edge vectors, never materialised.  which bit 0: rows are sources (through
+ *                           t_edge, the by-source index) instead of destinations; bit 1: the vector is the logits
+ *                           backward  coef[e,h]*attn[col]*lrelu'(feat[src]+feat[dst])  instead of  coef[e,h]*feat[nbr,col]
+ *                           (which = 0 is the forward aggregation of :98, 1 its backward w.r.t. feat, 2 / 3 the two halves of
+ *                           the logits backward; with which = 2 and d_attn != NULL also d_attn[col] += sum_e coef*lrelu(x)).
+ *                           partials: fp32 [2 * ceil(nnz/64) * heads*head_dim].
+ *   bliss_gat_edge_dot      out[e,h] = g[dst_e,h,:] . feat[src_e,h,:]   (d_a of the aggregation)
+ *   bliss_gat_alpha         calculate_alpha, model == 'gat' (bandit_sampler.py:146-154), exact sums, bf16 [nnz]. */
+int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                     int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
+                     void* stream);
+int bliss_gat_edge_dot(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                       int64_t feat_stride, const void* g, int64_t g_stride, int32_t heads, int32_t head_dim, void* out, void* stream);
+int bliss_gat_edge_softmax(const int32_t* indptr, int32_t n_dst, const void* x, const void* a_or_null, int32_t heads, int backward,
+                           void* out, void* stream);
+int bliss_gat_rows(int which, const int32_t* row_ptr, int32_t n_rows, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
+                   const int32_t* nnz_dev, int32_t nnz, const void* coef, const void* feat, int64_t feat_stride, const void* attn,
+                   int32_t heads, int32_t head_dim, float negative_slope, void* out, int64_t out_stride, float* partials,
+                   float* d_attn, void* stream);
+int bliss_gat_alpha(const int32_t* indptr, int32_t n_dst, const void* q_ij, const void* a_ij, void* alpha_out, int32_t* err, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launching stream (bench.py's roofline object).
  * bliss_prof_enable(id): -2 off (default), -1 every kernel, >= 0 one kernel id; names via
  * bliss_prof_kernel_name(id), id < bliss_prof_kernel_count().  bliss_prof_read synchronises on the

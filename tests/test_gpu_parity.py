@@ -502,3 +502,122 @@ def test_gcn_layer_vs_fp32(cuda):
         agg = lambda z: torch.zeros(S, z.shape[1]).index_add_(0, dst, z[src] * w[:, None])
         ref = (agg(x @ W) if fin > fout else agg(x) @ W) * idg[:, None] + layer.bias.float().cpu()
         assert (out - ref).abs().max() <= 4 * ref.abs().max() * 2 ** -8
+
+
+def _gat_ref(blk_src, blk_dst, S, h, W, attn, H, D, slope, res_W=None):
+    """fp32 restatement of custom_GATv2Conv.forward (model.py:63-112, share_weights, bias=False)."""
+    fs = (h @ W.t()).view(-1, H, D)
+    x = torch.nn.functional.leaky_relu(fs[blk_src] + fs[blk_dst], slope)
+    e = (x * attn.view(1, H, D)).sum(-1)                                                  # [B, H]
+    m = torch.full((S, H), -float("inf")).scatter_reduce(0, blk_dst[:, None].expand(-1, H), e, "amax")
+    ex = torch.exp(e - m[blk_dst])
+    a = ex / torch.zeros(S, H).index_add_(0, blk_dst, ex)[blk_dst]
+    out = torch.zeros(S, H, D).index_add_(0, blk_dst, a[:, :, None] * fs[blk_src])
+    if res_W is not None:
+        out = out + (h[:S] @ res_W.t()).view(S, H, D)
+    return out, e
+
+
+def test_gatv2_layer_forward_backward_vs_fp32(cuda):
+    """a19: logits, edge softmax, aggregation and all three backward passes against fp32 autograd of the same formulas
+    (bf16 storage: a few bf16 ulps of the tensor scale)."""
+    from bliss_gnn_amd.nn import GATv2Conv
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(3000, 50000, seed=41)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    sampler = bg.PoissonBanditLadiesSampler([300], eta=0.1)
+    torch.manual_seed(1)
+    _, _, (blk,) = sampler.sample_blocks(g, torch.arange(60, dtype=torch.int32, device=cuda))
+    K, S = blk.num_src_nodes(), blk.num_dst_nodes()
+    src, dst = blk.src.cpu().long(), blk.dst.cpu().long()
+    for (fin, H, D, residual) in ((40, 4, 16, False), (64, 4, 16, True), (64, 1, 7, True)):
+        torch.manual_seed(5)
+        layer = GATv2Conv(fin, D, H, 0.0, 0.0, 0.2, residual, None, bias=False, share_weights=True, allow_zero_in_degree=True)
+        layer = layer.to(cuda).bfloat16()
+        h = (torch.randn(K, fin, generator=torch.Generator().manual_seed(6)) * 0.5).bfloat16()
+        hd = h.to(cuda).requires_grad_(True)
+        out, e = layer(blk, hd, get_attention=True)
+        W = layer.fc_src.weight.detach().float().cpu().requires_grad_(True)
+        at = layer.attn.detach().float().cpu().requires_grad_(True)
+        hr = h.float().requires_grad_(True)
+        rW = None
+        if isinstance(layer.res_fc, torch.nn.Linear):
+            rW = layer.res_fc.weight.detach().float().cpu().requires_grad_(True)
+        ref_out, ref_e = _gat_ref(src, dst, S, hr, W, at, H, D, 0.2, rW)
+        if residual and rW is None:                      # identity residual (in == H*D)
+            ref_out = ref_out + hr[:S].view(S, H, D)
+        tol = lambda t: 6 * t.abs().max() * 2 ** -8
+        assert (e.float().cpu().view(-1, H) - ref_e).abs().max() <= tol(ref_e)
+        assert (out.float().cpu() - ref_out).abs().max() <= tol(ref_out)
+        gout = torch.randn(S, H, D, generator=torch.Generator().manual_seed(7)).bfloat16()
+        (out * gout.to(cuda)).float().sum().backward()
+        (ref_out * gout.float()).sum().backward()
+        assert (hd.grad.float().cpu() - hr.grad).abs().max() <= 3 * tol(hr.grad)
+        assert (layer.fc_src.weight.grad.float().cpu() - W.grad).abs().max() <= 3 * tol(W.grad)
+        assert (layer.attn.grad.float().cpu().view(-1) - at.grad.view(-1)).abs().max() <= 3 * tol(at.grad)
+
+
+def test_gat_alpha_and_exp3_match_oracle(cuda):
+    """a13 GAT branch: calculate_alpha with a_ij (possibly negative, zero-sum -> nan_to_num) is bit-exact vs the oracle,
+    and the resulting EXP3 update too."""
+    from oracle import bliss_oracle as bo
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(3000, 50000, seed=43)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    g.edata["w"] = bg.normalized_edata(g)
+    og = bo.CSC(ip, ix, ei)
+    edge_w = bo.normalized_edata(og)
+    s = bg.PoissonBanditLadiesSampler([200, 100], eta=0.1, model="gat")
+    o_w = torch.ones(2, og.num_edges, dtype=torch.bfloat16)
+    gen = torch.Generator().manual_seed(8)
+    for step in range(2):
+        seeds = torch.arange(30 * step, 30 * step + 40, dtype=torch.int32)
+        torch.manual_seed(step)
+        _, _, blocks = s.sample_blocks(g, seeds.to(cuda))
+        torch.manual_seed(step)
+        _, _, o_blocks = bo.sample_blocks_bandit(og, seeds, [200, 100], o_w, 0.1)
+        en, aij = [], []
+        for b, ob in zip(blocks, o_blocks):
+            e_ = (torch.rand(ob.n_src, generator=gen) * 20).bfloat16()
+            a_ = (torch.randn(ob.src.numel(), generator=gen)).bfloat16()
+            a_[ob.indptr[0]:ob.indptr[1]] = 0                        # a destination whose logits sum to zero
+            b.srcdata["embed_norm"], b.edata["a_ij"] = e_.to(cuda), a_.to(cuda)
+            en.append(e_); aij.append(a_)
+        s.exp3(blocks, g)
+        o_w, traces = bo.exp3(og, o_blocks, o_w, edge_w, en, a_ij=aij)
+        for b, tr in zip(blocks, traces):
+            assert torch.equal(b.edata["rewards"].cpu().view(torch.int16), tr["rewards"].view(torch.int16))
+        assert torch.equal(s.exp3_weights.cpu().view(torch.int16), o_w.view(torch.int16))
+
+
+def test_gatv2_model_train_step(cuda):
+    """Config 4 in miniature: GATv2 (heads 4,4,1) forward/backward on sampled blocks, bandit update with model='gat'."""
+    from bliss_gnn_amd.model import GATv2
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(4000, 60000, seed=45)
+    feats = torch.randn(4000, 48, generator=torch.Generator().manual_seed(1)).bfloat16()
+    labels = torch.randint(0, 6, (4000,), generator=torch.Generator().manual_seed(2))
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+    g.edata["w"] = bg.normalized_edata(g)
+    s = bg.PoissonBanditLadiesSampler([300, 150, 80], eta=0.1, model="gat")
+    torch.manual_seed(0)
+    model = GATv2(3, 48, 16, 6, [4, 4, 1], torch.nn.functional.elu, 0.1, 0.1, 0.2, True).to(cuda).bfloat16()
+    opt = torch.optim.Adam(model.parameters(), lr=0.002)
+    losses = []
+    for step in range(4):
+        torch.manual_seed(step)
+        inp, outp, blocks = s.sample_blocks(g, torch.arange(64, dtype=torch.int32, device=cuda))
+        pred = model(blocks, blocks[0].srcdata["features"])
+        assert pred.shape == (64, 6)
+        loss = torch.nn.functional.cross_entropy(pred, blocks[-1].dstdata["labels"])
+        opt.zero_grad(); loss.backward(); opt.step()
+        assert all(torch.isfinite(p.grad.float()).all() for p in model.parameters() if p.grad is not None)
+        for b in blocks:
+            assert b.edata["a_ij"].shape[0] == b.num_edges() and b.srcdata["embed_norm"].shape[0] == b.num_src_nodes()
+        s.exp3(blocks, g)
+        s.check_errors()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]                                    # same batch every step: the loss must go down
