@@ -178,6 +178,99 @@ class LayerEngine:
             self._commit_rng(snapshot)
         return self._finish(out, cnts)
 
+    # ------------------------------------------------------------------ non-Poisson samplers (multinomial draw)
+    def sample_blocks_multinomial(self, w_rows, seeds, fanouts, mode, eta, replace=False):
+        """BanditLadiesSampler / LadiesSampler (bandit_sampler.py:84-99, ladies_sampler.py:54-69): the node importances
+        are computed on the device; the draw is ``torch.multinomial`` itself, on the host, on those bits (ATen's CPU
+        kernel takes its exponentials from an MKL stream seeded by the global generator -- there is nothing to restate),
+        so this path syncs once per layer like the reference does."""
+        seeds = seeds.to(torch.int32).contiguous()
+        L = len(fanouts)
+        self._ensure(int(seeds.numel()), fanouts)
+        # a multinomial draw keeps min(num, C) nodes plus the seeds: make room
+        for n in range(L):
+            need = min(self.V, fanouts[n] + self.caps[n]["S"] + 64)
+            if self.caps[n]["K"] < need:
+                self.caps[n]["K"] = need
+            if n + 1 < L and self.caps[n + 1]["S"] < self.caps[n]["K"]:
+                self.caps[n + 1]["S"] = self.caps[n]["K"]
+                self.ws = None
+        self._ensure(int(seeds.numel()), fanouts)
+        while True:
+            dev, st = self.g.device, _stream()
+            counts = torch.empty(L * 10, dtype=torch.int32, device=dev)
+            eta_f, ome_f = float(np.float32(eta)), float(np.float32(1.0 - eta))
+            layers, state = [], (seeds, int(seeds.numel()), 0)
+            for n in range(L):
+                cur_seeds, n_seeds, n_seeds_dev = state
+                c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts)
+                w_pos = w_rows[n]
+                _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
+                                                        cur_seeds.data_ptr(), n_seeds, n_seeds_dev, self.caps[n]["S"], mode,
+                                                        eta_f, ome_f, self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
+                self.counts_host.copy_(counts, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                Cn = int(self.counts_host[10 * n + 2])
+                prob = self.ws[n].p[:Cn].cpu()
+                chosen = torch.multinomial(prob, min(int(fanouts[n]), Cn), replacement=replace)        # bandit_sampler.py:98
+                chosen_dev = chosen.to(torch.int32).to(dev)
+                _lib.check(_lib.lib.bliss_multinomial_select(C.byref(c_ws), chosen_dev.data_ptr(), int(chosen_dev.numel()), st),
+                           "bliss_multinomial_select")
+                _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
+                                                      cur_seeds.data_ptr(), self.caps[n]["S"], mode, eta_f, ome_f, self.Eg,
+                                                      C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
+                layers.append(lay)
+                state = (kept_nid, -1, cnt_ptr + 12)
+            self.counts_host.copy_(counts, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            raw = self.counts_host.numpy().tobytes()
+            cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
+            bad = 0
+            for c in cnts:
+                bad |= c.err
+            if bad & ~_CAP_ERRS or bad & 2:
+                raise RuntimeError(f"sampler kernel error 0x{bad:x}: {_lib.err_string(bad)}")
+            if bad == 0:
+                return self._finish((counts, layers), cnts)
+            self._grow([c.err for c in cnts])
+            self._ensure(int(seeds.numel()), fanouts)
+
+    def _layer_buffers(self, n, counts):
+        """Caller-owned outputs of layer n (one int32 and one bf16 allocation, sliced) + the C descriptors."""
+        dev = self.g.device
+        cap, ws = self.caps[n], self.ws[n]
+        cs, ck, cb = cap["S"], cap["K"], cap["B"]
+        build_t = cs <= 32768                     # by-source index built by the sampler kernels themselves
+        if ws.src_cnt is None or ws.src_cnt.numel() < ck + 1:
+            ws.src_cnt = torch.empty(ck + 1, dtype=torch.int32, device=dev)
+        ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck) + (2 * _up8(cb) + _up8(ck + 1) if build_t else 0),
+                           dtype=torch.int32, device=dev)
+        hbuf = torch.empty(2 * _up8(cb) + _up8(ck), dtype=torch.bfloat16, device=dev)
+        o = 0
+        b_indptr = ibuf[o:o + cs + 1]; o += _up8(cs + 1)
+        b_src = ibuf[o:o + cb]; o += _up8(cb)
+        b_dst = ibuf[o:o + cb]; o += _up8(cb)
+        b_pos = ibuf[o:o + cb]; o += _up8(cb)
+        b_eid = ibuf[o:o + cb]; o += _up8(cb)
+        kept_nid = ibuf[o:o + ck]; o += _up8(ck)
+        t_indptr = t_edge = t_scr = None
+        if build_t:
+            t_indptr = ibuf[o:o + ck + 1]; o += _up8(ck + 1)
+            t_edge = ibuf[o:o + cb]; o += _up8(cb)
+            t_scr = ibuf[o:o + cb]
+        b_w = hbuf[0:cb]
+        b_q = hbuf[_up8(cb):_up8(cb) + cb]
+        node_prob = hbuf[2 * _up8(cb):2 * _up8(cb) + ck]
+        cnt_ptr = counts.data_ptr() + 40 * n
+        c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
+                            ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
+                            kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
+                            ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
+        c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
+                              b_w.data_ptr(), b_q.data_ptr(), _ptr(t_indptr), _ptr(t_edge), _ptr(t_scr), cb)
+        lay = (b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10], t_indptr, t_edge)
+        return c_ws, c_out, lay, cnt_ptr, kept_nid
+
     # ------------------------------------------------------------------ static-shape (graph-capturable) variant
     def set_static_caps(self, S0, fanouts, max_sizes, k_margin=1.5, b_margin=3.0):
         """Fix the capacities from sizes observed in exact mode (``max_sizes[n] = dict(K=, B=)`` in sampling
@@ -253,35 +346,9 @@ class LayerEngine:
         layers = []
         cur_seeds, n_seeds, n_seeds_dev = seeds, int(seeds.numel()), 0
         for n in range(L):
-            cap, ws = self.caps[n], self.ws[n]
-            cs, ck, cb = cap["S"], cap["K"], cap["B"]
-            # caller-owned outputs: one int32 and one bf16 allocation per layer, sliced
-            build_t = cs <= 32768                     # by-source index built by the sampler kernels themselves
-            if ws.src_cnt is None or ws.src_cnt.numel() < ck + 1:
-                ws.src_cnt = torch.empty(ck + 1, dtype=torch.int32, device=dev)
-            ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck) + (2 * _up8(cb) + _up8(ck + 1) if build_t else 0),
-                               dtype=torch.int32, device=dev)
-            hbuf = torch.empty(2 * _up8(cb) + _up8(ck), dtype=torch.bfloat16, device=dev)
-            o = 0
-            b_indptr = ibuf[o:o + cs + 1]; o += _up8(cs + 1)
-            b_src = ibuf[o:o + cb]; o += _up8(cb)
-            b_dst = ibuf[o:o + cb]; o += _up8(cb)
-            b_pos = ibuf[o:o + cb]; o += _up8(cb)
-            b_eid = ibuf[o:o + cb]; o += _up8(cb)
-            kept_nid = ibuf[o:o + ck]; o += _up8(ck)
-            t_indptr = t_edge = t_scr = None
-            if build_t:
-                t_indptr = ibuf[o:o + ck + 1]; o += _up8(ck + 1)
-                t_edge = ibuf[o:o + cb]; o += _up8(cb)
-                t_scr = ibuf[o:o + cb]
-            b_w = hbuf[0:cb]
-            b_q = hbuf[_up8(cb):_up8(cb) + cb]
-            node_prob = hbuf[2 * _up8(cb):2 * _up8(cb) + ck]
-            cnt_ptr = counts.data_ptr() + 40 * n
-            c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
-                                ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
-                                kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
-                                ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
+            cap = self.caps[n]
+            cs, ws = cap["S"], self.ws[n]
+            c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts)
             w_pos = w_rows[n]
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
@@ -297,13 +364,10 @@ class LayerEngine:
                 ws.uniforms[:m].copy_(u[:m])
                 _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
                                                          0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
-            c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
-                                  b_w.data_ptr(), b_q.data_ptr(), _ptr(t_indptr), _ptr(t_edge), _ptr(t_scr), cb)
             _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                   cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, self.Eg, C.byref(c_ws),
                                                   C.byref(c_out), st), "bliss_build_block")
-            layers.append((b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10],
-                           t_indptr, t_edge))
+            layers.append(lay)
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
         if use_rng:      # join; mt_dev = generator state after exactly sum(C) draws
             _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),

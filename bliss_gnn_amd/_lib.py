@@ -61,6 +61,7 @@ SIGNATURES = {
     "bliss_rng_stream_end": [_P, _P, _P, _I32, _P, _P],
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
+    "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],
     "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],
     "bliss_normalized_edata": [C.POINTER(Graph), _P, _P],
     "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],

@@ -53,8 +53,8 @@ class BlockSampler:
 
 
 class BanditLadiesSampler(BlockSampler):
-    """bandit_sampler.py:29-367.  Multinomial selection (``select_neighbors`` :84-99) is not built yet;
-    use the Poisson subclass."""
+    """bandit_sampler.py:29-367.  ``select_neighbors`` (:84-99) is ``torch.multinomial`` on the device-computed
+    importances, drawn on the host (one sync per layer, like the reference)."""
 
     _poisson = False
 
@@ -125,15 +125,15 @@ class BanditLadiesSampler(BlockSampler):
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """bandit_sampler.py:341-367.  ``uniforms``: optional list (sampling order, last layer first)
         of fp32 vectors used instead of the global CPU generator."""
-        if not self._poisson:
-            raise NotImplementedError("multinomial selection (bandit_sampler.py:84-99) lands with SURVEY 8f rank 4; "
-                                      "use PoissonBanditLadiesSampler")
         eng = self._bind(g)
         self._ensure_weights(g)
         output_nodes = seed_nodes
         order = list(reversed(range(len(self.nodes_per_layer))))          # :350
-        blks = eng.sample_blocks([self._w_pos[b] for b in order], seed_nodes, [self.nodes_per_layer[b] for b in order],
-                                 _lib.MODE_BANDIT, self.eta, self.eps, uniforms)
+        rows, fan = [self._w_pos[b] for b in order], [self.nodes_per_layer[b] for b in order]
+        if self._poisson:
+            blks = eng.sample_blocks(rows, seed_nodes, fan, _lib.MODE_BANDIT, self.eta, self.eps, uniforms)
+        else:                                                             # select_neighbors :84-99 (torch.multinomial)
+            blks = eng.sample_blocks_multinomial(rows, seed_nodes, fan, _lib.MODE_BANDIT, self.eta, self.replace)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights           # :324

@@ -441,6 +441,62 @@ __global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ 
   for (int r = K + blockIdx.x * TPB + threadIdx.x; r < cap_k; r += gridDim.x * TPB) { kept_nid[r] = 0; node_prob[r] = 0x3f80; }
 }
 
+// ---------------------------------------------------------------- multinomial variants (BanditLadiesSampler / LadiesSampler)
+// select_neighbors draws `chosen` with torch.multinomial (bandit_sampler.py:98); generate_block then keeps
+// u_nodes = union(chosen, seeds) as block sources but only edges whose SOURCE was drawn (:287-298), and uses the
+// unscaled importance as P (:309).  new_id: rank in u_nodes for drawn nodes, -2 - rank for undrawn seeds, -1 otherwise.
+__global__ void __launch_bounds__(TPB) k_mn_prepare(LayerCounts* cnt, const bf16_t* __restrict__ p, bf16_t* __restrict__ P,
+                                                    int* __restrict__ new_id, int cap_c) {
+  const int C = min(cnt->C, cap_c);
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < C; j += gridDim.x * TPB) { P[j] = p[j]; new_id[j] = 0; }
+}
+__global__ void __launch_bounds__(TPB) k_mn_mark(LayerCounts* cnt, const int* __restrict__ chosen, int n_chosen, int* __restrict__ new_id, int cap_c) {
+  const int C = min(cnt->C, cap_c);
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n_chosen; i += gridDim.x * TPB) {
+    const int j = chosen[i];
+    if (j >= 0 && j < C) new_id[j] = 1; else atomicOr(&cnt->err, BLISS_ERR_CAP_CAND);
+  }
+}
+template <bool EMIT>
+__global__ void __launch_bounds__(TPB) k_mn_select(LayerCounts* cnt, const bf16_t* __restrict__ P, int* __restrict__ chunk_io,
+                                                   const int* __restrict__ cand_nid, int* __restrict__ new_id,
+                                                   int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob, int cap_c, int cap_k) {
+  __shared__ int sh4[TPB / 64];
+  const int S = cnt->S, C = min(cnt->C, cap_c);
+  const int nchunks = (C + CHUNK - 1) / CHUNK;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    unsigned long long mask[ITEMS];
+    int drawn[ITEMS];
+    int wave_total = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
+      drawn[i] = j < C ? (EMIT ? new_id[j] : new_id[j] == 1) : 0;
+      mask[i] = __ballot(j < C && (drawn[i] == 1 || j < S));              // member of u_nodes
+      wave_total += __popcll(mask[i]);
+    }
+    int tot;
+    const int woff = chunk_wave_offset(wave_total, sh4, &tot);
+    if (!EMIT) { if (threadIdx.x == 0) chunk_io[chunk] = tot; continue; }
+    int run = chunk_io[chunk] + woff;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
+      if (j < C) {
+        const bool in_u = (mask[i] >> lane_id()) & 1ull;
+        const int r = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
+        if (in_u && r < cap_k) { kept_nid[r] = cand_nid[j]; node_prob[r] = P[j]; new_id[j] = drawn[i] == 1 ? r : -2 - r; }
+        else new_id[j] = -1;
+      }
+      run += __popcll(mask[i]);
+    }
+  }
+  if (EMIT) {
+    const int K = min(cnt->K, cap_k);
+    for (int r = K + blockIdx.x * TPB + threadIdx.x; r < cap_k; r += gridDim.x * TPB) { kept_nid[r] = 0; node_prob[r] = 0x3f80; }
+  }
+}
+
 // ---------------------------------------------------------------- K_l: kept in-degree, sum of q/P per destination
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
@@ -732,6 +788,19 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
   PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, uniforms_offset_dev, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
                                      ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k));
+  return (int)hipGetLastError();
+}
+
+int bliss_multinomial_select(const bliss_layer_ws_t* ws, const int32_t* chosen, int32_t n_chosen, void* stream_) {
+  if (!ws || n_chosen < 0 || (n_chosen > 0 && !chosen)) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  LayerCounts* cnt = (LayerCounts*)ws->counts;
+  const int gc = grid_for(ws->cap_c, CHUNK), ge = grid_for(ws->cap_c, TPB);
+  k_mn_prepare<<<ge, TPB, 0, st>>>(cnt, (const bf16_t*)ws->p, (bf16_t*)ws->P, ws->new_id, ws->cap_c);
+  if (n_chosen > 0) k_mn_mark<<<grid_for(n_chosen, TPB), TPB, 0, st>>>(cnt, chosen, n_chosen, ws->new_id, ws->cap_c);
+  k_mn_select<false><<<gc, TPB, 0, st>>>(cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k);
+  k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k);
+  k_mn_select<true><<<gc, TPB, 0, st>>>(cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k);
   return (int)hipGetLastError();
 }
 

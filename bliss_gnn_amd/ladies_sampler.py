@@ -11,7 +11,7 @@ from .graph import NID
 
 
 class LadiesSampler(BlockSampler):
-    """ladies_sampler.py:24-123.  Multinomial selection (:54-69) is not built yet; use the Poisson subclass."""
+    """ladies_sampler.py:24-123.  ``select_neighbors`` (:54-69) = ``torch.multinomial`` on the device-computed importances."""
 
     _poisson = False
 
@@ -31,16 +31,16 @@ class LadiesSampler(BlockSampler):
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """ladies_sampler.py:109-123."""
-        if not self._poisson:
-            raise NotImplementedError("multinomial selection (ladies_sampler.py:54-69) lands with SURVEY 8f rank 4; "
-                                      "use PoissonLadiesSampler")
         if self._engine is None or self._engine.g is not g:
             self._engine = LayerEngine(g)
         w_pos = g.edata_by_position(self.edge_weight)                    # :114
         output_nodes = seed_nodes
         order = list(reversed(range(len(self.nodes_per_layer))))         # :112
-        blks = self._engine.sample_blocks([w_pos] * len(order), seed_nodes, [self.nodes_per_layer[b] for b in order],
-                                          _lib.MODE_LADIES, 0.0, self.eps, uniforms)
+        fan = [self.nodes_per_layer[b] for b in order]
+        if self._poisson:
+            blks = self._engine.sample_blocks([w_pos] * len(order), seed_nodes, fan, _lib.MODE_LADIES, 0.0, self.eps, uniforms)
+        else:                                                            # select_neighbors :54-69 (torch.multinomial)
+            blks = self._engine.sample_blocks_multinomial([w_pos] * len(order), seed_nodes, fan, _lib.MODE_LADIES, 0.0, self.replace)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights            # :100

@@ -116,6 +116,12 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
                          int32_t* uniforms_offset_dev, int32_t* rng_ctl, int is_last, int32_t rng_cap_total,
                          int64_t cand_bound, void* stream);
 
+/* The non-Poisson samplers: `chosen` [n_chosen] = candidate-local ids drawn by select_neighbors
+ * (torch.multinomial(prob, min(num, C)), bandit_sampler.py:98 / ladies_sampler.py:68 -- its random stream is MKL's
+ * inside ATen's CPU kernel, so the draw itself stays with torch on the host, on the device-computed ws->p).  Marks
+ * union(chosen, seeds) as block sources, only drawn nodes as edge sources (bandit_sampler.py:287-298), P = p (:309). */
+int bliss_multinomial_select(const bliss_layer_ws_t* ws, const int32_t* chosen, int32_t n_chosen, void* stream);
+
 /* generate_block      bandit_sampler.py:269-339 (BANDIT: Hajek weights) / ladies_sampler.py:71-107.
  * Same g, maps, w_pos, seeds, eta as the matching bliss_frontier_prob call.  Out: counts{B}, the block;
  * leaves the node maps clean. */

@@ -621,3 +621,29 @@ def test_gatv2_model_train_step(cuda):
         s.check_errors()
         losses.append(float(loss))
     assert losses[-1] < losses[0]                                    # same batch every step: the loss must go down
+
+
+@pytest.mark.parametrize("name", golden_cases("multinomial"))
+def test_multinomial_samplers_golden(cuda, name):
+    """a9: BanditLadiesSampler / LadiesSampler (torch.multinomial draw) == the reference run, incl. EXP3 for the bandit."""
+    bg = _bg()
+    z = load_golden(name)
+    g, _ = _graphs(z, cuda)
+    fan, seed = z["fanouts"].tolist(), int(z["torch_seed"])
+    if "bandit" in name:
+        sampler = bg.BanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=1000, eta=float(z["eta"]),
+                                         model="sage")
+        for step in range(int(z["n_steps"])):
+            torch.manual_seed(seed + step)
+            inp, _, blocks = sampler.sample_blocks(g, torch.from_numpy(z[f"s{step}_seeds"]).to(cuda))
+            for l, blk in enumerate(blocks):
+                _check_block(z, f"s{step}_l{l}_", blk, True)
+                blk.srcdata["embed_norm"] = bits_to_bf16(z[f"s{step}_l{l}_embed_norm"]).to(cuda)
+            sampler.exp3(blocks, g)
+            assert np.array_equal(z[f"s{step}_exp3_weights"], bf16_bits(sampler.exp3_weights))
+    else:
+        sampler = bg.LadiesSampler(fan)
+        torch.manual_seed(seed)
+        _, _, blocks = sampler.sample_blocks(g, torch.from_numpy(z["seeds"]).to(cuda))
+        for l, blk in enumerate(blocks):
+            _check_block(z, f"l{l}_", blk, False)
