@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbliss_gnn.so")
 
 EINVAL = -1
-MODE_BANDIT, MODE_LADIES = 0, 1
+MODE_BANDIT, MODE_LADIES, MODE_UNIFORM_NODES = 0, 1, 4
 
 ERR_BITS = {
     1: "frontier larger than 2^31-1 edges",

@@ -78,8 +78,9 @@ class BanditLadiesSampler(BlockSampler):
         self._w_pos = None                     # exp3 weights [L, |E|] bf16 in CSC-position order
         self._row_sum = None                   # exact row sums, int64 [L, 3]
         self._engine = None
-        if not importance_sampling:
-            raise NotImplementedError("importance_sampling=False (bandit_sampler.py:77-81) is not built yet")
+
+    def _mode(self):
+        return _lib.MODE_BANDIT | (0 if self.importance_sampling else _lib.MODE_UNIFORM_NODES)
 
     # -- state ------------------------------------------------------------------------------
     def _bind(self, g):
@@ -131,9 +132,9 @@ class BanditLadiesSampler(BlockSampler):
         order = list(reversed(range(len(self.nodes_per_layer))))          # :350
         rows, fan = [self._w_pos[b] for b in order], [self.nodes_per_layer[b] for b in order]
         if self._poisson:
-            blks = eng.sample_blocks(rows, seed_nodes, fan, _lib.MODE_BANDIT, self.eta, self.eps, uniforms)
+            blks = eng.sample_blocks(rows, seed_nodes, fan, self._mode(), self.eta, self.eps, uniforms)
         else:                                                             # select_neighbors :84-99 (torch.multinomial)
-            blks = eng.sample_blocks_multinomial(rows, seed_nodes, fan, _lib.MODE_BANDIT, self.eta, self.replace)
+            blks = eng.sample_blocks_multinomial(rows, seed_nodes, fan, self._mode(), self.eta, self.replace)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights           # :324
@@ -152,7 +153,7 @@ class BanditLadiesSampler(BlockSampler):
         self._ensure_weights(g)
         order = list(reversed(range(len(self.nodes_per_layer))))
         blks = eng.enqueue_static([self._w_pos[b] for b in order], seed_nodes, [self.nodes_per_layer[b] for b in order],
-                                  _lib.MODE_BANDIT, self.eta, self.eps)
+                                  self._mode(), self.eta, self.eps)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights

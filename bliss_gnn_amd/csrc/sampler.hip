@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
                                                         const unsigned long long* __restrict__ acc_q,
                                                         const int* __restrict__ chunk_off, int* local_id,
                                                         int* __restrict__ cand_nid, unsigned long long* acc_p2,
-                                                        float eta_f, float ome_f, int cap_c) {
+                                                        float eta_f, float ome_f, int cap_c, int uniform_nodes) {
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -241,8 +241,10 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
       if (a.k >= 0) {
         srcs[i] = a.src;
         first = first_pos[a.src] == (unsigned)e;
-        bf16_t t;
-        if (BANDIT) {
+        bf16_t t = 0;
+        if (uniform_nodes) {                            // importance_sampling=False (:77-81): only "has an out-edge" matters
+          acc_p2[a.src] = 1ull;
+        } else if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
           bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           bf16_t qsum = fixed_to_bf((int64_t)acc_q[a.k], FRAC_DST, &bad);
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
           float x = bf2f(w[a.pos]);                     // ladies_sampler.py:46-47  weight ** 2
           t = f2bf(x * x);
         }
-        int64_t fx = bf_to_fixed(t, FRAC_SRC, &bad);
+        int64_t fx = uniform_nodes ? 0 : bf_to_fixed(t, FRAC_SRC, &bad);
         if (fx) atomicAdd(acc_p2 + a.src, (unsigned long long)fx);   // :73 copy_e_sum by SOURCE
       }
       mask[i] = __ballot(first);
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
 #define FIN_TPB 512
 __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
                                                            unsigned long long* acc_p2, unsigned* first_pos,
-                                                           bf16_t* __restrict__ p, int* hist, int cap_c) {
+                                                           bf16_t* __restrict__ p, int* hist, int cap_c, int uniform_nodes) {
   __shared__ int lh[HIST_BINS];                       // 128 KiB static LDS (one workgroup per CU; gfx950 has 160 KiB)
   const int S = cnt->S;
   const int C = min(cnt->C, cap_c);
@@ -291,10 +293,12 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
   for (int id = blockIdx.x * FIN_TPB + threadIdx.x; id < C; id += gridDim.x * FIN_TPB) {
     int g;
     if (id < S) { g = seeds[id]; cand_nid[id] = g; } else g = cand_nid[id];
-    bf16_t p2 = fixed_to_bf((int64_t)acc_p2[g], FRAC_SRC, &bad);
+    const unsigned long long raw = acc_p2[g];
     acc_p2[g] = 0;
     first_pos[g] = 0xffffffffu;
-    const bf16_t pj = f2bf(sqrtf(bf2f(p2)));          // :75 torch.sqrt(prob)
+    bf16_t pj;
+    if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;            // :79-81 ones, 0 where out_degree == 0
+    else pj = f2bf(sqrtf(bf2f(fixed_to_bf((int64_t)raw, FRAC_SRC, &bad))));   // :75 torch.sqrt(prob)
     p[id] = pj;
     if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;   // sign bit set = negative / -0 cannot occur
   }
@@ -742,6 +746,8 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0 || !ws->hist) return BLISS_EINVAL;
   if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
   if (n_seeds > cap_s) return BLISS_EINVAL;
+  const int uniform_nodes = (mode & BLISS_MODE_UNIFORM_NODES) ? 1 : 0;
+  mode &= ~BLISS_MODE_UNIFORM_NODES;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;
@@ -761,15 +767,15 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   }
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 0, ws->cap_c));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c));
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
   else
-    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c));
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
   {
     int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);          // ~8 candidates per thread: amortise the 128 KiB LDS zero/flush
     if (gf < 1) gf = 1;
     if (gf > 256) gf = 256;
     PROF_LAUNCH(BK_CAND_FINALIZE, st, k_cand_finalize<<<gf, FIN_TPB, 0, st>>>(
-        seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->hist, ws->cap_c));
+        seeds, cnt, ws->cand_nid, (unsigned long long*)m->acc_p2, m->first_pos, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
   }
   return (int)hipGetLastError();
 }
@@ -808,6 +814,7 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
                       int32_t cap_s, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
                       const bliss_layer_ws_t* ws, const bliss_block_out_t* out, void* stream_) {
   if (!g || !m || !seeds || !ws || !out || !w_pos || cap_s <= 0) return BLISS_EINVAL;
+  mode &= ~BLISS_MODE_UNIFORM_NODES;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;

@@ -26,8 +26,10 @@ class LadiesSampler(BlockSampler):
         self.allow_zero_in_degree = allow_zero_in_degree
         self.eps = 0.9999
         self._engine = None
-        if not importance_sampling:
-            raise NotImplementedError("importance_sampling=False (ladies_sampler.py:49-51) is not built yet")
+
+    def _mode(self):
+        # (the reference's non-importance branch builds an fp32 ``ones`` for ladies, ladies_sampler.py:50; bf16 here)
+        return _lib.MODE_LADIES | (0 if self.importance_sampling else _lib.MODE_UNIFORM_NODES)
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """ladies_sampler.py:109-123."""
@@ -38,9 +40,9 @@ class LadiesSampler(BlockSampler):
         order = list(reversed(range(len(self.nodes_per_layer))))         # :112
         fan = [self.nodes_per_layer[b] for b in order]
         if self._poisson:
-            blks = self._engine.sample_blocks([w_pos] * len(order), seed_nodes, fan, _lib.MODE_LADIES, 0.0, self.eps, uniforms)
+            blks = self._engine.sample_blocks([w_pos] * len(order), seed_nodes, fan, self._mode(), 0.0, self.eps, uniforms)
         else:                                                            # select_neighbors :54-69 (torch.multinomial)
-            blks = self._engine.sample_blocks_multinomial([w_pos] * len(order), seed_nodes, fan, _lib.MODE_LADIES, 0.0, self.replace)
+            blks = self._engine.sample_blocks_multinomial([w_pos] * len(order), seed_nodes, fan, self._mode(), 0.0, self.replace)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights            # :100

@@ -31,6 +31,7 @@ extern "C" {
 
 #define BLISS_MODE_BANDIT 0   /* EXP3 edge probabilities  (bandit_sampler.py) */
 #define BLISS_MODE_LADIES 1   /* static edge weights      (ladies_sampler.py) */
+#define BLISS_MODE_UNIFORM_NODES 4   /* OR-ed in: importance_sampling=False, p_j = [j has an out-edge] (bandit_sampler.py:77-81) */
 
 /* The message graph g as the sampler sees it (train_lightning.py:373: CSC only). */
 typedef struct {

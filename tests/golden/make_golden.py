@@ -72,25 +72,26 @@ def check_block(ob, b, bandit, what):
         assert np.array_equal(bits(ob.node_prob), bits(b.srcdata["node_prob"])), what + " node_prob"
 
 
-def bandit_case(name, indptr, indices, eid, seeds_per_step, fanouts, eta, torch_seed, poisson=True):
+def bandit_case(name, indptr, indices, eid, seeds_per_step, fanouts, eta, torch_seed, poisson=True, importance_sampling=1):
     """Several consecutive train steps: sample_blocks -> (synthetic embed_norm) -> exp3."""
     g = ref_graph(indptr, indices, eid)
     og = bo.CSC(indptr, indices, eid)
     cls = ref_bandit.PoissonBanditLadiesSampler if poisson else ref_bandit.BanditLadiesSampler
-    sampler = cls(fanouts, importance_sampling=1, node_embedding="features", num_steps=1000, eta=eta, model="sage")
+    sampler = cls(fanouts, importance_sampling=importance_sampling, node_embedding="features", num_steps=1000, eta=eta, model="sage")
     o_w = torch.ones(len(fanouts), og.num_edges, dtype=torch.bfloat16)
     edge_w = bo.normalized_edata(og)
     assert np.array_equal(bits(edge_w), bits(g.edata["w"])), "normalized_edata"
     out = dict(indptr=indptr.numpy(), indices=indices.numpy(), eid=eid.numpy(), fanouts=np.array(fanouts),
                eta=np.array(eta), torch_seed=np.array(torch_seed), n_steps=np.array(len(seeds_per_step)),
-               edge_w=bits(edge_w), poisson=np.array(int(poisson)))
+               edge_w=bits(edge_w), poisson=np.array(int(poisson)), importance_sampling=np.array(int(importance_sampling)))
     gen = torch.Generator().manual_seed(1234 + torch_seed)
     for step, seeds in enumerate(seeds_per_step):
         out[f"s{step}_seeds"] = seeds.numpy()
         torch.manual_seed(torch_seed + step)
         inp, outp, mfgs = sampler.sample_blocks(g, seeds)
         torch.manual_seed(torch_seed + step)
-        o_inp, o_outp, o_blocks = bo.sample_blocks_bandit(og, seeds, fanouts, o_w, eta, poisson=poisson)
+        o_inp, o_outp, o_blocks = bo.sample_blocks_bandit(og, seeds, fanouts, o_w, eta, poisson=poisson,
+                                                           importance_sampling=bool(importance_sampling))
         assert torch.equal(o_inp, inp.long()), "input_nodes"
         embed = []
         for l, (b, ob) in enumerate(zip(mfgs, o_blocks)):
@@ -163,6 +164,7 @@ def main():
     gen = torch.Generator().manual_seed(9)
     steps = [torch.randperm(300, generator=gen)[:8].to(torch.int32) for _ in range(2)]
     bandit_case("synth0_bandit_multinomial", ip, ix, ei, steps, [40, 20, 10], 0.1, 300, poisson=False)
+    bandit_case("synth0_poisson_bandit_uniform_nodes", ip, ix, ei, steps, [40, 20, 10], 0.1, 302, importance_sampling=0)
     ladies_case("synth0_ladies_multinomial", ip, ix, ei, steps[0], [40, 20, 10], 301, poisson=False)
 
 

@@ -47,7 +47,8 @@ def test_poisson_bandit_golden(cuda, name):
     g, _ = _graphs(z, cuda)
     assert np.array_equal(z["edge_w"], bf16_bits(g.edata["w"]))                 # normalized_edata
     fanouts, eta, seed = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"])
-    sampler = bg.PoissonBanditLadiesSampler(fanouts, importance_sampling=1, node_embedding="features", num_steps=1000,
+    imp = int(z["importance_sampling"]) if "importance_sampling" in z else 1
+    sampler = bg.PoissonBanditLadiesSampler(fanouts, importance_sampling=imp, node_embedding="features", num_steps=1000,
                                             eta=eta, model="sage")
     for step in range(int(z["n_steps"])):
         seeds = torch.from_numpy(z[f"s{step}_seeds"]).to(cuda)

@@ -32,13 +32,14 @@ def test_bandit_matches_reference_run(name):
     g = _graph(z)
     fanouts, eta, seed = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"])
     poisson = bool(int(z["poisson"]))
+    imp = bool(int(z["importance_sampling"])) if "importance_sampling" in z else True
     edge_w = bo.normalized_edata(g)
     assert np.array_equal(z["edge_w"], bf16_bits(edge_w))
     w = torch.ones(len(fanouts), g.num_edges, dtype=torch.bfloat16)
     for step in range(int(z["n_steps"])):
         seeds = torch.from_numpy(z[f"s{step}_seeds"])
         torch.manual_seed(seed + step)
-        inp, outp, blocks = bo.sample_blocks_bandit(g, seeds, fanouts, w, eta, poisson=poisson)
+        inp, outp, blocks = bo.sample_blocks_bandit(g, seeds, fanouts, w, eta, poisson=poisson, importance_sampling=imp)
         embed = []
         for l, blk in enumerate(blocks):
             _check_block(z, f"s{step}_l{l}_", blk, True)
