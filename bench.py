@@ -88,20 +88,29 @@ def main():
     dims = [hidden, hidden, cfg["classes"]]
     from bliss_gnn_amd import roofline
     timer = roofline.KernelTimer()
-    graphed = world == 1 and not args.eager
+    graphed = not args.eager
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = None
     if graphed:
-        # whole step (sampler + gather + fwd/bwd + Adam + exp3) replayed from ONE HIP graph
-        step = GraphedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"])
-        step.calibrate(loader, steps=8)
-        step.capture(loader, warmup=3)
-        run_step, sizes_of = step, step.sizes
-    else:
+        # whole step (sampler + gather + fwd/bwd + [grad all-reduce] + Adam + exp3 [+ all-gather]) replayed from ONE HIP graph
+        try:
+            step = GraphedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"], distributed=world > 1)
+            step.calibrate(loader, steps=8)
+            step.capture(loader, warmup=3)
+            run_step, sizes_of = step, step.sizes
+        except Exception as e:                       # e.g. a runtime that cannot capture collectives: launch kernel by kernel
+            if world == 1:
+                raise
+            print("rank %d: graph capture failed (%r); falling back to the eager step" % (rank, e), file=sys.stderr)
+            graphed, step = False, None
+            sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000, eta=eta,
+                                                    model="sage")
+    if not graphed:
         step = TrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"], grad_sync=grad_sync, exp3_sync=exp3_sync)
         run_step = step
         sizes_of = lambda: [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in step.last["mfgs"]]
@@ -127,7 +136,7 @@ def main():
 
     # ---- roofline: the same step launched kernel by kernel, HIP events around the library kernels ----------------
     dominant, calib, dom_timing, alg_dom = None, {}, None, 0.0
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:
         k_step = step.eager_step if graphed else step
         torch.cuda.synchronize()
         timer.enable("all")
@@ -158,7 +167,7 @@ def main():
         "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer SAGE hidden %d, poisson-bandit eta %.1f, "
                                "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"], hidden, eta,
                                                                  "/".join(map(str, fan)), cfg["batch"]),
-                   "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather)" % world if world > 1 else "single GPU",
+                   "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather over RCCL)" % world if world > 1 else "single GPU",
                    "launch": "whole step replayed from one HIP graph" if graphed else "eager (kernel by kernel)",
                    "global_batch": cfg["batch"] * world},
         "sampled_edges_per_sec": n_edges / dt, "frontier_edges_per_sec": n_frontier / dt,

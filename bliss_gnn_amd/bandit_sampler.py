@@ -204,14 +204,16 @@ class BanditLadiesSampler(BlockSampler):
                                                      self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
                                                      self._norms[idx:].data_ptr(), st), "bliss_exp3_normalize")
 
-    def apply_updates(self, idx, pos, factor, g):
-        """w[pos] *= factor on layer ``idx`` (positions unique within one call), bandit_sampler.py:248."""
-        n = int(pos.numel())
-        if n == 0:
+    def apply_updates(self, idx, pos, factor, g, n_dev=None):
+        """w[pos] *= factor on layer ``idx`` (positions unique within one call), bandit_sampler.py:248.  ``n_dev``: optional
+        int32 device tensor holding how many leading entries are valid (capacity-padded lists, graph capture)."""
+        bound = int(pos.numel())
+        if bound == 0:
             return
-        n_dev = torch.tensor([n], dtype=torch.int32, device=pos.device)
+        if n_dev is None:
+            n_dev = torch.tensor([bound], dtype=torch.int32, device=pos.device)
         _lib.check(_lib.lib.bliss_exp3_apply(self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr(), pos.data_ptr(),
-                                             factor.data_ptr(), n_dev.data_ptr(), n, self._err.data_ptr(), _stream()),
+                                             factor.data_ptr(), n_dev.data_ptr(), bound, self._err.data_ptr(), _stream()),
                    "bliss_exp3_apply")
 
     def normalize(self, idx, g):

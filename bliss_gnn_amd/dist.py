@@ -67,3 +67,23 @@ def exp3_all_ranks(sampler, mfgs, g):
         for pos_r, fac_r in gather_updates(mfg.pos, factors[idx]):
             sampler.apply_updates(idx, pos_r, fac_r, g)
         sampler.normalize(idx, g)
+
+
+def exp3_all_ranks_static(sampler, mfgs, g):
+    """The same exchange for capacity-padded blocks with the true edge counts on the device: fixed-size messages, no
+    host round trip -- the whole step, collectives included, can be recorded into one HIP graph."""
+    world = dist.get_world_size()
+    factors = [torch.empty(int(m.src.numel()), dtype=torch.bfloat16, device=g.device) for m in mfgs]
+    sampler.exp3(mfgs, g, apply=False, factors=factors)
+    for idx, mfg in enumerate(mfgs):
+        cap = int(mfg.src.numel())
+        ibuf = torch.empty(cap + 8, dtype=torch.int32, device=g.device)          # positions + the true count
+        ibuf[:cap] = mfg.pos
+        ibuf[cap:cap + 1] = mfg._counts_dev[4:5]                                  # LayerCounts::B
+        igath = [torch.empty_like(ibuf) for _ in range(world)]
+        fgath = [torch.empty_like(factors[idx]) for _ in range(world)]
+        dist.all_gather(igath, ibuf)
+        dist.all_gather(fgath, factors[idx])
+        for ib, fb in zip(igath, fgath):                                          # rank order on every rank
+            sampler.apply_updates(idx, ib[:cap], fb, g, n_dev=ib[cap:cap + 1])
+        sampler.normalize(idx, g)

@@ -100,8 +100,9 @@ class GraphedTrainStep:
     blocks are padded to capacities learned from a few eager steps (``calibrate``); true sizes stay on the device
     and come back with the step's single end-of-step sync.  Results are bit-identical to the eager path."""
 
-    def __init__(self, g, sampler, model, batch_size, lr=0.002, multilabel=False):
+    def __init__(self, g, sampler, model, batch_size, lr=0.002, multilabel=False, distributed=False):
         self.g, self.sampler, self.model, self.bs = g, sampler, model, int(batch_size)
+        self.distributed = distributed          # replicas: gradient all-reduce + EXP3 exchange recorded in the graph too
         self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()
         # one fused multi-tensor kernel instead of ~40 foreach launches (each >= 5 us inside a graph)
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)
@@ -120,6 +121,11 @@ class GraphedTrainStep:
             for n, b in enumerate(reversed(blocks)):                      # sampling order
                 mx[n]["K"] = max(mx[n]["K"], b.num_src_nodes())
                 mx[n]["B"] = max(mx[n]["B"], b.num_edges())
+        if self.distributed:                       # the exchanged lists are capacity-sized: every rank needs the same capacities
+            import torch.distributed as dist
+            t = torch.tensor([[m["K"], m["B"]] for m in mx], dtype=torch.int64, device=self.g.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mx = [dict(K=int(k), B=int(b)) for k, b in t.tolist()]
         fan = [self.sampler.nodes_per_layer[b] for b in reversed(range(L))]
         self.sampler._engine.set_static_caps(self.bs, fan, mx, k_margin, b_margin)
 
@@ -131,8 +137,14 @@ class GraphedTrainStep:
         loss = self.loss_fn(pred, y)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
-        self.opt.step()
-        self.sampler.exp3(mfgs, self.g)
+        if self.distributed:
+            from . import dist as bdist
+            bdist.allreduce_gradients(self.model)
+            self.opt.step()
+            bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
+        else:
+            self.opt.step()
+            self.sampler.exp3(mfgs, self.g)
         # detach: a live autograd graph would pin the warm-up stream's AccumulateGrad nodes into the capture
         return loss.detach()
 

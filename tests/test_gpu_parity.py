@@ -648,3 +648,41 @@ def test_multinomial_samplers_golden(cuda, name):
         _, _, blocks = sampler.sample_blocks(g, torch.from_numpy(z["seeds"]).to(cuda))
         for l, blk in enumerate(blocks):
             _check_block(z, f"l{l}_", blk, False)
+
+
+def test_graphed_step_with_collectives_single_rank(cuda):
+    """The multi-GPU step (gradient all-reduce + static-shape EXP3 all-gather) recorded into one HIP graph, on a world of
+    one rank: must replay, and must leave exactly the EXP3 state of the non-distributed graphed step."""
+    import os
+    import torch.distributed as dist
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep
+    bg = _bg()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29741"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        ip, ix, ei = chung_lu_csc(6000, 100000, seed=51)
+        feats = torch.randn(6000, 32, generator=torch.Generator().manual_seed(2)).bfloat16()
+        labels = torch.randint(0, 4, (6000,), generator=torch.Generator().manual_seed(3))
+        ids = torch.arange(6000, dtype=torch.int32, device=cuda)
+        outs = []
+        for distributed in (False, True):
+            g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+            g.edata["w"] = bg.normalized_edata(g)
+            s = bg.PoissonBanditLadiesSampler([300, 150, 80], eta=0.1)
+            torch.manual_seed(0)
+            model = SAGE(32, 16, 4, 3, torch.relu, 0.0).to(cuda).bfloat16()
+            step = GraphedTrainStep(g, s, model, 48, distributed=distributed)
+            loader = BatchLoader(ids, 48, seed=5).forever()
+            torch.manual_seed(9)
+            step.calibrate(loader, steps=3)
+            step.capture(loader, warmup=2)
+            for _ in range(4):
+                step(next(loader))
+            s.check_errors()
+            outs.append((s.exp3_weights.cpu().view(torch.int16).clone(), float(step.loss)))
+        assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    finally:
+        dist.destroy_process_group()
