@@ -4,13 +4,14 @@
 source-row norms the bandit reward needs on ``block.srcdata['embed_norm']`` (model.py:318-320) and
 runs the SAGEConv layers with the sampler's edge weights (model.py:321-329).
 """
+import torch
 import torch.nn as nn
 
 from .nn import SAGEConv, embed_norm
 
 
 class SAGE(nn.Module):
-    """model.py:292-333 (``inference`` = SURVEY 8f 'next' row, not built yet)."""
+    """model.py:292-383."""
 
     def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout):
         super().__init__()
@@ -35,6 +36,53 @@ class SAGE(nn.Module):
                 h = self.activation(h)
                 h = self.dropout(h)
         return h
+
+    @torch.no_grad()
+    def inference(self, g, device=None, batch_size=128, use_uva=False, num_workers=0, node_chunk=16384):
+        """model.py:335-383: layer-wise full-neighbour inference over ALL nodes (no sampling, plain mean, no edge weights).
+
+        The reference walks the nodes 128 at a time through a DataLoader; every output row depends only on its own
+        in-neighbours, so the rows are computed here in chunks of ``node_chunk`` contiguous nodes straight from the CSC
+        (``batch_size``, ``use_uva`` and ``num_workers`` are accepted for signature compatibility).  Returns y [V, classes]
+        and leaves it in ``g.ndata['h']`` like the reference (:382)."""
+        was_training = self.training
+        self.eval()                                                          # :364
+        V = g.num_nodes()
+        deg = g.indptr[1:] - g.indptr[:-1]
+        dst_all = torch.repeat_interleave(torch.arange(V, device=g.device, dtype=torch.int32), deg)
+        h = g.ndata["features"]                                              # :346
+        for l, layer in enumerate(self.layers):                              # :366
+            before = layer._in_src_feats > layer._out_feats                  # SAGEConv: fc_neigh before aggregation iff in > out
+            src_feat = layer.fc_neigh(h) if before else h
+            y = torch.empty(V, layer._out_feats, dtype=h.dtype, device=h.device)
+            for b0 in range(0, V, node_chunk):
+                b1 = min(V, b0 + node_chunk)
+                neigh = _full_neighbor_mean(g, src_feat, b0, b1, dst_all)
+                if not before:
+                    neigh = layer.fc_neigh(neigh)
+                out = layer.fc_self(h[b0:b1]) + neigh
+                if l < len(self.layers) - 1:
+                    out = self.dropout(self.activation(out))                 # :377-379 (dropout is the identity in eval mode)
+                y[b0:b1] = out
+            h = y
+        g.ndata["h"] = h
+        self.train(was_training)
+        return h
+
+
+def _full_neighbor_mean(g, h, b0, b1, dst_all):
+    """mean over ALL in-neighbours of nodes b0..b1-1 (a MultiLayerFullNeighborSampler(1) block without edge weights,
+    model.py:347-349, 375-376): the CSC columns of a contiguous node range are one contiguous slice."""
+    import torch
+    from .graph import Block
+    from .nn import weighted_aggregate
+    e0, e1 = int(g.indptr[b0]), int(g.indptr[b1])
+    indptr = (g.indptr[b0:b1 + 1] - e0).to(torch.int32)
+    src = g.indices[e0:e1]
+    dst = dst_all[e0:e1] - b0
+    blk = Block(None, h.shape[0], b1 - b0, indptr, src, dst, src, src, torch.empty(0, dtype=torch.int32, device=h.device))
+    blk._transposed = (None, None)
+    return weighted_aggregate(blk, h, None, mean=True)
 
 
 class GCN(nn.Module):

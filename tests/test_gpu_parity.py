@@ -686,3 +686,33 @@ def test_graphed_step_with_collectives_single_rank(cuda):
         assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     finally:
         dist.destroy_process_group()
+
+
+def test_sage_full_neighbor_inference(cuda):
+    """SAGE.inference (model.py:335-383) == an fp32 restatement (plain mean over all in-neighbours,
+    SAGEConv layer by layer, relu between layers), for several chunk sizes."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    V = 3000
+    ip, ix, ei = chung_lu_csc(V, 40000, seed=61)
+    feats = torch.randn(V, 24, generator=torch.Generator().manual_seed(1)).bfloat16()
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda)})
+    torch.manual_seed(0)
+    model = SAGE(24, 16, 5, 3, torch.relu, 0.5).to(cuda).bfloat16()
+    deg = (ip[1:] - ip[:-1])
+    dst = torch.repeat_interleave(torch.arange(V), deg)
+    src = ix.long()
+    h = feats.float()
+    for l, layer in enumerate(model.layers):
+        Ws, bs, Wn = layer.fc_self.weight.float().cpu(), layer.fc_self.bias.float().cpu(), layer.fc_neigh.weight.float().cpu()
+        hb = h.bfloat16().float()                                    # the layer input is stored in bf16
+        agg = lambda z: torch.zeros(V, z.shape[1]).index_add_(0, dst, z[src]) / deg.clamp(min=1).float()[:, None]
+        neigh = agg((hb @ Wn.t()).bfloat16().float()) if Wn.shape[1] > Wn.shape[0] else agg(hb).bfloat16().float() @ Wn.t()
+        h = hb @ Ws.t() + bs + neigh
+        if l < 2:
+            h = torch.relu(h)
+    for chunk in (16384, 700):
+        y = model.inference(g, cuda, 128, False, 0, node_chunk=chunk)
+        assert y.shape == (V, 5) and g.ndata["h"] is y and model.training
+        assert (y.float().cpu() - h).abs().max() <= 0.05 * h.abs().max()      # three bf16 layers deep
