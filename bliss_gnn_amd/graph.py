@@ -197,3 +197,23 @@ class Block:
                                                       torch.cuda.current_stream().cuda_stream), "bliss_block_transpose")
             self._transposed = (t_indptr, t_edge)
         return self._transposed
+
+
+def full_neighbor_block(g, b0, b1):
+    """The block ``MultiLayerFullNeighborSampler(1)`` yields for the contiguous seed range b0..b1-1 (the reference's
+    ``inference`` loaders, model.py:248-263, 347-362, 453-468): ALL in-edges of the seeds, destinations first among the
+    sources, edge order = CSC order.  (The extra sources are numbered in ascending id order instead of first appearance;
+    no destination row depends on that numbering.)  Evaluation-time helper: it synchronises once for the source count."""
+    S = b1 - b0
+    e0, e1 = int(g.indptr[b0]), int(g.indptr[b1])
+    indptr = (g.indptr[b0:b1 + 1] - e0).to(torch.int32)
+    col = g.indices[e0:e1].long()
+    outside = (col < b0) | (col >= b1)
+    others = torch.unique(col[outside])
+    src = torch.where(outside, S + torch.searchsorted(others, col), col - b0).to(torch.int32)
+    deg = (indptr[1:] - indptr[:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(S, device=col.device, dtype=torch.int32), deg, output_size=e1 - e0)
+    src_nid = torch.cat([torch.arange(b0, b1, device=col.device), others]).to(torch.int32)
+    pos = torch.arange(e0, e1, device=col.device, dtype=torch.int32) if e1 < 2 ** 31 else None
+    eid = g.eid[e0:e1] if g.eid is not None else pos
+    return Block(g, src_nid.numel(), S, indptr, src, dst, pos, eid, src_nid)

@@ -114,6 +114,37 @@ class GCN(nn.Module):
                 h = self.dropout(h)                                           # model.py:437-438
         return h
 
+    @torch.no_grad()
+    def inference(self, g, device=None, batch_size=128, use_uva=False, num_workers=0):
+        """model.py:441-488.  GraphConv(norm='both') normalises by the BLOCK's out-degrees, so the result depends on how
+        the nodes are batched: ``batch_size`` is honoured exactly (contiguous batches, unshuffled, last one short)."""
+        was_training = self.training
+        self.eval()
+        n = len(self.layers)
+        h = _blockwise_inference(self.layers, g, g.ndata["features"], int(batch_size),
+                                 lambda l, out: self.dropout(out) if l < n - 1 else out)
+        self.train(was_training)
+        return h
+
+
+def _blockwise_inference(layers, g, h, batch_size, finish):
+    """The shared loop of the reference's three ``inference`` methods: per layer, walk all nodes in contiguous batches,
+    run the layer on the full-neighbour block of the batch and write the rows into y (model.py:267-288, 472-487)."""
+    from .graph import full_neighbor_block
+    V = g.num_nodes()
+    for l, layer in enumerate(layers):
+        y = None
+        for b0 in range(0, V, batch_size):
+            b1 = min(V, b0 + batch_size)
+            blk = full_neighbor_block(g, b0, b1)
+            out = finish(l, layer(blk, h[blk.srcdata["_ID"].long()]))
+            if y is None:
+                y = torch.empty(V, out.shape[1], dtype=h.dtype, device=h.device)
+            y[b0:b1] = out
+        h = y
+        g.ndata["h"] = h
+    return h
+
 
 class GATv2(nn.Module):
     """model.py:115-234.  ``forward`` stores embed_norm (srcdata) and the head-mean pre-softmax logits ``a_ij`` (edata)
@@ -144,4 +175,16 @@ class GATv2(nn.Module):
                                         get_attention=True)
             block.edata["a_ij"] = a.squeeze(-1).mean(dim=1)                                                    # :224-227
             h = h.flatten(1) if l < len(blocks) - 1 else h.mean(1)                                             # :228-232
+        return h
+
+    @torch.no_grad()
+    def inference(self, g, device=None, batch_size=128, use_uva=False, num_workers=0, node_chunk=4096):
+        """model.py:236-289.  Every output row depends only on its own in-edges (edge softmax is per destination), so the
+        nodes are walked ``node_chunk`` at a time instead of the reference loader's ``batch_size``; the rows are the same."""
+        was_training = self.training
+        self.eval()                                                                                            # :265
+        n = len(self.gatv2_layers)
+        h = _blockwise_inference(self.gatv2_layers, g, g.ndata["features"].bfloat16(), int(node_chunk),
+                                 lambda l, out: out.flatten(1) if l < n - 1 else out.mean(1))                  # :282-285
+        self.train(was_training)
         return h

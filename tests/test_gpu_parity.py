@@ -716,3 +716,85 @@ def test_sage_full_neighbor_inference(cuda):
         y = model.inference(g, cuda, 128, False, 0, node_chunk=chunk)
         assert y.shape == (V, 5) and g.ndata["h"] is y and model.training
         assert (y.float().cpu() - h).abs().max() <= 0.05 * h.abs().max()      # three bf16 layers deep
+
+
+def _small_graph(cuda, V=1500, E=16000, F=12, seed=71):
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(V, E, seed=seed)
+    feats = torch.randn(V, F, generator=torch.Generator().manual_seed(1)).bfloat16()
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda)})
+    deg = ip[1:] - ip[:-1]
+    return g, ip, ix.long(), torch.repeat_interleave(torch.arange(V), deg), deg, feats
+
+
+def test_full_neighbor_block(cuda):
+    """graph.full_neighbor_block == the MultiLayerFullNeighborSampler(1) block of a contiguous seed range."""
+    from bliss_gnn_amd.graph import full_neighbor_block
+    g, ip, src, dst, deg, _ = _small_graph(cuda)
+    for b0, b1 in ((0, 128), (700, 828), (1400, 1500)):
+        blk = full_neighbor_block(g, b0, b1)
+        e0, e1 = int(ip[b0]), int(ip[b1])
+        nid = blk.srcdata["_ID"].cpu().long()
+        assert torch.equal(nid[:b1 - b0], torch.arange(b0, b1)) and nid.unique().numel() == nid.numel()
+        assert torch.equal(nid[blk.src.cpu().long()], src[e0:e1])
+        assert torch.equal(blk.dst.cpu().long() + b0, dst[e0:e1])
+        assert torch.equal(blk.indptr.cpu().long(), ip[b0:b1 + 1] - e0)
+        assert set(nid[b1 - b0:].tolist()) == set(src[e0:e1].tolist()) - set(range(b0, b1))
+
+
+def test_gcn_inference_honours_batch_size(cuda):
+    """GCN.inference (model.py:441-488): GraphConv normalises by the block's own out-degrees, so the fp32 restatement
+    walks the same batches."""
+    from bliss_gnn_amd.model import GCN
+    g, ip, src, dst, deg, feats = _small_graph(cuda)
+    V = feats.shape[0]
+    torch.manual_seed(0)
+    model = GCN(12, 16, 4, 2, torch.relu, 0.5).to(cuda).bfloat16()
+    for bs in (128, 500):
+        h = feats.float()
+        for l, layer in enumerate(model.layers):
+            W, b = layer.weight.float().cpu(), layer.bias.float().cpu()
+            y = torch.zeros(V, W.shape[1])
+            for b0 in range(0, V, bs):
+                b1 = min(V, b0 + bs)
+                e0, e1 = int(ip[b0]), int(ip[b1])
+                s, d = src[e0:e1], dst[e0:e1] - b0
+                od = torch.zeros(V).index_add_(0, s, torch.ones(e1 - e0)).clamp(min=1)
+                z = h * od.pow(-0.5)[:, None]
+                agg = torch.zeros(b1 - b0, h.shape[1]).index_add_(0, d, z[s])
+                out = (agg @ W) * deg[b0:b1].clamp(min=1).float().pow(-0.5)[:, None] + b
+                y[b0:b1] = torch.relu(out) if l == 0 else out
+            h = y
+        got = model.inference(g, cuda, bs, False, 0)
+        assert got.shape == (V, 4)
+        assert (got.float().cpu() - h).abs().max() <= 0.05 * h.abs().max()
+    a, b_ = model.inference(g, cuda, 128, False, 0), model.inference(g, cuda, 500, False, 0)
+    assert not torch.equal(a, b_)                                   # the batching really enters the result
+
+
+def test_gat_inference(cuda):
+    """GATv2.inference (model.py:236-289) == fp32 restatement of the GATv2 layer over all in-edges; chunk-independent."""
+    from bliss_gnn_amd.model import GATv2
+    g, ip, src, dst, deg, feats = _small_graph(cuda)
+    V = feats.shape[0]
+    torch.manual_seed(0)
+    heads = [2, 1]
+    model = GATv2(2, 12, 8, 3, heads, torch.relu, 0.0, 0.0, 0.2, True).to(cuda).bfloat16()
+    h = feats.float()
+    for l, layer in enumerate(model.gatv2_layers):
+        H, D = heads[l], layer._out_feats
+        f = (h @ layer.fc_src.weight.float().cpu().t()).view(V, H, D)
+        e = (torch.nn.functional.leaky_relu(f[src] + f[dst], 0.2) * layer.attn.float().cpu()).sum(-1)      # [E, H]
+        mx = torch.full((V, H), -1e30).scatter_reduce(0, dst[:, None].expand(-1, H), e, "amax")
+        ex = torch.exp(e - mx[dst])
+        a = ex / torch.zeros(V, H).index_add_(0, dst, ex)[dst]
+        out = torch.zeros(V, H, D).index_add_(0, dst, a[:, :, None] * f[src])
+        if layer.res_fc is not None:
+            res = h if isinstance(layer.res_fc, torch.nn.Identity) else h @ layer.res_fc.weight.float().cpu().t()
+            out = out + res.view(V, -1, D)
+        h = torch.relu(out).flatten(1) if l == 0 else out.mean(1)
+    ys = [model.inference(g, cuda, 128, False, 0, node_chunk=c) for c in (4096, 300)]
+    assert ys[0].shape == (V, 3)
+    assert (ys[0].float().cpu() - h).abs().max() <= 0.05 * h.abs().max()
+    assert torch.equal(ys[0], ys[1])
