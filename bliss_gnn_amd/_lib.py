@@ -68,6 +68,7 @@ SIGNATURES = {
     "bliss_spmm_fwd": [_P, _P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
     "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
     "bliss_block_transpose": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _I64, _P],
+    "bliss_graph_prepare": [_P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
@@ -84,7 +85,8 @@ SIGNATURES = {
 }
 
 
-SPECIAL_SIGNATURES = ("bliss_prof_kernel_name", "bliss_block_transpose_temp_bytes")   # non-int return types, set in _load()
+SPECIAL_SIGNATURES = ("bliss_prof_kernel_name", "bliss_block_transpose_temp_bytes", "bliss_graph_prepare_capacity",
+                      "bliss_graph_prepare_temp_bytes")   # non-int return types, set in _load()
 
 
 def _load():
@@ -99,6 +101,9 @@ def _load():
         fn.restype = C.c_int
     lib.bliss_block_transpose_temp_bytes.argtypes = [_I32, _I32]
     lib.bliss_block_transpose_temp_bytes.restype = C.c_int64
+    for name in ("bliss_graph_prepare_capacity", "bliss_graph_prepare_temp_bytes"):
+        getattr(lib, name).argtypes = [_I64, _I32, C.c_int]
+        getattr(lib, name).restype = C.c_int64
     lib.bliss_prof_kernel_name.argtypes = [C.c_int]
     lib.bliss_prof_kernel_name.restype = C.c_char_p
     assert lib.bliss_layer_counts_bytes() == C.sizeof(LayerCounts), "LayerCounts layout mismatch"

@@ -179,6 +179,19 @@ int64_t bliss_block_transpose_temp_bytes(int32_t cap_b, int32_t n_src_cap);
 int bliss_block_transpose(const int32_t* src, const int32_t* nnz_dev, int32_t nnz, int32_t cap_b, int32_t n_src_cap,
                           int32_t* t_indptr, int32_t* t_edge, void* temp, int64_t temp_bytes, void* stream);
 
+/* Graph preparation: edge list -> the int32 CSC graph the samplers read.  Replaces
+ * dgl.remove_self_loop + dgl.add_self_loop (+ g.add_edges(dst, src) when undirected) + g.int() + g.formats(['csc'])
+ * of train_lightning.py:334-341, 373.  Edge ids follow DGL: surviving edges renumbered in order, then the V self loops,
+ * then (undirected) the reverse of every edge; columns hold their edges in ascending edge id (self loop last).
+ * Outputs are sized bliss_graph_prepare_capacity() = (n_edges + V) * (undirected ? 2 : 1) (must stay < 2^31); the true
+ * edge count is written to the device word n_out; err (device int32, caller-zeroed) gets bit 1 if an endpoint is outside
+ * [0, V).  No host synchronisation. */
+int64_t bliss_graph_prepare_capacity(int64_t n_edges, int32_t num_nodes, int undirected);
+int64_t bliss_graph_prepare_temp_bytes(int64_t n_edges, int32_t num_nodes, int undirected);
+int bliss_graph_prepare(const int32_t* coo_src, const int32_t* coo_dst, int64_t n_edges, int32_t num_nodes, int undirected,
+                        int64_t* indptr, int32_t* indices, int32_t* eid, int64_t* n_out, int32_t* err, void* temp,
+                        int64_t temp_bytes, void* stream);
+
 /* calculate_alpha (SAGE/GCN) + calculate_rewards + update_exp3_weights up to the scatter,
  * bandit_sampler.py:157, :180-193, :221-248.  One launch per block.
  * edge_w_pos: g.edata['w'] by CSC position.  w_pos: the layer's exp3 row (updated in place).

@@ -420,3 +420,20 @@ def sage_conv_ref(blk: OBlock, h, W_self, b_self, W_neigh, edge_weight):
     else:
         neigh = spmm_mean_ref(blk, h, edge_weight) @ W_neigh.float().t()
     return h_self @ W_self.float().t() + b_self.float() + neigh
+
+
+def prepare_graph(src, dst, num_nodes, undirected=False):
+    """train_lightning.py:334-341, 373 restated: remove_self_loop, add_self_loop, optional add_edges(dst, src), then
+    CSC by a STABLE sort on destination ([DGL-recalled] columns keep ascending edge id, so the self loop is last).
+    Pinned by the reference's ToyDataset (load_graph.py:96) -> tests/test_oracle.py."""
+    src, dst = torch.as_tensor(src).long(), torch.as_tensor(dst).long()
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    loops = torch.arange(num_nodes)
+    src, dst = torch.cat([src, loops]), torch.cat([dst, loops])
+    if undirected:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    order = torch.sort(dst, stable=True).indices
+    indptr = torch.zeros(num_nodes + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.bincount(dst, minlength=num_nodes), 0)
+    return CSC(indptr, src[order].to(torch.int32), order.to(torch.int32))

@@ -798,3 +798,51 @@ def test_gat_inference(cuda):
     assert ys[0].shape == (V, 3)
     assert (ys[0].float().cpu() - h).abs().max() <= 0.05 * h.abs().max()
     assert torch.equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize("undirected", [False, True])
+def test_prepare_graph_matches_oracle(cuda, undirected):
+    """csrc/prep.hip == oracle.prepare_graph (train_lightning.py:334-341, 373), ids bit-exact."""
+    from bliss_gnn_amd.prep import prepare_graph
+    from oracle import bliss_oracle as bo
+    gen = torch.Generator().manual_seed(5)
+    cases = [(torch.tensor([2, 3, 3, 4]), torch.tensor([0, 0, 1, 1]), 5)]                   # ToyDataset, load_graph.py:96
+    for V, E in ((1, 0), (7, 0), (50, 400), (3000, 100000)):
+        src, dst = torch.randint(0, V, (E,), generator=gen), torch.randint(0, V, (E,), generator=gen)
+        if E:
+            dst[::7] = src[::7]                                                             # plenty of self loops to drop
+            src[1::11], dst[1::11] = src[0], dst[0]                                         # and duplicate edges
+        cases.append((src, dst, V))
+    cases.append((torch.arange(20), torch.arange(20), 20))                                  # nothing but self loops
+    for src, dst, V in cases:
+        want = bo.prepare_graph(src, dst, V, undirected)
+        got = prepare_graph(src.to(cuda), dst.to(cuda), V, undirected)
+        assert torch.equal(got.indptr.cpu(), want.indptr)
+        assert torch.equal(got.indices.cpu(), want.indices)
+        assert torch.equal(got.eid.cpu(), want.eid)
+    with pytest.raises(ValueError):
+        prepare_graph(torch.tensor([0, 9], device=cuda), torch.tensor([1, 1], device=cuda), 5)
+
+
+def test_prepared_graph_feeds_the_sampler(cuda):
+    """prepare_graph -> normalized_edata -> sample_blocks: same blocks as the oracle on the oracle-prepared graph."""
+    from bliss_gnn_amd.prep import prepare_graph
+    from oracle import bliss_oracle as bo
+    bg = _bg()
+    gen = torch.Generator().manual_seed(8)
+    V, E = 400, 5000
+    src, dst = torch.randint(0, V, (E,), generator=gen), torch.randint(0, V, (E,), generator=gen)
+    og = bo.prepare_graph(src, dst, V, True)
+    g = prepare_graph(src.to(cuda), dst.to(cuda), V, True)
+    g.edata["w"] = bg.normalized_edata(g)
+    assert torch.equal(g.edata["w"].cpu().view(torch.int16), bo.normalized_edata(og).view(torch.int16))
+    seeds = torch.randperm(V, generator=gen)[:16].to(torch.int32)
+    fan = [40, 20]
+    sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=10, eta=0.1, model="sage")
+    torch.manual_seed(3)
+    inp, _, blocks = sampler.sample_blocks(g, seeds.to(cuda))
+    torch.manual_seed(3)
+    o_inp, _, o_blocks = bo.sample_blocks_bandit(og, seeds, fan, torch.ones(2, og.num_edges, dtype=torch.bfloat16), 0.1)
+    assert torch.equal(inp.cpu().long(), o_inp)
+    for b, ob in zip(blocks, o_blocks):
+        assert torch.equal(b.src.cpu().long(), ob.src) and torch.equal(b.edata["_ID"].cpu().long(), ob.eid)

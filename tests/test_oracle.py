@@ -130,3 +130,27 @@ def test_poisson_draw_matches_torch_bernoulli():
     torch.manual_seed(11); a = bo.poisson_draw(P)
     torch.manual_seed(11); b = bo.poisson_draw(P, torch.rand(70000))
     assert torch.equal(a, b)
+
+
+def test_prepare_graph_toy_and_generator_convention():
+    """oracle.prepare_graph (train_lightning.py:334-341, 373) on the reference's ToyDataset (load_graph.py:96) gives the
+    CSC the golden toy fixtures were produced on, and the synthetic generator's CSC follows the same edge-id convention."""
+    from bliss_gnn_amd.synth import chung_lu_csc
+    g = bo.prepare_graph([2, 3, 3, 4], [0, 0, 1, 1], 5)
+    z = load_golden("toy_poisson_bandit")
+    assert np.array_equal(g.indptr.numpy(), z["indptr"]) and np.array_equal(g.indices.numpy(), z["indices"])
+    assert np.array_equal(g.eid.numpy(), z["eid"])
+    # self loops in the input are dropped and re-added with the highest ids; duplicates survive; undirected doubles everything
+    g = bo.prepare_graph([0, 1, 1, 2, 1], [0, 0, 0, 2, 2], 3, undirected=True)
+    assert g.indptr.tolist() == [0, 4, 9, 12]                # worked by hand: kept e0-2, loops e3-5, reverses e6-11
+    assert g.indices.tolist() == [1, 1, 0, 0, 1, 0, 0, 2, 1, 1, 2, 2]
+    assert g.eid.tolist() == [0, 1, 3, 9, 4, 6, 7, 8, 10, 2, 5, 11]
+    ip, ix, ei = chung_lu_csc(500, 6000, seed=5)
+    dst = torch.repeat_interleave(torch.arange(500), ip[1:] - ip[:-1])
+    src_by_eid = torch.empty(ix.numel(), dtype=torch.int64)
+    dst_by_eid = torch.empty(ix.numel(), dtype=torch.int64)
+    src_by_eid[ei.long()] = ix.long()
+    dst_by_eid[ei.long()] = dst
+    n = ix.numel() - 500                                     # the generator's last V edge ids are its self loops
+    g = bo.prepare_graph(src_by_eid[:n], dst_by_eid[:n], 500)
+    assert torch.equal(g.indptr, ip) and torch.equal(g.indices, ix) and torch.equal(g.eid, ei)
