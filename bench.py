@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--config", default="reddit", choices=["cora", "pubmed", "reddit", "yelp"])
     ap.add_argument("--cpu-baseline-steps", type=int, default=-1, help="-1: auto (bounded sample), 0: skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tune-gemm", type=int, default=1, help="1: TunableOp picks the library GEMM solutions during warm-up")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the step's HIP graph")
     return ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
         try:
             step = GraphedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"], distributed=world > 1)
             step.calibrate(loader, steps=8)
-            step.capture(loader, warmup=3)
+            step.capture(loader, warmup=3, tune_gemm=args.tune_gemm)
             run_step, sizes_of = step, step.sizes
         except Exception as e:                       # e.g. a runtime that cannot capture collectives: launch kernel by kernel
             if world == 1:

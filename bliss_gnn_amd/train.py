@@ -10,6 +10,8 @@ replays, in order, exactly what they do to the sampler and the model each step
     loss = loss_fn(model(mfgs, x), y);  loss.backward();  optimiser.step()     :141-142 + Lightning
     sampler.exp3(mfgs, g)                                                      BatchSizeCallback :469-471
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -153,9 +155,20 @@ class GraphedTrainStep:
         self.last_counts = self.sampler.finish_static()
         self.num_steps += 1
 
-    def capture(self, loader, warmup=3):
-        """Eager static-shape warm-up steps on a side stream (allocator + autograd warm), then capture."""
+    def capture(self, loader, warmup=3, tune_gemm=False):
+        """Eager static-shape warm-up steps on a side stream (allocator + autograd warm), then capture.
+
+        ``tune_gemm``: let PyTorch's TunableOp pick the rocBLAS / hipBLASLt solution for every dense transform during
+        the warm-up (the shapes are static, so each is tuned once); the tall-skinny weight-gradient GEMMs otherwise get
+        a default tile that fills only a fraction of the 256 CUs."""
         eng = self.sampler._engine
+        if tune_gemm:
+            tn = torch.cuda.tunable
+            tn.enable(True)
+            tn.tuning_enable(True)
+            tn.set_max_tuning_duration(30)
+            tn.set_max_tuning_iterations(20)
+            tn.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bliss_tunableop_%d.csv" % os.getpid()))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -165,6 +178,8 @@ class GraphedTrainStep:
                 self.loss = self._body()
                 self._finish()
         torch.cuda.current_stream().wait_stream(side)
+        if tune_gemm:
+            torch.cuda.tunable.tuning_enable(False)        # keep using the tuned solutions, stop measuring
         self.loss = None
         import gc
         gc.collect()
