@@ -7,9 +7,9 @@
 // sync to learn the count; here the 2.5 KB generator state is uploaded once per sample_blocks call,
 // the count is read from the device, and the advanced state is handed back with the step's sizes.
 //
-// The 624-word recurrence is a serial chain from block to block with three dependency stages per block;
-// a 256-thread workgroup walks it out of place between two LDS buffers (one word per thread per stage,
-// three barriers per 624 numbers) and tempers / stores block i while stage A of block i+1 runs.
+// The 624-word recurrence is a serial chain.  The one-shot kernel (k_mt19937_uniform) walks it with a 256-thread
+// workgroup in its three dependency stages; the streaming generator (k_mt19937_stream) gives the chain to ONE wave,
+// which needs no barriers inside a block, and lets the other three waves temper and store behind it.
 #include "common.cuh"
 #include "bliss_gnn.h"
 #include "prof.h"
@@ -102,13 +102,46 @@ __device__ __forceinline__ void store_sc1_x4(float* p, float a, float b, float c
 // regenerated block occupies out[624 k .. 624 (k+1)) -- so every regenerated block is stored with aligned 16-byte
 // stores.  Stream position p lives at out[base + p]; ctl[4] = base (set by k_rng_ctl_init).
 #define MT_PUBLISH_EVERY 4
+
+// One wave walks next_state() out of place, 64 words per step in index order.  Word k needs od[k], od[k+1] and either
+// od[k+397] (k < 227) or nw[k-227] -- written at least three steps (227 words) earlier by this same wave, so LDS
+// program order is all the synchronisation the recurrence needs: no barrier inside a block.
+// The cross-lane dependencies through LDS are invisible to the compiler (a lane never re-reads its own addresses), so a
+// compiler barrier after every step pins the program order the hardware then honours (a wave's DS operations execute in
+// order).  The operands of step c+1 never depend on the store of step c, so they are fetched ahead of it.
+__device__ __forceinline__ void mt_fetch(const uint32_t* od, const uint32_t* nw, int k, uint32_t& u, uint32_t& v, uint32_t& m) {
+  constexpr int H = MT_N - MT_M;   // 227
+  if (k < MT_N) {
+    u = od[k];
+    v = (k == MT_N - 1) ? nw[0] : od[k + 1];
+    m = (k < H) ? od[k + MT_M] : nw[k - H];
+  }
+}
+__device__ __forceinline__ void mt_produce_wave(const uint32_t* od, uint32_t* nw, int lane) {
+  constexpr int STEPS = (MT_N + 63) / 64;
+  uint32_t u = 0, v = 0, m = 0, u1 = 0, v1 = 0, m1 = 0;
+  mt_fetch(od, nw, lane, u, v, m);
+#pragma unroll
+  for (int c = 0; c < STEPS; ++c) {
+    const int k = c * 64 + lane;
+    if (c + 1 < STEPS) mt_fetch(od, nw, k + 64, u1, v1, m1);
+    if (k < MT_N) nw[k] = m ^ mt_twist(u, v);
+    asm volatile("" ::: "memory");
+    u = u1; v = v1; m = m1;
+  }
+}
+
+// The serial chain (wave 0) is kept free of everything else: waves 1..3 temper and store block i while wave 0 makes
+// block i+1 (one workgroup barrier per block); progress is published every MT_PUBLISH_EVERY blocks, and the stop word is
+// polled one period ahead so that nobody ever waits for that load.
 __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restrict__ state, int* ctl, float* __restrict__ out,
                                                         uint32_t* __restrict__ raw, int cap_total) {
   __shared__ __attribute__((aligned(16))) uint32_t buf[2][MT_N];
   __shared__ int stop_sh;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < MT_N; i += 256) { const uint32_t v = state[i]; buf[0][i] = v; raw[i] = v; }
   const int left = (int)state[MT_N], next = (int)state[MT_N + 1];
+  if (tid == 0) stop_sh = -1;
   __syncthreads();
   int avail = left - 1;
   if (avail < 0) avail = 0;
@@ -116,28 +149,34 @@ __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restri
   const int base = MT_N - avail;
   for (int i = tid; i < avail; i += 256)
     __hip_atomic_store(out + base + i, mt_uniform(buf[0][next + i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int done = avail, cur = 0, blk = 0, stop = -1;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(ctl + 0, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  while (done < cap_total) {
-    if (tid == 0) stop_sh = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    stop = stop_sh;
-    if (stop >= 0 && done >= stop) break;
-    for (int rep = 0; rep < MT_PUBLISH_EVERY && done < cap_total; ++rep) {
-      mt_generate(buf[cur], buf[cur ^ 1], tid);         // ends with a barrier
-      cur ^= 1; ++blk;
-      if (tid < MT_N / 4) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&buf[cur][tid * 4]);
-        *reinterpret_cast<uint4*>(raw + blk * MT_N + tid * 4) = v;      // read only after this kernel ended: plain store
-        store_sc1_x4(out + blk * MT_N + tid * 4, mt_uniform(v.x), mt_uniform(v.y), mt_uniform(v.z), mt_uniform(v.w));
+  int cur = 0, stop_pending = -1;
+  // top of iteration i: blocks 1..i-1 are stored, block i sits in buf[cur] (block 0 = the entry state)
+  for (int i = 0;; ++i) {
+    const int covered = avail + (i > 0 ? i - 1 : 0) * MT_N;
+    const bool more = covered < cap_total;
+    if ((i % MT_PUBLISH_EVERY) == 0 || !more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores (and the pending poll) ...
+      if (tid == 64) stop_sh = stop_pending;
+      __syncthreads();                                    // ... the workgroup meets ...
+      if (tid == 64) {                                    // ... one lane publishes and polls for the next period
+        __hip_atomic_store(ctl + 0, covered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stop_pending = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      done += MT_N;
+      const int stop = stop_sh;
+      if (!more || (stop >= 0 && covered >= stop)) break;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
-    __syncthreads();                                    // ... the workgroup meets ...
-    if (tid == 0) __hip_atomic_store(ctl + 0, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... one lane publishes
+    if (wave == 0) {
+      mt_produce_wave(buf[cur], buf[cur ^ 1], lane);
+    } else if (i >= 1) {
+      const int g = tid - 64;                             // 156 groups of four words
+      if (g < MT_N / 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&buf[cur][g * 4]);
+        *reinterpret_cast<uint4*>(raw + i * MT_N + g * 4) = v;          // read only after this kernel ended: plain store
+        store_sc1_x4(out + i * MT_N + g * 4, mt_uniform(v.x), mt_uniform(v.y), mt_uniform(v.z), mt_uniform(v.w));
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
   }
 }
 
