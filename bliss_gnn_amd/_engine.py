@@ -12,6 +12,8 @@ never).  PyTorch is used for device memory and the current stream only.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -40,7 +42,7 @@ class _LayerWs:
     def __init__(self, dev, cap_s, cap_c):
         self.cap_s, self.cap_c = cap_s, cap_c
         self.seg_ptr = torch.empty(cap_s + 1, dtype=torch.int32, device=dev)
-        self.seed_acc = torch.empty(32 * cap_s, dtype=torch.uint8, device=dev)
+        self.seed_acc = torch.empty(40 * cap_s, dtype=torch.uint8, device=dev)
         self.cand_nid = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.new_id = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
@@ -69,6 +71,16 @@ class LayerEngine:
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
+        # binned candidate pipeline (csrc/sampler.hip): LDS-resident per-source reductions when |V| / n_bins slots fit in
+        # 64 KiB; otherwise (or with BLISS_BINS=0) the memory-side atomic passes.  Scratch shared by all layers.
+        self.n_bins = 0
+        for nb in (256, 1024):
+            if -(-V // nb) * 12 <= 64 * 1024:
+                self.n_bins = nb
+                break
+        if os.environ.get("BLISS_BINS", "1") == "0":
+            self.n_bins = 0
+        self._bins = None
         self.hist = torch.zeros(32768, dtype=torch.int32, device=dev)      # self-cleaning (k_poisson_scale)
         self.mt_dev = torch.empty(626, dtype=torch.int32, device=dev)
         self.mt_host = torch.empty(626, dtype=torch.int32).pin_memory()        # state handed to the device
@@ -106,9 +118,25 @@ class LayerEngine:
             self.rng_raw = torch.empty(624 * (self.rng_cap // 624 + 3), dtype=torch.int32, device=dev)
             self.rng_ctl = torch.zeros(8 + len(fan), dtype=torch.int32, device=dev)     # ctl[8] + per-layer offsets
 
+    def _bin_buffers(self):
+        if self._bins is None:
+            dev, nb = self.g.device, self.n_bins
+            cap = int(1.25 * self.Eg / nb) + 8192
+            words = (-(-self.Eg // 4096) + 1) * 128 + 4
+            self._bins = dict(cap=cap, cursor=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
+                              rec=torch.empty(nb * cap, dtype=torch.int64, device=dev),
+                              t=torch.empty(nb * cap, dtype=torch.bfloat16, device=dev),
+                              bitmap=torch.zeros(words, dtype=torch.int32, device=dev),
+                              prefix=torch.empty(words, dtype=torch.int32, device=dev),
+                              tkey=torch.empty(self.V, dtype=torch.int64, device=dev),
+                              tsum=torch.empty(self.V, dtype=torch.int64, device=dev))
+        return self._bins
+
     def _grow(self, errs):
         for n, e in enumerate(errs):
             c = self.caps[n]
+            if e & 2 and self.n_bins:       # a bin overflowed (extremely skewed source ids): use the atomic passes
+                self.n_bins = 0
             if e & 64:
                 c["S"] = min(self.V, 2 * c["S"])
             if e & 4:
@@ -168,7 +196,7 @@ class LayerEngine:
                 bad |= e
             if bad & ~_CAP_ERRS:
                 raise RuntimeError(f"sampler kernel error 0x{bad:x}: {_lib.err_string(bad)}")
-            if bad & 2:
+            if bad & 2 and not self.n_bins:
                 raise RuntimeError("candidate capacity exceeded / seed id out of range")
             if bad == 0:
                 break
@@ -266,6 +294,12 @@ class LayerEngine:
                             ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
                             kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
                             ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
+        if self.n_bins:
+            b = self._bin_buffers()
+            c_ws.n_bins, c_ws.bin_cap = self.n_bins, b["cap"]
+            c_ws.bin_cursor, c_ws.bin_rec, c_ws.bin_t = b["cursor"].data_ptr(), b["rec"].data_ptr(), b["t"].data_ptr()
+            c_ws.bitmap, c_ws.word_prefix = b["bitmap"].data_ptr(), b["prefix"].data_ptr()
+            c_ws.touched_key, c_ws.touched_sum = b["tkey"].data_ptr(), b["tsum"].data_ptr()
         c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),
                               b_w.data_ptr(), b_q.data_ptr(), _ptr(t_indptr), _ptr(t_edge), _ptr(t_scr), cb)
         lay = (b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, counts[10 * n:10 * n + 10], t_indptr, t_edge)

@@ -6,7 +6,8 @@
 enum BlissKernelId {
   BK_SEG_SCAN = 0, BK_PASS1, BK_PASS2, BK_CHUNK_SCAN, BK_PASS3, BK_CAND_FINALIZE, BK_POISSON_SCALE, BK_SELECT1, BK_SELECT2,
   BK_BLOCK1, BK_INDPTR_SCAN, BK_BLOCK2, BK_CLEANUP, BK_MT19937, BK_SPMM_FWD, BK_SPMM_BWD, BK_EMBED_NORM, BK_EXP3_UPDATE,
-  BK_EXP3_APPLY, BK_NORMALIZE, BK_ROW_SUM, BK_NORM_EDATA, BK_TRANSPOSE, BK_SPMM_FIXUP, BK_COUNT
+  BK_EXP3_APPLY, BK_NORMALIZE, BK_ROW_SUM, BK_NORM_EDATA, BK_TRANSPOSE, BK_SPMM_FIXUP, BK_COL_SUMS, BK_BIN_SCATTER, BK_BIN_REDUCE,
+  BK_BITMAP_SCAN, BK_CAND_NUMBER, BK_COUNT
 };
 
 extern int g_bliss_prof_sel;                       // -2 off, -1 all, >= 0 one kernel id

@@ -16,7 +16,8 @@ const char* kNames[BK_COUNT] = {
   "k_seg_scan", "k_frontier_pass1", "k_frontier_pass2", "k_chunk_scan", "k_frontier_pass3", "k_cand_finalize", "k_poisson_scale",
   "k_select_pass1", "k_select_pass2", "k_block_pass1", "k_indptr_scan", "k_block_pass2", "k_cleanup", "k_mt19937_uniform",
   "k_spmm_fwd", "k_spmm_bwd", "k_embed_norm", "k_exp3_update", "k_exp3_apply", "k_normalize_row", "k_row_sum",
-  "k_normalized_edata", "k_block_transpose", "k_spmm_fixup"};
+  "k_normalized_edata", "k_block_transpose", "k_spmm_fixup", "k_col_sums", "k_bin_scatter", "k_bin_reduce", "k_bitmap_scan",
+  "k_cand_number"};
 thread_local Pair t_cur;
 
 void drain_locked() {

@@ -80,12 +80,15 @@ __device__ __forceinline__ bf16_t edge_q(bf16_t w, bf16_t wsum, int n, float eta
 __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
                                                    LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
                                                    unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
-                                                   int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k) {
+                                                   int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
+                                                   int* __restrict__ bin_cursor, int n_bins) {
   __shared__ int sh[17];
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
-  for (int i = threadIdx.x; i < cap_s * 4; i += blockDim.x) seed_acc[i] = 0ull;   // acc_w, acc_q, acc_wt (u64) + deg_blk (i32)
+  // acc_w, acc_q, acc_wt (u64) + deg_blk (i32) + seed_p2 (u64)
+  for (int i = threadIdx.x; i < cap_s * 5; i += blockDim.x) seed_acc[i] = 0ull;
+  if (bin_cursor) for (int i = threadIdx.x; i <= n_bins; i += blockDim.x) bin_cursor[i] = 0;   // [n_bins] = touched count
   if (src_cnt) for (int i = threadIdx.x; i <= cap_k; i += blockDim.x) src_cnt[i] = 0;
   long long run = 0;
   for (int base = 0; base < S; base += blockDim.x) {
@@ -301,6 +304,284 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
     else pj = f2bf(sqrtf(bf2f(fixed_to_bf((int64_t)raw, FRAC_SRC, &bad))));   // :75 torch.sqrt(prob)
     p[id] = pj;
     if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;   // sign bit set = negative / -0 cannot occur
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) {
+    int v = lh[b];
+    if (v) atomicAdd(hist + b, v);
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// ================================================================ binned candidate pipeline
+// The passes above spend their time in scattered memory-side atomics: one atomicMin (first appearance) and one 64-bit
+// atomicAdd (sum of squares) per frontier edge, ~14 edges per candidate on a Reddit-like layer, at the ~20 G atomics/s
+// the memory side sustains.  When |V| / n_bins node slots fit in LDS the same two reductions are done there instead:
+//   k_col_sums     one workgroup per seed column: sum_j w_ij, then sum_k q_ik with the column held in registers
+//   k_bin_scatter  every edge becomes a record (position, source, (q/sum q)^2), multisplit in LDS by source % n_bins and
+//                  appended to its bin with ONE global atomic per (workgroup, bin)
+//   k_bin_reduce   one workgroup per bin: min position and exact fixed-point sum per source with LDS atomics; sets one
+//                  bit per first appearance in a bitmap over frontier positions and lists the touched sources
+//   k_bitmap_scan  prefix popcount of the bitmap => rank of every first appearance (the candidate order)
+//   k_cand_number  numbers the candidates, p_j = sqrt(sum), histogram for the Poisson scale
+// Integer sums and minima are order-free, so the results are bit-identical to the atomic passes.
+#define BIN_ITEMS 16
+#define BIN_BATCH (TPB * BIN_ITEMS)          // frontier positions per workgroup step: 4096
+#define MAX_BINS 1024
+#define COL_TPB 512
+#define COL_R 4
+#define BINRED_TPB 512
+
+template <int NT>
+__device__ __forceinline__ long long block_sum_i64(long long v, long long* sh) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int lo = __shfl_down((int)(v & 0xffffffffll), d), hi = __shfl_down((int)(v >> 32), d);
+    v += ((long long)hi << 32) | (unsigned)lo;
+  }
+  __syncthreads();                                    // sh free again
+  if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  long long t = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += sh[w];
+  return t;
+}
+
+__global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
+                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                      unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
+                                                      float eta_f, float ome_f) {
+  __shared__ long long sh[COL_TPB / 64];
+  const int S = cnt->S, tid = threadIdx.x;
+  if (cnt->E == 0) return;
+  int bad = 0;
+  for (int k = blockIdx.x; k < S; k += gridDim.x) {
+    const int n = seg_ptr[k + 1] - seg_ptr[k];
+    if (n == 0) continue;                             // block-uniform; the accumulators stay 0
+    const int64_t p0 = indptr[seeds[k]];
+    bf16_t wr[COL_R];
+    long long part = 0;
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r) {
+      const int i = tid + r * COL_TPB;
+      wr[r] = 0;
+      if (i < n) { wr[r] = w[p0 + i]; part += bf_to_fixed(wr[r], FRAC_DST, &bad); }          // :129 copy_e_sum over exp3 weights
+    }
+    for (int i = tid + COL_R * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], FRAC_DST, &bad);
+    const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
+    const bf16_t wsum = fixed_to_bf(ws_fixed, FRAC_DST, &bad);
+    part = 0;
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r) {
+      const int i = tid + r * COL_TPB;
+      if (i < n) part += bf_to_fixed(edge_q(wr[r], wsum, n, eta_f, ome_f), FRAC_DST, &bad);  // :67 copy_e_sum(insg, edge_prob)
+    }
+    for (int i = tid + COL_R * COL_TPB; i < n; i += COL_TPB)
+      part += bf_to_fixed(edge_q(w[p0 + i], wsum, n, eta_f, ome_f), FRAC_DST, &bad);
+    const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
+    if (tid == 0) { acc_w[k] = (unsigned long long)ws_fixed; acc_q[k] = (unsigned long long)qs_fixed; }
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+template <bool BANDIT>
+__global__ void __launch_bounds__(TPB) k_bin_scatter(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+                                                     const bf16_t* __restrict__ w, const int* __restrict__ seeds,
+                                                     const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                     const unsigned long long* __restrict__ acc_w,
+                                                     const unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
+                                                     int uniform_nodes, int n_bins, long long bin_cap, int* bin_cursor,
+                                                     unsigned long long* __restrict__ bin_rec, bf16_t* __restrict__ bin_t,
+                                                     unsigned* __restrict__ bitmap) {
+  __shared__ int hist[MAX_BINS];
+  __shared__ int gbase[MAX_BINS];
+  const int S = cnt->S, E = cnt->E, tid = threadIdx.x;
+  const int nb = (E + BIN_BATCH - 1) / BIN_BATCH;
+  const int bmask = n_bins - 1;
+  int bad = 0;
+  for (int batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+    for (int b = tid; b < n_bins; b += TPB) hist[b] = 0;
+    if (tid < BIN_BATCH / 32) bitmap[batch * (BIN_BATCH / 32) + tid] = 0u;      // this batch's slice of the first-appearance bitmap
+    __syncthreads();
+    int srcs[BIN_ITEMS], ranks[BIN_ITEMS];
+    bf16_t ts[BIN_ITEMS];
+    int hint = -1;
+    const int wbase = batch * BIN_BATCH + (tid >> 6) * (64 * BIN_ITEMS);       // a wave owns 1024 consecutive positions
+#pragma unroll
+    for (int j = 0; j < BIN_ITEMS; ++j) {
+      ranks[j] = -1; srcs[j] = 0; ts[j] = 0;
+      const int base = wbase + j * 64;
+      if (base >= E) continue;                                                  // wave-uniform
+      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      if (a.k >= 0) {
+        bf16_t t;
+        if (uniform_nodes) {
+          t = (bf16_t)0x3f80;                           // importance_sampling=False (:77-81): only "has an out-edge" matters
+        } else if (BANDIT) {
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
+          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
+          bf16_t qsum = fixed_to_bf((int64_t)acc_q[a.k], FRAC_DST, &bad);
+          float r = rbf(bf2f(q) / bf2f(qsum));          // :71 e_div_u on the reversed frontier
+          t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
+        } else {
+          float x = bf2f(w[a.pos]);                     // ladies_sampler.py:46-47  weight ** 2
+          t = f2bf(x * x);
+        }
+        srcs[j] = a.src; ts[j] = t;
+        ranks[j] = atomicAdd(&hist[a.src & bmask], 1);
+      }
+    }
+    __syncthreads();
+    for (int b = tid; b < n_bins; b += TPB) {
+      const int h = hist[b];
+      int g0 = 0;
+      if (h) {
+        g0 = atomicAdd(bin_cursor + b, h);
+        if ((long long)g0 + h > bin_cap) bad |= BLISS_ERR_CAP_CAND;
+      }
+      gbase[b] = g0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BIN_ITEMS; ++j) {
+      if (ranks[j] >= 0) {
+        const int b = srcs[j] & bmask;
+        const long long idx = (long long)gbase[b] + ranks[j];
+        if (idx < bin_cap) {
+          const size_t o = (size_t)b * (size_t)bin_cap + (size_t)idx;
+          const unsigned e = (unsigned)(wbase + j * 64 + lane_id());
+          bin_rec[o] = ((unsigned long long)e << 32) | (unsigned)srcs[j];
+          bin_t[o] = ts[j];
+        }
+      }
+    }
+    __syncthreads();                                    // hist / gbase are reused by the next batch
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+__global__ void __launch_bounds__(BINRED_TPB) k_bin_reduce(LayerCounts* cnt, int n_bins, int log2_bins, long long bin_cap,
+                                                           int* bin_cursor, const unsigned long long* __restrict__ bin_rec,
+                                                           const bf16_t* __restrict__ bin_t, int num_nodes, int slots,
+                                                           const int* __restrict__ local_id, unsigned long long* __restrict__ seed_p2,
+                                                           unsigned long long* __restrict__ touched_key,
+                                                           unsigned long long* __restrict__ touched_sum, unsigned* bitmap, int cap_c) {
+  extern __shared__ unsigned long long dyn_lds[];
+  unsigned long long* sm = dyn_lds;                    // [slots] exact sum of (q / sum q)^2 per source of this bin
+  unsigned* mn = (unsigned*)(dyn_lds + slots);         // [slots] first frontier position per source
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (cnt->E == 0) return;
+  const int ne = b < num_nodes ? ((num_nodes - 1 - b) >> log2_bins) + 1 : 0;   // nodes v with v % n_bins == b
+  for (int i = tid; i < ne; i += BINRED_TPB) { sm[i] = 0ull; mn[i] = 0xffffffffu; }
+  __syncthreads();
+  long long n = bin_cursor[b];
+  if (n > bin_cap) n = bin_cap;
+  const unsigned long long* rec = bin_rec + (size_t)b * (size_t)bin_cap;
+  const bf16_t* tt = bin_t + (size_t)b * (size_t)bin_cap;
+  int bad = 0;
+  for (long long i = tid; i < n; i += BINRED_TPB) {
+    const unsigned long long r = rec[i];
+    const int li = (int)((unsigned)r >> log2_bins);
+    atomicMin(&mn[li], (unsigned)(r >> 32));
+    const int64_t fx = bf_to_fixed(tt[i], FRAC_SRC, &bad);
+    if (fx) atomicAdd(&sm[li], (unsigned long long)fx);                         // :73 copy_e_sum by SOURCE
+  }
+  __syncthreads();
+  int* touched_n = bin_cursor + n_bins;
+  for (int base = 0; base < ne; base += BINRED_TPB) {
+    const int li = base + tid;
+    bool is_cand = false;
+    unsigned fp = 0, src = 0;
+    if (li < ne) {
+      fp = mn[li];
+      if (fp != 0xffffffffu) {
+        src = ((unsigned)li << log2_bins) | (unsigned)b;
+        const int lid = local_id[src];
+        if (lid >= 0) seed_p2[lid] = sm[li];            // a seed: numbered already, only its sum is needed
+        else is_cand = true;
+      }
+    }
+    const unsigned long long mask = __ballot(is_cand);
+    if (mask) {
+      int g0 = 0;
+      const int leader = __ffsll((long long)mask) - 1;
+      if (lane_id() == leader) g0 = atomicAdd(touched_n, __popcll(mask));
+      g0 = __shfl(g0, leader);
+      if (is_cand) {
+        const int j = g0 + __popcll(mask & ((1ull << lane_id()) - 1ull));
+        if (j < cap_c) { touched_key[j] = ((unsigned long long)fp << 32) | src; touched_sum[j] = sm[li]; }
+        atomicOr(bitmap + (fp >> 5), 1u << (fp & 31u));
+      }
+    }
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+#define BSCAN_W 8                                       // bitmap words per thread and step
+__global__ void __launch_bounds__(1024) k_bitmap_scan(const unsigned* __restrict__ bitmap, int* __restrict__ word_prefix,
+                                                      LayerCounts* cnt, int cap_c) {
+  __shared__ int sh[17];
+  const int nw = (cnt->E + 31) >> 5;                   // the bitmap is allocated (and zeroed) in whole 128-word batches
+  int run = 0;
+  for (int base = 0; base < nw; base += 1024 * BSCAN_W) {
+    const int i = base + threadIdx.x * BSCAN_W;
+    int c[BSCAN_W], tot = 0;
+#pragma unroll
+    for (int u = 0; u < BSCAN_W; u += 4) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i + u < nw) v = *reinterpret_cast<const uint4*>(bitmap + i + u);      // nw rounds up to a multiple of 4 inside the allocation
+      c[u] = __popc(v.x); c[u + 1] = __popc(v.y); c[u + 2] = __popc(v.z); c[u + 3] = __popc(v.w);
+      tot += c[u] + c[u + 1] + c[u + 2] + c[u + 3];
+    }
+    int total, ex = block_excl_scan(tot, sh, &total);
+    int acc = run + ex;
+#pragma unroll
+    for (int u = 0; u < BSCAN_W; ++u) {
+      if (i + u < nw) word_prefix[i + u] = acc;
+      acc += c[u];
+    }
+    run += total;
+  }
+  if (threadIdx.x == 0) {
+    int total = cnt->S + run;
+    if (total > cap_c) { atomicOr(&cnt->err, BLISS_ERR_CAP_CAND); total = cap_c; }
+    cnt->C = total;
+  }
+}
+
+__global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
+                                                         int* local_id, const unsigned long long* __restrict__ seed_p2,
+                                                         const unsigned long long* __restrict__ touched_key,
+                                                         const unsigned long long* __restrict__ touched_sum,
+                                                         const unsigned* __restrict__ bitmap, const int* __restrict__ word_prefix,
+                                                         bf16_t* __restrict__ p, int* hist, int cap_c, int uniform_nodes) {
+  __shared__ int lh[HIST_BINS];                       // 128 KiB static LDS (one workgroup per CU; gfx950 has 160 KiB)
+  const int S = cnt->S;
+  const int C = min(cnt->C, cap_c);
+  if ((int)blockIdx.x * FIN_TPB >= C) return;
+  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) lh[b] = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int i = blockIdx.x * FIN_TPB + threadIdx.x; i < C; i += gridDim.x * FIN_TPB) {
+    int id;
+    unsigned long long raw;
+    if (i < S) {
+      id = i; raw = seed_p2[i];
+      cand_nid[i] = seeds[i];
+    } else {
+      const unsigned long long key = touched_key[i - S];
+      raw = touched_sum[i - S];
+      const unsigned fp = (unsigned)(key >> 32), g = (unsigned)key;
+      id = S + word_prefix[fp >> 5] + __popc(bitmap[fp >> 5] & ((1u << (fp & 31u)) - 1u));   // rank of the first appearance
+      if (id >= cap_c) continue;
+      local_id[g] = id; cand_nid[id] = (int)g;
+    }
+    bf16_t pj;
+    if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;            // :79-81 ones, 0 where out_degree == 0
+    else pj = f2bf(sqrtf(bf2f(fixed_to_bf((int64_t)raw, FRAC_SRC, &bad))));   // :75 torch.sqrt(prob)
+    p[id] = pj;
+    if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) {
@@ -756,8 +1037,40 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   unsigned long long* acc_q = acc_w + cap_s;                                // [cap_s]
   if (frontier_bound < 1) frontier_bound = 1;
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
+  const bool binned = ws->n_bins > 0;
+  int log2_bins = 0, slots = 0;
+  if (binned) {
+    while ((1 << log2_bins) < ws->n_bins) ++log2_bins;
+    slots = (g->num_nodes + ws->n_bins - 1) >> log2_bins;
+    if ((1 << log2_bins) != ws->n_bins || ws->n_bins > MAX_BINS || (size_t)slots * 12 > 64 * 1024 || ws->bin_cap <= 0 ||
+        !ws->bin_cursor || !ws->bin_rec || !ws->bin_t || !ws->bitmap || !ws->word_prefix || !ws->touched_key || !ws->touched_sum)
+      return BLISS_EINVAL;
+  }
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
-                                                            m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k));
+                                                            m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
+                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins));
+  if (binned) {
+    unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
+    unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
+    const int gb = grid_for(frontier_bound, BIN_BATCH);
+    if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f));
+    if (mode == BLISS_MODE_BANDIT)
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
+    else
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
+    PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
+        cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (const bf16_t*)ws->bin_t, g->num_nodes, slots, m->local_id, seed_p2,
+        (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
+    PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_scan<<<1, 1024, 0, st>>>(ws->bitmap, ws->word_prefix, cnt, ws->cap_c));
+    int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);
+    if (gf < 1) gf = 1;
+    if (gf > 256) gf = 256;
+    PROF_LAUNCH(BK_CAND_NUMBER, st, k_cand_number<<<gf, FIN_TPB, 0, st>>>(
+        seeds, cnt, ws->cand_nid, m->local_id, seed_p2, (const unsigned long long*)ws->touched_key,
+        (const unsigned long long*)ws->touched_sum, ws->bitmap, ws->word_prefix, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
+    return (int)hipGetLastError();
+  }
   if (mode == BLISS_MODE_BANDIT) {
     PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
     PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));

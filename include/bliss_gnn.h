@@ -63,7 +63,7 @@ typedef struct {
 typedef struct {
   void* counts;             /* bliss_layer_counts_t */
   int32_t* seg_ptr;         /* [cap_s + 1] start of every seed's column in the frontier */
-  void* seed_acc;           /* [32 * cap_s bytes] exact per-seed accumulators */
+  void* seed_acc;           /* [40 * cap_s bytes] exact per-seed accumulators */
   int32_t* chunk_cnt;       /* [max(frontier_bound, cap_c) / 1024 + 2] */
   int32_t* cand_nid;        /* [cap_c] global id of every candidate, seeds first (ndata[NID]) */
   void* p;                  /* bf16 [cap_c] LADIES importance p_j */
@@ -74,6 +74,18 @@ typedef struct {
   int32_t* hist;            /* [32768] counts per bf16 bit pattern of p; zero on entry, left zero */
   int32_t* src_cnt;         /* [cap_k + 1] edges per block source / fill cursor of the by-source index, or NULL */
   int32_t cap_c, cap_k;
+  /* Binned candidate pipeline (optional; n_bins = 0 selects the atomic passes, which need no extra memory).
+   * n_bins: power of two <= 1024 with ceil(num_nodes / n_bins) * 12 bytes <= 64 KiB of LDS.  The buffers may be shared
+   * by all layers of a call (they are dead once bliss_frontier_prob's kernels have run). */
+  int32_t n_bins;
+  int64_t bin_cap;          /* records per bin; a bin that overflows raises BLISS_ERR_CAP_CAND */
+  int32_t* bin_cursor;      /* [n_bins + 1] */
+  uint64_t* bin_rec;        /* [n_bins * bin_cap] (frontier position << 32 | source id) */
+  void* bin_t;              /* bf16 [n_bins * bin_cap] the edge's term of p_j^2 */
+  uint32_t* bitmap;         /* [frontier_bound / 32 rounded up to 128 words, + 4] first appearances by frontier position */
+  int32_t* word_prefix;     /* [same length] exclusive popcount prefix of the bitmap words */
+  uint64_t* touched_key;    /* [cap_c] (first position << 32 | source id) of every non-seed frontier source */
+  uint64_t* touched_sum;    /* [cap_c] its exact sum */
 } bliss_layer_ws_t;
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */

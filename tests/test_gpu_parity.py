@@ -846,3 +846,43 @@ def test_prepared_graph_feeds_the_sampler(cuda):
     assert torch.equal(inp.cpu().long(), o_inp)
     for b, ob in zip(blocks, o_blocks):
         assert torch.equal(b.src.cpu().long(), ob.src) and torch.equal(b.edata["_ID"].cpu().long(), ob.eid)
+
+
+@pytest.mark.parametrize("name", ["synth1_poisson_bandit", "synth0_poisson_bandit_uniform_nodes", "synth2_poisson_ladies"])
+def test_atomic_candidate_passes_still_match(cuda, name, monkeypatch):
+    """The binned candidate pipeline is the default; BLISS_BINS=0 selects the memory-side atomic passes (the path for
+    graphs whose |V| / 1024 node slots exceed the LDS).  Both must reproduce the reference run."""
+    monkeypatch.setenv("BLISS_BINS", "0")
+    if "ladies" in name:
+        test_poisson_ladies_golden(cuda, name)
+    else:
+        test_poisson_bandit_golden(cuda, name)
+
+
+def test_binned_and_atomic_paths_agree_on_a_larger_graph(cuda, monkeypatch):
+    """Same blocks from both candidate pipelines on a graph big enough for many workgroups per kernel (several 4096-edge
+    batches, hubs with thousands of appearances) and with 1024 bins forced by the node count."""
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    V = 300000                                       # > 256 * 5461 / ... no: 300000 / 256 = 1172 slots -> 256 bins
+    ip, ix, ei = chung_lu_csc(V, 3000000, seed=4)
+    seeds = torch.randperm(V, generator=torch.Generator().manual_seed(5))[:512].to(torch.int32).to(cuda)
+    out = []
+    for bins in ("1", "0"):
+        monkeypatch.setenv("BLISS_BINS", bins)
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler([2000, 1000], importance_sampling=1, node_embedding="features", num_steps=10,
+                                                eta=0.1, model="sage")
+        torch.manual_seed(11)
+        inp, _, blocks = sampler.sample_blocks(g, seeds)
+        assert (sampler._engine.n_bins > 0) == (bins == "1")
+        out.append((inp, blocks))
+    assert torch.equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a._counts.C == b._counts.C and a._counts.E == b._counts.E and a._counts.c == b._counts.c
+        for f in ("src", "dst", "pos"):
+            assert torch.equal(getattr(a, f), getattr(b, f))
+        assert torch.equal(a._trace["cand_nid"], b._trace["cand_nid"])
+        assert torch.equal(a._trace["p"].view(torch.int16), b._trace["p"].view(torch.int16))
+        assert torch.equal(a.edata["edge_weights"].view(torch.int16), b.edata["edge_weights"].view(torch.int16))
