@@ -78,7 +78,7 @@ class LayerEngine:
             if -(-V // nb) * 12 <= 64 * 1024:
                 self.n_bins = nb
                 break
-        if os.environ.get("BLISS_BINS", "1") == "0":
+        if os.environ.get("BLISS_BINS", "1") == "0" or self.Eg > 2048 * 4096 * 32:     # (bitmap tiles: MAX_TILES in sampler.hip)
             self.n_bins = 0
         self._bins = None
         self.hist = torch.zeros(32768, dtype=torch.int32, device=dev)      # self-cleaning (k_poisson_scale)
@@ -127,7 +127,7 @@ class LayerEngine:
                               rec=torch.empty(nb * cap, dtype=torch.int64, device=dev),
                               t=torch.empty(nb * cap, dtype=torch.bfloat16, device=dev),
                               bitmap=torch.zeros(words, dtype=torch.int32, device=dev),
-                              prefix=torch.empty(words, dtype=torch.int32, device=dev),
+                              prefix=torch.empty(words + 2048, dtype=torch.int32, device=dev),
                               tkey=torch.empty(self.V, dtype=torch.int64, device=dev),
                               tsum=torch.empty(self.V, dtype=torch.int64, device=dev))
         return self._bins

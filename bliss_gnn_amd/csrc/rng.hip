@@ -108,7 +108,7 @@ __device__ __forceinline__ void store_sc1_x4(float* p, float a, float b, float c
 // program order is all the synchronisation the recurrence needs: no barrier inside a block.
 // The cross-lane dependencies through LDS are invisible to the compiler (a lane never re-reads its own addresses), so a
 // compiler barrier after every step pins the program order the hardware then honours (a wave's DS operations execute in
-// order).  The operands of step c+1 never depend on the store of step c, so they are fetched ahead of it.
+// order).
 __device__ __forceinline__ void mt_fetch(const uint32_t* od, const uint32_t* nw, int k, uint32_t& u, uint32_t& v, uint32_t& m) {
   constexpr int H = MT_N - MT_M;   // 227
   if (k < MT_N) {
@@ -118,27 +118,32 @@ __device__ __forceinline__ void mt_fetch(const uint32_t* od, const uint32_t* nw,
   }
 }
 __device__ __forceinline__ void mt_produce_wave(const uint32_t* od, uint32_t* nw, int lane) {
+  // word k of step c+2 reads nw[k-227], written by steps <= c-1: its operands can be fetched before the store of step c,
+  // which keeps two LDS round trips in flight (the chain is latency-bound, not issue-bound)
   constexpr int STEPS = (MT_N + 63) / 64;
-  uint32_t u = 0, v = 0, m = 0, u1 = 0, v1 = 0, m1 = 0;
+  uint32_t u = 0, v = 0, m = 0, u1 = 0, v1 = 0, m1 = 0, u2 = 0, v2 = 0, m2 = 0;
   mt_fetch(od, nw, lane, u, v, m);
+  mt_fetch(od, nw, lane + 64, u1, v1, m1);
 #pragma unroll
   for (int c = 0; c < STEPS; ++c) {
     const int k = c * 64 + lane;
-    if (c + 1 < STEPS) mt_fetch(od, nw, k + 64, u1, v1, m1);
+    if (c + 2 < STEPS) mt_fetch(od, nw, k + 128, u2, v2, m2);
     if (k < MT_N) nw[k] = m ^ mt_twist(u, v);
     asm volatile("" ::: "memory");
     u = u1; v = v1; m = m1;
+    u1 = u2; v1 = v2; m1 = m2;
   }
 }
 
 // The serial chain (wave 0) is kept free of everything else: waves 1..3 temper and store block i while wave 0 makes
-// block i+1 (one workgroup barrier per block); progress is published every MT_PUBLISH_EVERY blocks, and the stop word is
-// polled one period ahead so that nobody ever waits for that load.
+// block i+1 (one workgroup barrier per block); progress is published every MT_PUBLISH_EVERY blocks, one period late, and
+// the stop word is polled one period ahead, so that neither the write-through stores nor that load are ever waited for.
 __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restrict__ state, int* ctl, float* __restrict__ out,
                                                         uint32_t* __restrict__ raw, int cap_total) {
   __shared__ __attribute__((aligned(16))) uint32_t buf[2][MT_N];
   __shared__ int stop_sh;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __builtin_amdgcn_s_setprio(3);      // the chain shares its SIMD with the sampler's waves: let the arbiter pick it first
   for (int i = tid; i < MT_N; i += 256) { const uint32_t v = state[i]; buf[0][i] = v; raw[i] = v; }
   const int left = (int)state[MT_N], next = (int)state[MT_N + 1];
   if (tid == 0) stop_sh = -1;
@@ -149,19 +154,24 @@ __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restri
   const int base = MT_N - avail;
   for (int i = tid; i < avail; i += 256)
     __hip_atomic_store(out + base + i, mt_uniform(buf[0][next + i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int cur = 0, stop_pending = -1;
+  int cur = 0, stop_pending = -1, published_next = avail, covered = avail;
   // top of iteration i: blocks 1..i-1 are stored, block i sits in buf[cur] (block 0 = the entry state)
   for (int i = 0;; ++i) {
-    const int covered = avail + (i > 0 ? i - 1 : 0) * MT_N;
+    covered = avail + (i > 0 ? i - 1 : 0) * MT_N;
     const bool more = covered < cap_total;
     if ((i % MT_PUBLISH_EVERY) == 0 || !more) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores (and the pending poll) ...
-      if (tid == 64) stop_sh = stop_pending;
-      __syncthreads();                                    // ... the workgroup meets ...
-      if (tid == 64) {                                    // ... one lane publishes and polls for the next period
-        __hip_atomic_store(ctl + 0, covered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stop_pending = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // Progress is published one period late so that nobody waits for write-through stores on the critical path: a
+      // storing wave issues exactly two stores per block and nothing else, its stores retire in order, so vmcnt(2 *
+      // period) means "everything up to the previous publish point has reached memory".
+      if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MT_PUBLISH_EVERY) : "memory");
+      if (tid == 0) stop_sh = stop_pending;
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(ctl + 0, published_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stop_pending = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // used one period later
       }
+      published_next = covered;
       const int stop = stop_sh;
       if (!more || (stop >= 0 && covered >= stop)) break;
     }
@@ -178,6 +188,9 @@ __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restri
     __syncthreads();
     cur ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // final drain: everything generated is visible ...
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(ctl + 0, covered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and published
 }
 
 // main stream, one wave: wait until the generator has produced the numbers layer `n` needs; hand the layer its offset

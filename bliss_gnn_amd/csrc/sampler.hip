@@ -322,11 +322,12 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 //                  appended to its bin with ONE global atomic per (workgroup, bin)
 //   k_bin_reduce   one workgroup per bin: min position and exact fixed-point sum per source with LDS atomics; sets one
 //                  bit per first appearance in a bitmap over frontier positions and lists the touched sources
-//   k_bitmap_scan  prefix popcount of the bitmap => rank of every first appearance (the candidate order)
+//   k_bitmap_tiles prefix popcount of the bitmap => rank of every first appearance (the candidate order)
 //   k_cand_number  numbers the candidates, p_j = sqrt(sum), histogram for the Poisson scale
 // Integer sums and minima are order-free, so the results are bit-identical to the atomic passes.
-#define BIN_ITEMS 16
-#define BIN_BATCH (TPB * BIN_ITEMS)          // frontier positions per workgroup step: 4096
+#define BIN_TPB 1024
+#define BIN_ITEMS 4
+#define BIN_BATCH (BIN_TPB * BIN_ITEMS)      // frontier positions per workgroup step: 4096 (16 waves keep the loads in flight)
 #define MAX_BINS 1024
 #define COL_TPB 512
 #define COL_R 4
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
 }
 
 template <bool BANDIT>
-__global__ void __launch_bounds__(TPB) k_bin_scatter(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
+__global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                      const bf16_t* __restrict__ w, const int* __restrict__ seeds,
                                                      const int* __restrict__ seg_ptr, LayerCounts* cnt,
                                                      const unsigned long long* __restrict__ acc_w,
@@ -401,13 +402,13 @@ __global__ void __launch_bounds__(TPB) k_bin_scatter(const int64_t* __restrict__
   const int bmask = n_bins - 1;
   int bad = 0;
   for (int batch = blockIdx.x; batch < nb; batch += gridDim.x) {
-    for (int b = tid; b < n_bins; b += TPB) hist[b] = 0;
+    for (int b = tid; b < n_bins; b += BIN_TPB) hist[b] = 0;
     if (tid < BIN_BATCH / 32) bitmap[batch * (BIN_BATCH / 32) + tid] = 0u;      // this batch's slice of the first-appearance bitmap
     __syncthreads();
     int srcs[BIN_ITEMS], ranks[BIN_ITEMS];
     bf16_t ts[BIN_ITEMS];
     int hint = -1;
-    const int wbase = batch * BIN_BATCH + (tid >> 6) * (64 * BIN_ITEMS);       // a wave owns 1024 consecutive positions
+    const int wbase = batch * BIN_BATCH + (tid >> 6) * (64 * BIN_ITEMS);       // a wave owns 256 consecutive positions
 #pragma unroll
     for (int j = 0; j < BIN_ITEMS; ++j) {
       ranks[j] = -1; srcs[j] = 0; ts[j] = 0;
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(TPB) k_bin_scatter(const int64_t* __restrict__
       }
     }
     __syncthreads();
-    for (int b = tid; b < n_bins; b += TPB) {
+    for (int b = tid; b < n_bins; b += BIN_TPB) {
       const int h = hist[b];
       int g0 = 0;
       if (h) {
@@ -488,65 +489,52 @@ __global__ void __launch_bounds__(BINRED_TPB) k_bin_reduce(LayerCounts* cnt, int
     if (fx) atomicAdd(&sm[li], (unsigned long long)fx);                         // :73 copy_e_sum by SOURCE
   }
   __syncthreads();
-  int* touched_n = bin_cursor + n_bins;
-  for (int base = 0; base < ne; base += BINRED_TPB) {
-    const int li = base + tid;
+  // seeds are numbered already: only their sums are needed; what stays marked in mn[] are the new candidates
+  __shared__ int wg_cnt, wg_base;
+  if (tid == 0) wg_cnt = 0;
+  __syncthreads();
+  for (int li = tid; li < ne; li += BINRED_TPB) {
     bool is_cand = false;
-    unsigned fp = 0, src = 0;
-    if (li < ne) {
-      fp = mn[li];
-      if (fp != 0xffffffffu) {
-        src = ((unsigned)li << log2_bins) | (unsigned)b;
-        const int lid = local_id[src];
-        if (lid >= 0) seed_p2[lid] = sm[li];            // a seed: numbered already, only its sum is needed
-        else is_cand = true;
-      }
+    if (mn[li] != 0xffffffffu) {
+      const int lid = local_id[((unsigned)li << log2_bins) | (unsigned)b];
+      if (lid >= 0) { seed_p2[lid] = sm[li]; mn[li] = 0xffffffffu; }
+      else is_cand = true;
     }
     const unsigned long long mask = __ballot(is_cand);
-    if (mask) {
-      int g0 = 0;
-      const int leader = __ffsll((long long)mask) - 1;
-      if (lane_id() == leader) g0 = atomicAdd(touched_n, __popcll(mask));
-      g0 = __shfl(g0, leader);
-      if (is_cand) {
-        const int j = g0 + __popcll(mask & ((1ull << lane_id()) - 1ull));
-        if (j < cap_c) { touched_key[j] = ((unsigned long long)fp << 32) | src; touched_sum[j] = sm[li]; }
-        atomicOr(bitmap + (fp >> 5), 1u << (fp & 31u));
-      }
+    if (mask && lane_id() == 0) atomicAdd(&wg_cnt, __popcll(mask));
+  }
+  __syncthreads();
+  if (tid == 0) { wg_base = wg_cnt ? atomicAdd(bin_cursor + n_bins, wg_cnt) : 0; wg_cnt = 0; }   // ONE global atomic per bin
+  __syncthreads();
+  for (int li = tid; li < ne; li += BINRED_TPB) {
+    const unsigned fp = mn[li];
+    if (fp != 0xffffffffu) {
+      const int j = wg_base + atomicAdd(&wg_cnt, 1);
+      if (j < cap_c) { touched_key[j] = ((unsigned long long)fp << 32) | (((unsigned)li << log2_bins) | (unsigned)b); touched_sum[j] = sm[li]; }
+      atomicOr(bitmap + (fp >> 5), 1u << (fp & 31u));
     }
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
 
-#define BSCAN_W 8                                       // bitmap words per thread and step
-__global__ void __launch_bounds__(1024) k_bitmap_scan(const unsigned* __restrict__ bitmap, int* __restrict__ word_prefix,
-                                                      LayerCounts* cnt, int cap_c) {
+// rank of a first appearance = bits set before it: exclusive popcount prefix per bitmap word inside a tile of 4096 words
+// (one workgroup per tile, no serial loop) + per-tile totals that k_cand_number prefixes itself
+#define BTILE_W 4                                       // bitmap words per thread
+#define BTILE (1024 * BTILE_W)
+#define MAX_TILES 2048
+__global__ void __launch_bounds__(1024) k_bitmap_tiles(const unsigned* __restrict__ bitmap, int* __restrict__ word_prefix,
+                                                       int* __restrict__ tile_sum, LayerCounts* cnt) {
   __shared__ int sh[17];
   const int nw = (cnt->E + 31) >> 5;                   // the bitmap is allocated (and zeroed) in whole 128-word batches
-  int run = 0;
-  for (int base = 0; base < nw; base += 1024 * BSCAN_W) {
-    const int i = base + threadIdx.x * BSCAN_W;
-    int c[BSCAN_W], tot = 0;
-#pragma unroll
-    for (int u = 0; u < BSCAN_W; u += 4) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (i + u < nw) v = *reinterpret_cast<const uint4*>(bitmap + i + u);      // nw rounds up to a multiple of 4 inside the allocation
-      c[u] = __popc(v.x); c[u + 1] = __popc(v.y); c[u + 2] = __popc(v.z); c[u + 3] = __popc(v.w);
-      tot += c[u] + c[u + 1] + c[u + 2] + c[u + 3];
-    }
-    int total, ex = block_excl_scan(tot, sh, &total);
-    int acc = run + ex;
-#pragma unroll
-    for (int u = 0; u < BSCAN_W; ++u) {
-      if (i + u < nw) word_prefix[i + u] = acc;
-      acc += c[u];
-    }
-    run += total;
-  }
-  if (threadIdx.x == 0) {
-    int total = cnt->S + run;
-    if (total > cap_c) { atomicOr(&cnt->err, BLISS_ERR_CAP_CAND); total = cap_c; }
-    cnt->C = total;
+  const int ntiles = (nw + BTILE - 1) / BTILE;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int i = tile * BTILE + threadIdx.x * BTILE_W;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i < nw) v = *reinterpret_cast<const uint4*>(bitmap + i);
+    const int c0 = __popc(v.x), c1 = __popc(v.y), c2 = __popc(v.z), c3 = __popc(v.w);
+    int total, ex = block_excl_scan(c0 + c1 + c2 + c3, sh, &total);
+    if (i < nw) *reinterpret_cast<int4*>(word_prefix + i) = make_int4(ex, ex + c0, ex + c0 + c1, ex + c0 + c1 + c2);
+    if (threadIdx.x == 0) tile_sum[tile] = total;
   }
 }
 
@@ -555,10 +543,23 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
                                                          const unsigned long long* __restrict__ touched_key,
                                                          const unsigned long long* __restrict__ touched_sum,
                                                          const unsigned* __restrict__ bitmap, const int* __restrict__ word_prefix,
-                                                         bf16_t* __restrict__ p, int* hist, int cap_c, int uniform_nodes) {
+                                                         const int* __restrict__ tile_sum, bf16_t* __restrict__ p, int* hist,
+                                                         int cap_c, int uniform_nodes) {
   __shared__ int lh[HIST_BINS];                       // 128 KiB static LDS (one workgroup per CU; gfx950 has 160 KiB)
+  __shared__ int tile_off[MAX_TILES];
+  __shared__ int sh[17];
   const int S = cnt->S;
-  const int C = min(cnt->C, cap_c);
+  const int ntiles = (((cnt->E + 31) >> 5) + BTILE - 1) / BTILE;
+  int run = 0;                                        // every workgroup prefixes the (few) tile totals for itself
+  for (int base = 0; base < ntiles; base += FIN_TPB) {
+    const int t = base + threadIdx.x;
+    int total, ex = block_excl_scan(t < ntiles ? tile_sum[t] : 0, sh, &total);
+    if (t < ntiles) tile_off[t] = run + ex;
+    run += total;
+  }
+  int C = S + run;
+  if (C > cap_c) { C = cap_c; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, BLISS_ERR_CAP_CAND); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt->C = C;
   if ((int)blockIdx.x * FIN_TPB >= C) return;
   for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) lh[b] = 0;
   __syncthreads();
@@ -573,7 +574,7 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
       const unsigned long long key = touched_key[i - S];
       raw = touched_sum[i - S];
       const unsigned fp = (unsigned)(key >> 32), g = (unsigned)key;
-      id = S + word_prefix[fp >> 5] + __popc(bitmap[fp >> 5] & ((1u << (fp & 31u)) - 1u));   // rank of the first appearance
+      id = S + tile_off[(fp >> 5) / BTILE] + word_prefix[fp >> 5] + __popc(bitmap[fp >> 5] & ((1u << (fp & 31u)) - 1u));   // rank of the first appearance
       if (id >= cap_c) continue;
       local_id[g] = id; cand_nid[id] = (int)g;
     }
@@ -1056,19 +1057,21 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
       PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f));
     if (mode == BLISS_MODE_BANDIT)
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
     else
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
         cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (const bf16_t*)ws->bin_t, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
-    PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_scan<<<1, 1024, 0, st>>>(ws->bitmap, ws->word_prefix, cnt, ws->cap_c));
+    if (frontier_bound > (int64_t)MAX_TILES * BTILE * 32) return BLISS_EINVAL;
+    int* tile_sum = ws->word_prefix + ((frontier_bound + 4095) / 4096 + 1) * 128 + 4;    // the tile totals live behind the word prefixes
+    PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_tiles<<<grid_for(frontier_bound, (int64_t)BTILE * 32, MAX_TILES), 1024, 0, st>>>(ws->bitmap, ws->word_prefix, tile_sum, cnt));
     int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);
     if (gf < 1) gf = 1;
     if (gf > 256) gf = 256;
     PROF_LAUNCH(BK_CAND_NUMBER, st, k_cand_number<<<gf, FIN_TPB, 0, st>>>(
         seeds, cnt, ws->cand_nid, m->local_id, seed_p2, (const unsigned long long*)ws->touched_key,
-        (const unsigned long long*)ws->touched_sum, ws->bitmap, ws->word_prefix, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
+        (const unsigned long long*)ws->touched_sum, ws->bitmap, ws->word_prefix, tile_sum, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
     return (int)hipGetLastError();
   }
   if (mode == BLISS_MODE_BANDIT) {

@@ -83,7 +83,7 @@ typedef struct {
   uint64_t* bin_rec;        /* [n_bins * bin_cap] (frontier position << 32 | source id) */
   void* bin_t;              /* bf16 [n_bins * bin_cap] the edge's term of p_j^2 */
   uint32_t* bitmap;         /* [frontier_bound / 32 rounded up to 128 words, + 4] first appearances by frontier position */
-  int32_t* word_prefix;     /* [same length] exclusive popcount prefix of the bitmap words */
+  int32_t* word_prefix;     /* [same length + 2048] exclusive popcount prefix of the bitmap words (per 4096-word tile) + tile totals */
   uint64_t* touched_key;    /* [cap_c] (first position << 32 | source id) of every non-seed frontier source */
   uint64_t* touched_sum;    /* [cap_c] its exact sum */
 } bliss_layer_ws_t;
