@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune-gemm", type=int, default=1, help="1: TunableOp picks the library GEMM solutions during warm-up")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the step's HIP graph")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step per graph, sampling not overlapped with the backward pass")
     return ap.parse_args()
 
 
@@ -61,7 +62,7 @@ def main():
     import bliss_gnn_amd as bg
     from bliss_gnn_amd.model import SAGE
     from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc, node_data
-    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, TrainStep
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, PipelinedTrainStep, TrainStep
     from bliss_gnn_amd import dist as bdist
 
     cfg = CONFIGS[args.config]
@@ -96,14 +97,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = None
+    step, launch = None, "eager (kernel by kernel)"
     if graphed:
-        # whole step (sampler + gather + fwd/bwd + [grad all-reduce] + Adam + exp3 [+ all-gather]) replayed from ONE HIP graph
+        # the whole step (sampler + gather + fwd/bwd + [grad all-reduce] + Adam + exp3 [+ all-gather]) comes from ONE HIP
+        # graph; by default two consecutive steps per graph, with the next batch's sampling overlapped with the backward pass
         try:
-            step = GraphedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"], distributed=world > 1)
+            cls = GraphedTrainStep if args.no_pipeline else PipelinedTrainStep
+            step = cls(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"], distributed=world > 1)
             step.calibrate(loader, steps=8)
-            step.capture(loader, warmup=3, tune_gemm=args.tune_gemm)
-            run_step, sizes_of = step, step.sizes
+            step.capture(loader, warmup=2, tune_gemm=args.tune_gemm)
+            launch = ("one HIP graph per step" if args.no_pipeline else
+                      "HIP graphs on two streams (sampler | model); sampling of batch t+1 overlaps backward+Adam of batch t")
         except Exception as e:                       # e.g. a runtime that cannot capture collectives: launch kernel by kernel
             if world == 1:
                 raise
@@ -113,45 +117,61 @@ def main():
                                                     model="sage")
     if not graphed:
         step = TrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"], grad_sync=grad_sync, exp3_sync=exp3_sync)
-        run_step = step
-        sizes_of = lambda: [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in step.last["mfgs"]]
+    pipelined = isinstance(step, PipelinedTrainStep)
 
-    for _ in range(args.warmup):
-        run_step(next(loader))
+    def advance(n, eager=False):
+        """Run exactly n train steps; returns the per-step block sizes (one list per sampled batch)."""
+        sizes = []
+        while n > 0:
+            if pipelined and n >= 2:
+                (step.eager_pair if eager else step)(loader)
+                sizes += step.sizes2()
+                n -= 2
+            elif pipelined:                          # an odd step: train the batch in flight, sample the next one
+                step.drain()
+                step.prime(next(loader))
+                sizes.append(step.sizes())
+                n -= 1
+            elif graphed:
+                (step.eager_step if eager else step)(next(loader))
+                sizes.append(step.sizes())
+                n -= 1
+            else:
+                step(next(loader))
+                sizes.append([dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in step.last["mfgs"]])
+                n -= 1
+        return sizes
+
+    advance(args.warmup)
     sync()
-    sizes_acc, n_edges, n_frontier = None, 0, 0
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(next(loader))
-        sz = sizes_of()
-        n_edges += sum(x["B"] for x in sz)
-        n_frontier += sum(x["E"] for x in sz)
-        sizes_acc = sz if sizes_acc is None else [{k: a[k] + b[k] for k in a} for a, b in zip(sizes_acc, sz)]
+    all_sizes = advance(args.steps)
     sync()
     dt = time.perf_counter() - t1
+    n_edges = sum(x["B"] for sz in all_sizes for x in sz)
+    n_frontier = sum(x["E"] for sz in all_sizes for x in sz)
+    sizes_acc = [{k: sum(sz[l][k] for sz in all_sizes) for k in all_sizes[0][l]} for l in range(len(all_sizes[0]))]
     t = torch.tensor([dt, float(n_edges), float(n_frontier)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, n_edges, n_frontier = float(tmax[0]), float(tsum[1]), float(tsum[2])
 
-    # ---- roofline: the same step launched kernel by kernel, HIP events around the library kernels ----------------
+    # ---- roofline: the same steps launched kernel by kernel, HIP events around the library kernels ----------------
     dominant, calib, dom_timing, alg_dom = None, {}, None, 0.0
     if rank == 0 and world == 1 and not args.no_roofline:
-        k_step = step.eager_step if graphed else step
         torch.cuda.synchronize()
         timer.enable("all")
-        for _ in range(5):
-            k_step(next(loader))
+        advance(6, eager=True)
         torch.cuda.synchronize()
         calib = timer.read()
         hbm_kernels = {k: v for k, v in calib.items()
                        if roofline.algorithmic_bytes(k, dict(S=1, E=1, C=1, K=1, B=1), [1, 1, 1], 0) and k != "k_mt19937_uniform"}
         dominant = max(hbm_kernels, key=lambda k: hbm_kernels[k]["total_ms"])
         timer.enable(dominant)                       # only this kernel carries events now
-        for _ in range(min(args.steps, 30)):
-            k_step(next(loader))
-            alg_dom += sum(roofline.algorithmic_bytes(dominant, s_, dims, l) for l, s_ in enumerate(sizes_of()))
+        n_dom = min(args.steps, 30) // 2 * 2
+        for sz in advance(n_dom, eager=True):
+            alg_dom += sum(roofline.algorithmic_bytes(dominant, s_, dims, l) for l, s_ in enumerate(sz))
         torch.cuda.synchronize()
         dom_timing = timer.read().get(dominant)
         timer.enable("off")
@@ -169,7 +189,7 @@ def main():
                                "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"], hidden, eta,
                                                                  "/".join(map(str, fan)), cfg["batch"]),
                    "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather over RCCL)" % world if world > 1 else "single GPU",
-                   "launch": "whole step replayed from one HIP graph" if graphed else "eager (kernel by kernel)",
+                   "launch": launch,
                    "global_batch": cfg["batch"] * world},
         "sampled_edges_per_sec": n_edges / dt, "frontier_edges_per_sec": n_frontier / dt,
         "sizes_per_step": mean_sizes, "algorithmic_bytes_per_step": alg,
@@ -191,7 +211,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / roofline.HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": dom_timing["avg_us"], "launches": dom_timing["launches"],
-                           "measured_over": "%d kernel-by-kernel runs of the same step right after the timed region" % min(args.steps, 30),
+                           "measured_over": "%d kernel-by-kernel runs of the same step right after the timed region" % n_dom,
                            "algorithmic_bytes_per_launch": per_launch,
                            "kernel_time_share_in_calibration": {k: round(v["total_ms"] / max(sum(x["total_ms"] for x in calib.values()), 1e-9), 4)
                                                                 for k, v in sorted(calib.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}

@@ -85,7 +85,8 @@ class LayerEngine:
         self.mt_dev = torch.empty(626, dtype=torch.int32, device=dev)
         self.mt_host = torch.empty(626, dtype=torch.int32).pin_memory()        # state handed to the device
         self.mt_back = torch.empty(626, dtype=torch.int32).pin_memory()        # state handed back
-        self._static = None
+        self._static = {}
+        self._slot_bufs, self._slot_counts, self._slot_counts_host = {}, {}, {}
         self.caps = None
         self.ws = None
         self.counts_host = None
@@ -263,17 +264,25 @@ class LayerEngine:
             self._grow([c.err for c in cnts])
             self._ensure(int(seeds.numel()), fanouts)
 
-    def _layer_buffers(self, n, counts):
-        """Caller-owned outputs of layer n (one int32 and one bf16 allocation, sliced) + the C descriptors."""
+    def _layer_buffers(self, n, counts, slot=None):
+        """Caller-owned outputs of layer n (one int32 and one bf16 allocation, sliced) + the C descriptors.
+        ``slot``: static-shape callers keep one persistent set of outputs per slot (a pipelined train loop holds two
+        batches at a time); None = fresh memory per call."""
         dev = self.g.device
         cap, ws = self.caps[n], self.ws[n]
         cs, ck, cb = cap["S"], cap["K"], cap["B"]
         build_t = cs <= 32768                     # by-source index built by the sampler kernels themselves
         if ws.src_cnt is None or ws.src_cnt.numel() < ck + 1:
             ws.src_cnt = torch.empty(ck + 1, dtype=torch.int32, device=dev)
-        ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck) + (2 * _up8(cb) + _up8(ck + 1) if build_t else 0),
-                           dtype=torch.int32, device=dev)
-        hbuf = torch.empty(2 * _up8(cb) + _up8(ck), dtype=torch.bfloat16, device=dev)
+        key = (slot, n, cs, ck, cb)
+        if slot is not None and key in self._slot_bufs:
+            ibuf, hbuf = self._slot_bufs[key]
+        else:
+            ibuf = torch.empty(_up8(cs + 1) + 4 * _up8(cb) + _up8(ck) + (2 * _up8(cb) + _up8(ck + 1) if build_t else 0),
+                               dtype=torch.int32, device=dev)
+            hbuf = torch.empty(2 * _up8(cb) + _up8(ck), dtype=torch.bfloat16, device=dev)
+            if slot is not None:
+                self._slot_bufs[key] = (ibuf, hbuf)
         o = 0
         b_indptr = ibuf[o:o + cs + 1]; o += _up8(cs + 1)
         b_src = ibuf[o:o + cb]; o += _up8(cb)
@@ -324,13 +333,18 @@ class LayerEngine:
         self._static_snapshot = torch.get_rng_state()
         self._stage_rng(self._static_snapshot)
 
-    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999):
+    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
-        blocks (sampling order); sizes, errors and the generator state are read back by finish()."""
+        blocks (sampling order); sizes, errors and the generator state are read back by finish().
+
+        ``slot``: which persistent set of output buffers to fill.  ``chain_rng``: continue from the generator state the
+        previous enqueue left on the device instead of the host-staged one (several batches sampled per host round trip)."""
         L = len(fanouts)
-        out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True)
+        out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng)
         counts_dev, layers = out
-        self.counts_host.copy_(counts_dev, non_blocking=True)
+        if slot not in self._slot_counts_host:
+            self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
+        self._slot_counts_host[slot].copy_(counts_dev, non_blocking=True)
         self.mt_back.copy_(self.mt_dev, non_blocking=True)
         blocks = []
         for n, lay in enumerate(layers):
@@ -344,33 +358,39 @@ class LayerEngine:
                 blk._transposed = (t_indptr, t_edge)
             blk._trace = {}
             blocks.append(blk)
-        self._static = (blocks, L)          # kept: a captured graph replays this enqueue without re-running it
+        self._static[slot] = (blocks, L)    # kept: a captured graph replays this enqueue without re-running it
         return blocks
 
-    def finish(self):
+    def finish(self, slot=0, commit=True):
         """After the stream has been synchronised: true sizes, error check, generator hand-back."""
-        blocks, L = self._static
-        raw = self.counts_host.numpy().tobytes()
+        blocks, L = self._static[slot]
+        raw = self._slot_counts_host[slot].numpy().tobytes()
         cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
         bad = 0
         for c in cnts:
             bad |= c.err
         for b, c in zip(blocks, cnts):
             b._counts = c
-        self._commit_rng(self._static_snapshot)
+        if commit:
+            self._commit_rng(self._static_snapshot)
         if bad:
             raise RuntimeError(f"static-shape step exceeded its capacities or hit a kernel error 0x{bad:x} "
                                f"({_lib.err_string(bad)}); the step's results are invalid -- raise the margins")
         return cnts
 
-    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot):
+    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
-        if snapshot is not None:
+        if snapshot is not None and not chain_rng:
             if snapshot is not True:
                 self._stage_rng(snapshot)
             self.mt_dev.copy_(self.mt_host, non_blocking=True)
-        counts = torch.empty(L * 10, dtype=torch.int32, device=dev)
+        if slot is None:
+            counts = torch.empty(L * 10, dtype=torch.int32, device=dev)
+        else:
+            if slot not in self._slot_counts or self._slot_counts[slot].numel() != L * 10:
+                self._slot_counts[slot] = torch.empty(L * 10, dtype=torch.int32, device=dev)
+            counts = self._slot_counts[slot]
         use_rng = uniforms is None
         if use_rng:      # fork the generator: it runs beside everything below
             _lib.check(_lib.lib.bliss_rng_stream_begin(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_out.data_ptr(),
@@ -382,7 +402,7 @@ class LayerEngine:
         for n in range(L):
             cap = self.caps[n]
             cs, ws = cap["S"], self.ws[n]
-            c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts)
+            c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts, slot)
             w_pos = w_rows[n]
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,

@@ -211,3 +211,174 @@ class GraphedTrainStep:
     def sizes(self):
         """Per block (input-most first): the true S, E, C, K, B of the last step."""
         return [dict(S=c.S, E=c.E, C=c.C, K=c.K, B=c.B) for c in reversed(self.last_counts)]
+
+
+class PipelinedTrainStep(GraphedTrainStep):
+    """Two train steps per call, software-pipelined: while the backward pass and Adam of batch ``a`` run on one stream,
+    the sampler already builds the blocks of batch ``b`` on the other (and vice versa); every piece is a replayed HIP graph.
+
+        F(a) X(a) [ S(b) || B(a) ]  F(b) X(b) [ S(a') || B(b) ]          F forward+loss, X exp3 update, B backward+Adam, S sample
+
+    The sampler is a long chain of small latency- and atomic-bound kernels that leaves most of the chip idle; the
+    dense backward fills that idle capacity.  Nothing is reordered that depends on anything else: S(b) needs the EXP3
+    weights after X(a) (it waits for it) and not the parameters; X reads only what the forward left on the blocks
+    (embed_norm, q_ij), so running it before B changes no value -- every step computes exactly what the sequential
+    loop computes, bit for bit, and torch's CPU generator is consumed in the same order (S(b) then S(a')).
+
+    One call = two optimiser steps on two batches; the batch sampled last is trained by the next call (``drain``
+    trains the final one)."""
+
+    def __init__(self, g, sampler, model, batch_size, lr=0.002, multilabel=False, distributed=False):
+        super().__init__(g, sampler, model, batch_size, lr, multilabel, distributed)
+        self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
+        self.mfgs = [None, None]
+        self.side = torch.cuda.Stream()
+        self.losses = None
+        self.last_counts2 = None
+
+    def _sample(self, slot, chain):
+        return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain)[2]
+
+    def _forward(self, mfgs):
+        pred = self.model(mfgs, mfgs[0].srcdata["features"])
+        loss = self.loss_fn(pred, mfgs[-1].dstdata["labels"])
+        if self.distributed:
+            from . import dist as bdist
+            bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
+        else:
+            self.sampler.exp3(mfgs, self.g)
+        return loss
+
+    def _backward(self, loss):
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.distributed:
+            from . import dist as bdist
+            bdist.allreduce_gradients(self.model)
+        self.opt.step()
+
+    def _pair(self):
+        # The sampler stays on the capture's origin stream (its random-number generator forks from there); the model runs
+        # on the second stream, forward AND backward (autograd replays a node on the stream of its forward).
+        main, side = torch.cuda.current_stream(), self.side
+        side.wait_stream(main)
+        losses = []
+        for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
+            with torch.cuda.stream(side):
+                loss = self._forward(self.mfgs[cur])         # F + X
+            main.wait_stream(side)                           # the sampler needs the EXP3 weights X just wrote
+            self.mfgs[nxt] = self._sample(nxt, chain)        # S, beside ...
+            with torch.cuda.stream(side):
+                self._backward(loss)                         # ... B
+                side.wait_stream(main)                       # the next forward needs the blocks S built
+            losses.append(loss.detach())
+        main.wait_stream(side)
+        return tuple(losses)
+
+    def prime(self, seeds):
+        """Sample the first batch (slot 0) so that the pipeline has something to train on."""
+        self.seeds2[0].copy_(seeds)
+        self.sampler._engine.stage_rng_from_torch()
+        self.mfgs[0] = self._sample(0, False)
+        torch.cuda.current_stream().synchronize()
+        self.sampler.finish_static(0, commit=True)
+
+    def _finish_pair(self):
+        torch.cuda.current_stream().synchronize()
+        c1 = self.sampler.finish_static(1, commit=False)
+        c0 = self.sampler.finish_static(0, commit=True)
+        self.last_counts2 = [c1, c0]                     # the two batches sampled by this replay, in sampling order
+        self.last_counts = c0
+        self.num_steps += 2
+
+    def _load(self, loader):
+        self.seeds2[1].copy_(next(loader))               # S(b) runs first, then S(a')
+        self.seeds2[0].copy_(next(loader))
+        self.sampler._engine.stage_rng_from_torch()
+
+    def capture(self, loader, warmup=2, tune_gemm=False):
+        eng = self.sampler._engine
+        if tune_gemm:
+            tn = torch.cuda.tunable
+            tn.enable(True)
+            tn.tuning_enable(True)
+            tn.set_max_tuning_duration(30)
+            tn.set_max_tuning_iterations(20)
+            tn.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bliss_tunableop_%d.csv" % os.getpid()))
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            self.prime(next(loader))
+            for _ in range(warmup):
+                self._load(loader)
+                self.losses = self._pair()
+                self._finish_pair()
+        torch.cuda.current_stream().wait_stream(warm)
+        if tune_gemm:
+            torch.cuda.tunable.tuning_enable(False)
+        self.losses = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        # Six graphs, not one: a HIP graph with the sampler and the backward pass as parallel branches is executed with both
+        # branches on one hardware queue (ROCm 7.2), i.e. not overlapped.  Replaying the sampler graphs and the model graphs
+        # from two real streams, ordered by events, gives the overlap.
+        self._load(loader)
+        main, side = torch.cuda.current_stream(), self.side
+        pool = torch.cuda.graph_pool_handle()
+        self.g_fwd, self.g_bwd, self.g_smp, held = [None, None], [None, None], [None, None], [None, None]
+        for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
+            self.g_fwd[cur], self.g_bwd[cur], self.g_smp[nxt] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side):
+                held[cur] = self._forward(self.mfgs[cur])
+            with torch.cuda.graph(self.g_smp[nxt]):
+                self.mfgs[nxt] = self._sample(nxt, chain)
+            with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
+                self._backward(held[cur])
+        self.losses = tuple(h.detach() for h in held)
+        self.graph = True
+        self._replay()                                   # the captures themselves executed nothing
+        self._finish_pair()
+
+    def _replay(self):
+        main, side = torch.cuda.current_stream(), self.side
+        side.wait_stream(main)
+        for cur, nxt in ((0, 1), (1, 0)):
+            with torch.cuda.stream(side):
+                self.g_fwd[cur].replay()                 # F + X
+            main.wait_stream(side)                       # the sampler needs the EXP3 weights X just wrote
+            self.g_smp[nxt].replay()                     # S, beside ...
+            with torch.cuda.stream(side):
+                self.g_bwd[cur].replay()                 # ... B
+                side.wait_stream(main)                   # the next forward needs the blocks S built
+        main.wait_stream(side)
+
+    def __call__(self, loader):
+        """Two steps: trains the batch sampled by the previous call and the next batch of ``loader``; samples two."""
+        self._load(loader)
+        self._replay()
+        self._finish_pair()
+        return self.losses
+
+    def eager_pair(self, loader):
+        """The same two steps launched kernel by kernel (used to time individual kernels)."""
+        self._load(loader)
+        self.losses = self._pair()
+        self._finish_pair()
+        return self.losses
+
+    def drain(self):
+        """Train on the batch that is sampled but not trained yet (end of training)."""
+        main, side = torch.cuda.current_stream(), self.side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            loss = self._forward(self.mfgs[0])
+            self._backward(loss)
+        main.wait_stream(side)
+        main.synchronize()
+        self.num_steps += 1
+        return loss.detach()
+
+    def sizes2(self):
+        """sizes() for each of the two batches sampled by the last call."""
+        return [[dict(S=c.S, E=c.E, C=c.C, K=c.K, B=c.B) for c in reversed(cs)] for cs in self.last_counts2]

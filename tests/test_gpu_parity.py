@@ -886,3 +886,51 @@ def test_binned_and_atomic_paths_agree_on_a_larger_graph(cuda, monkeypatch):
         assert torch.equal(a._trace["cand_nid"], b._trace["cand_nid"])
         assert torch.equal(a._trace["p"].view(torch.int16), b._trace["p"].view(torch.int16))
         assert torch.equal(a.edata["edge_weights"].view(torch.int16), b.edata["edge_weights"].view(torch.int16))
+
+
+def test_pipelined_two_step_graph_matches_sequential(cuda):
+    """PipelinedTrainStep (sampling of the next batch overlapped with the backward of the current one, two steps per
+    graph replay) leaves exactly the EXP3 state, parameters and CPU generator of the one-step-per-replay loop."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, PipelinedTrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(8000, 160000, seed=12)
+    feats = torch.randn(8000, 64, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 5, (8000,), generator=torch.Generator().manual_seed(3))
+    fan, bs = [400, 200, 100], 64
+    ids = torch.arange(8000, dtype=torch.int32, device=cuda)
+    outs = []
+    for cls in (GraphedTrainStep, PipelinedTrainStep):
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler(fan, eta=0.1)
+        torch.manual_seed(0)
+        model = SAGE(64, 32, 5, 3, torch.relu, 0.0).to(cuda).bfloat16()
+        step = cls(g, sampler, model, bs)
+        loader = BatchLoader(ids, bs, seed=5).forever()
+        torch.manual_seed(9)
+        step.calibrate(loader, steps=3)
+        losses = []
+        if cls is GraphedTrainStep:
+            step.capture(loader, warmup=2)                       # 3 steps
+            for _ in range(8):                                   # 11 trained batches in total
+                step(next(loader))
+                losses.append(float(step.loss))
+            sampler.sample_blocks(g, next(loader))               # the pipelined loop has sampled one batch ahead
+        else:
+            step.capture(loader, warmup=1)                       # prime + 1 warm pair + captured pair = 4 trained, 5 sampled
+            for _ in range(3):
+                la, lb = step(loader)
+                losses += [float(la), float(lb)]                 # 10 trained, 11 sampled
+            losses.append(float(step.drain()))                   # 11 trained
+            sampler.sample_blocks(g, next(loader))               # keep the two generators aligned: 12 sampled on both sides
+        sampler.check_errors()
+        outs.append(dict(w=sampler.exp3_weights.cpu().view(torch.int16).clone(), rng=torch.get_rng_state(),
+                         params=[p.detach().cpu().clone() for p in model.parameters()], losses=losses))
+    a, b = outs
+    assert torch.equal(a["rng"], b["rng"])
+    assert torch.equal(a["w"], b["w"])
+    assert a["losses"][-7:] == b["losses"][-7:]
+    for pa, pb in zip(a["params"], b["params"]):
+        assert torch.equal(pa, pb)
