@@ -123,8 +123,11 @@ def main():
         """Run exactly n train steps; returns the per-step block sizes (one list per sampled batch)."""
         sizes = []
         while n > 0:
-            if pipelined and n >= 2:
-                (step.eager_pair if eager else step)(loader)
+            if pipelined and n >= 2 and not eager:
+                sizes += step.run(loader, n // 2)
+                n -= n // 2 * 2
+            elif pipelined and n >= 2:
+                step.eager_pair(loader)
                 sizes += step.sizes2()
                 n -= 2
             elif pipelined:                          # an odd step: train the batch in flight, sample the next one

@@ -333,19 +333,36 @@ class LayerEngine:
         self._static_snapshot = torch.get_rng_state()
         self._stage_rng(self._static_snapshot)
 
-    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False):
+    def static_rng_begin(self, chain_rng=False):
+        """Start the random-number generator of the NEXT enqueue_static(..., external_rng=True) now, on the current stream:
+        a pipelined loop calls this before the sampler's other inputs are ready, so the serial MT19937 chain is off the
+        critical path.  Plain launches (not graph-captured): the generator runs on the library's own stream."""
+        if not chain_rng:
+            self.mt_dev.copy_(self.mt_host, non_blocking=True)
+        _lib.check(_lib.lib.bliss_rng_stream_begin(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_out.data_ptr(),
+                                                   self.rng_raw.data_ptr(), self.rng_cap, _stream()), "bliss_rng_stream_begin")
+
+    def static_rng_end(self, slot=0):
+        """Join the generator started by static_rng_begin and leave the state after exactly sum(C) draws in mt_dev / mt_back."""
+        _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
+                                                 self.rng_cap, self._slot_counts[slot].data_ptr() + 20, _stream()), "bliss_rng_stream_end")
+        self.mt_back.copy_(self.mt_dev, non_blocking=True)
+
+    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
         blocks (sampling order); sizes, errors and the generator state are read back by finish().
 
         ``slot``: which persistent set of output buffers to fill.  ``chain_rng``: continue from the generator state the
         previous enqueue left on the device instead of the host-staged one (several batches sampled per host round trip)."""
         L = len(fanouts)
-        out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng)
+        out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng,
+                            external_rng=external_rng)
         counts_dev, layers = out
         if slot not in self._slot_counts_host:
             self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
         self._slot_counts_host[slot].copy_(counts_dev, non_blocking=True)
-        self.mt_back.copy_(self.mt_dev, non_blocking=True)
+        if not external_rng:
+            self.mt_back.copy_(self.mt_dev, non_blocking=True)
         blocks = []
         for n, lay in enumerate(layers):
             b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept_nid, node_prob, cdev, t_indptr, t_edge = lay
@@ -378,10 +395,10 @@ class LayerEngine:
                                f"({_lib.err_string(bad)}); the step's results are invalid -- raise the margins")
         return cnts
 
-    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False):
+    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False, external_rng=False):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
-        if snapshot is not None and not chain_rng:
+        if snapshot is not None and not chain_rng and not external_rng:
             if snapshot is not True:
                 self._stage_rng(snapshot)
             self.mt_dev.copy_(self.mt_host, non_blocking=True)
@@ -392,7 +409,7 @@ class LayerEngine:
                 self._slot_counts[slot] = torch.empty(L * 10, dtype=torch.int32, device=dev)
             counts = self._slot_counts[slot]
         use_rng = uniforms is None
-        if use_rng:      # fork the generator: it runs beside everything below
+        if use_rng and not external_rng:      # fork the generator: it runs beside everything below
             _lib.check(_lib.lib.bliss_rng_stream_begin(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_out.data_ptr(),
                                                        self.rng_raw.data_ptr(), self.rng_cap, st), "bliss_rng_stream_begin")
         eta_f = float(np.float32(eta))
@@ -423,7 +440,7 @@ class LayerEngine:
                                                   C.byref(c_out), st), "bliss_build_block")
             layers.append(lay)
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
-        if use_rng:      # join; mt_dev = generator state after exactly sum(C) draws
+        if use_rng and not external_rng:      # join; mt_dev = generator state after exactly sum(C) draws
             _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
                                                      self.rng_cap, counts.data_ptr() + 20, st), "bliss_rng_stream_end")
         return counts, layers

@@ -15,6 +15,8 @@ import os
 import torch
 import torch.nn as nn
 
+from . import _lib
+
 
 class BatchLoader:
     """dgl.dataloading.DataLoader(g, train_nid, sampler, batch_size, shuffle=True, drop_last=True)
@@ -236,8 +238,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.losses = None
         self.last_counts2 = None
 
-    def _sample(self, slot, chain):
-        return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain)[2]
+    def _sample(self, slot, chain, external_rng=False):
+        return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng)[2]
 
     def _forward(self, mfgs):
         pred = self.model(mfgs, mfgs[0].srcdata["features"])
@@ -331,8 +333,8 @@ class PipelinedTrainStep(GraphedTrainStep):
             self.g_fwd[cur], self.g_bwd[cur], self.g_smp[nxt] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side):
                 held[cur] = self._forward(self.mfgs[cur])
-            with torch.cuda.graph(self.g_smp[nxt]):
-                self.mfgs[nxt] = self._sample(nxt, chain)
+            with torch.cuda.graph(self.g_smp[nxt]):       # without its generator: that one is launched ahead of time
+                self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True)
             with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
                 self._backward(held[cur])
         self.losses = tuple(h.detach() for h in held)
@@ -340,14 +342,17 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._replay()                                   # the captures themselves executed nothing
         self._finish_pair()
 
-    def _replay(self):
+    def _replay(self, first_chain=False):
         main, side = torch.cuda.current_stream(), self.side
+        eng = self.sampler._engine
         side.wait_stream(main)
-        for cur, nxt in ((0, 1), (1, 0)):
+        for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
+            eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
             with torch.cuda.stream(side):
                 self.g_fwd[cur].replay()                 # F + X
             main.wait_stream(side)                       # the sampler needs the EXP3 weights X just wrote
             self.g_smp[nxt].replay()                     # S, beside ...
+            eng.static_rng_end(nxt)
             with torch.cuda.stream(side):
                 self.g_bwd[cur].replay()                 # ... B
                 side.wait_stream(main)                   # the next forward needs the blocks S built
@@ -359,6 +364,49 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._replay()
         self._finish_pair()
         return self.losses
+
+    def run(self, loader, n_pairs, ring=4):
+        """``n_pairs`` calls without a host round trip in between: the generator state is chained on the device from
+        batch to batch (torch's CPU generator is brought up to date once, at the end), and sizes / error words come back
+        through a small ring of pinned buffers while later pairs are already running.  Returns the block sizes of every
+        batch sampled, in order."""
+        eng = self.sampler._engine
+        L = len(self.sampler.nodes_per_layer)
+        if getattr(self, "_ring", None) is None or len(self._ring) != ring:
+            self._ring = [torch.empty(2 * L * 10, dtype=torch.int32).pin_memory() for _ in range(ring)]
+            self._ring_ev = [torch.cuda.Event() for _ in range(ring)]
+        sizes, pending, bad = [], [], 0
+
+        def collect(i):
+            nonlocal bad
+            self._ring_ev[i].synchronize()
+            raw = self._ring[i].numpy().tobytes()
+            for half in range(2):
+                cs = [_lib.LayerCounts.from_buffer_copy(raw[40 * (half * L + n): 40 * (half * L + n) + 40]) for n in range(L)]
+                for c in cs:
+                    bad |= c.err
+                sizes.append([dict(S=c.S, E=c.E, C=c.C, K=c.K, B=c.B) for c in reversed(cs)])
+
+        eng.stage_rng_from_torch()
+        for k in range(n_pairs):
+            if len(pending) == ring:
+                collect(pending.pop(0))
+            self.seeds2[1].copy_(next(loader))           # stream order: after the previous pair's samplers have read them
+            self.seeds2[0].copy_(next(loader))
+            self._replay(first_chain=k > 0)
+            r = self._ring[k % ring]
+            r[:L * 10].copy_(eng._slot_counts[1], non_blocking=True)
+            r[L * 10:].copy_(eng._slot_counts[0], non_blocking=True)
+            self._ring_ev[k % ring].record()
+            pending.append(k % ring)
+        for i in pending:
+            collect(i)
+        if n_pairs:
+            self._finish_pair()
+        if bad:
+            raise RuntimeError(f"static-shape step exceeded its capacities or hit a kernel error 0x{bad:x} "
+                               f"({_lib.err_string(bad)}); results are invalid -- raise the margins")
+        return sizes
 
     def eager_pair(self, loader):
         """The same two steps launched kernel by kernel (used to time individual kernels)."""

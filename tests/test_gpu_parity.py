@@ -920,9 +920,11 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             sampler.sample_blocks(g, next(loader))               # the pipelined loop has sampled one batch ahead
         else:
             step.capture(loader, warmup=1)                       # prime + 1 warm pair + captured pair = 4 trained, 5 sampled
-            for _ in range(3):
-                la, lb = step(loader)
-                losses += [float(la), float(lb)]                 # 10 trained, 11 sampled
+            la, lb = step(loader)
+            losses += [float(la), float(lb)]                     # 6 trained, 7 sampled
+            sizes = step.run(loader, 2)                          # two more pairs without a host round trip in between
+            assert len(sizes) == 4 and all(s[0]["E"] > 0 for s in sizes)
+            losses += [None, None] + [float(x) for x in step.losses]     # 10 trained, 11 sampled
             losses.append(float(step.drain()))                   # 11 trained
             sampler.sample_blocks(g, next(loader))               # keep the two generators aligned: 12 sampled on both sides
         sampler.check_errors()
@@ -931,6 +933,6 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
     a, b = outs
     assert torch.equal(a["rng"], b["rng"])
     assert torch.equal(a["w"], b["w"])
-    assert a["losses"][-7:] == b["losses"][-7:]
+    assert a["losses"][-3:] == b["losses"][-3:] and a["losses"][-7:-5] == b["losses"][-7:-5]
     for pa, pb in zip(a["params"], b["params"]):
         assert torch.equal(pa, pb)
