@@ -25,6 +25,12 @@ def algorithmic_bytes(kernel, s, dims=None, layer=None):
         "k_frontier_pass1": 6 * E + 8 * S,                    # column indices + exp3 weights, per-seed pointers
         "k_frontier_pass2": 6 * E + 16 * S,                   # + per-seed sums in/out
         "k_frontier_pass3": 6 * E + 16 * S + 12 * Cn,         # + candidate ids out, per-candidate accumulators
+        # binned candidate pipeline: the same minimum traffic as passes 1-3, split over its kernels (the (position, source,
+        # term) records it writes and re-reads are implementation traffic, not algorithmic bytes)
+        "k_col_sums": 2 * E + 24 * S,                         # exp3 weights of the seeds' columns, per-seed sums out
+        "k_bin_scatter": 6 * E + 16 * S,                      # column indices + exp3 weights, per-seed sums in
+        "k_bin_reduce": 12 * Cn,                              # per-candidate first position + sum out
+        "k_cand_number": 14 * Cn,                             # candidate ids + p out
         "k_block_pass1": 6 * E + 16 * S + 6 * Cn,             # + new ids / P of the candidates
         "k_block_pass2": 6 * E + 16 * S + 6 * Cn + 20 * B,    # + the block's edges out (src,dst,pos,eid,w,q)
         "k_cand_finalize": 14 * Cn,
