@@ -684,6 +684,22 @@ def test_graphed_step_with_collectives_single_rank(cuda):
             s.check_errors()
             outs.append((s.exp3_weights.cpu().view(torch.int16).clone(), float(step.loss)))
         assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+        # the pipelined two-stream loop with the same collectives inside its model graphs: 2 + 2 + 4 = 8 trained batches
+        from bliss_gnn_amd.train import PipelinedTrainStep
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        s = bg.PoissonBanditLadiesSampler([300, 150, 80], eta=0.1)
+        torch.manual_seed(0)
+        model = SAGE(32, 16, 4, 3, torch.relu, 0.0).to(cuda).bfloat16()
+        step = PipelinedTrainStep(g, s, model, 48, distributed=True)
+        loader = BatchLoader(ids, 48, seed=5).forever()
+        torch.manual_seed(9)
+        step.calibrate(loader, steps=3)
+        step.capture(loader, warmup=1)
+        step.run(loader, 1)
+        step.drain()                                     # 7 trained batches, like the runs above (3 + 4)
+        s.check_errors()
+        assert torch.equal(s.exp3_weights.cpu().view(torch.int16), outs[0][0])
     finally:
         dist.destroy_process_group()
 
