@@ -68,6 +68,7 @@ class LayerEngine:
         self.local_id = torch.full((V,), -1, dtype=torch.int32, device=dev)
         self.first_pos = torch.full((V,), -1, dtype=torch.int32, device=dev)      # 0xFFFFFFFF
         self.acc_p2 = torch.zeros(V, dtype=torch.int64, device=dev)
+        self.kept_map = torch.full((V,), -1, dtype=torch.int32, device=dev)
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
@@ -126,7 +127,6 @@ class LayerEngine:
             words = (-(-self.Eg // 4096) + 1) * 128 + 4
             self._bins = dict(cap=cap, cursor=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                               rec=torch.empty(nb * cap, dtype=torch.int64, device=dev),
-                              t=torch.empty(nb * cap, dtype=torch.bfloat16, device=dev),
                               bitmap=torch.zeros(words, dtype=torch.int32, device=dev),
                               prefix=torch.empty(words + 2048, dtype=torch.int32, device=dev),
                               tkey=torch.empty(self.V, dtype=torch.int64, device=dev),
@@ -303,10 +303,11 @@ class LayerEngine:
                             ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
                             kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
                             ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
+        c_ws.kept_map = self.kept_map.data_ptr()
         if self.n_bins:
             b = self._bin_buffers()
             c_ws.n_bins, c_ws.bin_cap = self.n_bins, b["cap"]
-            c_ws.bin_cursor, c_ws.bin_rec, c_ws.bin_t = b["cursor"].data_ptr(), b["rec"].data_ptr(), b["t"].data_ptr()
+            c_ws.bin_cursor, c_ws.bin_rec = b["cursor"].data_ptr(), b["rec"].data_ptr()
             c_ws.bitmap, c_ws.word_prefix = b["bitmap"].data_ptr(), b["prefix"].data_ptr()
             c_ws.touched_key, c_ws.touched_sum = b["tkey"].data_ptr(), b["tsum"].data_ptr()
         c_out = _lib.BlockOut(b_indptr.data_ptr(), b_src.data_ptr(), b_dst.data_ptr(), b_pos.data_ptr(), b_eid.data_ptr(),

@@ -42,8 +42,9 @@ class LayerWs(C.Structure):
     _fields_ = [("counts", C.c_void_p), ("seg_ptr", C.c_void_p), ("seed_acc", C.c_void_p), ("chunk_cnt", C.c_void_p),
                 ("cand_nid", C.c_void_p), ("p", C.c_void_p), ("P", C.c_void_p), ("new_id", C.c_void_p),
                 ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("hist", C.c_void_p), ("src_cnt", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32),
-                ("n_bins", C.c_int32), ("bin_cap", C.c_int64), ("bin_cursor", C.c_void_p), ("bin_rec", C.c_void_p), ("bin_t", C.c_void_p),
-                ("bitmap", C.c_void_p), ("word_prefix", C.c_void_p), ("touched_key", C.c_void_p), ("touched_sum", C.c_void_p)]
+                ("n_bins", C.c_int32), ("bin_cap", C.c_int64), ("bin_cursor", C.c_void_p), ("bin_rec", C.c_void_p),
+                ("bitmap", C.c_void_p), ("word_prefix", C.c_void_p), ("touched_key", C.c_void_p), ("touched_sum", C.c_void_p),
+                ("kept_map", C.c_void_p)]
 
 
 class BlockOut(C.Structure):

@@ -29,6 +29,7 @@ namespace {
 // items of 64 (one position per lane).  Consecutive items let the segment lookup carry its hint, and
 // ordered ranks come from ballots + one 4-entry LDS exchange per chunk instead of a block scan per item.
 #define SPAN (64 * ITEMS)
+#define SEG_ZERO_WGS 8
 
 struct EdgeAt {
   int k;          // seed index (local destination id); valid iff e < E
@@ -86,10 +87,15 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
-  // acc_w, acc_q, acc_wt (u64) + deg_blk (i32) + seed_p2 (u64)
-  for (int i = threadIdx.x; i < cap_s * 5; i += blockDim.x) seed_acc[i] = 0ull;
-  if (bin_cursor) for (int i = threadIdx.x; i <= n_bins; i += blockDim.x) bin_cursor[i] = 0;   // [n_bins] = touched count
-  if (src_cnt) for (int i = threadIdx.x; i <= cap_k; i += blockDim.x) src_cnt[i] = 0;
+  if (blockIdx.x > 0 || gridDim.x == 1) {                            // the zeroing does not wait for the serial scan
+    const int nz = gridDim.x > 1 ? gridDim.x - 1 : 1, bz = gridDim.x > 1 ? blockIdx.x - 1 : 0;
+    const int t0 = bz * blockDim.x + threadIdx.x, step = nz * blockDim.x;
+    // acc_w, acc_q, acc_wt (u64) + deg_blk (i32) + seed_p2 (u64)
+    for (int i = t0; i < cap_s * 5; i += step) seed_acc[i] = 0ull;
+    if (src_cnt) for (int i = t0; i <= cap_k; i += step) src_cnt[i] = 0;
+    if (bin_cursor) for (int i = t0; i <= n_bins; i += step) bin_cursor[i] = 0;   // [n_bins] = touched count
+    if (gridDim.x > 1) return;
+  }
   long long run = 0;
   for (int base = 0; base < S; base += blockDim.x) {
     int k = base + threadIdx.x, deg = 0;
@@ -111,10 +117,8 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
     seg_ptr[S] = (int)run;
     cnt->S = S; cnt->E = (any_bad & BLISS_ERR_CAP_FRONTIER) ? 0 : (int)run;
     cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
-    cnt->err = 0;
+    cnt->err = any_bad;
   }
-  __syncthreads();
-  if (bad) atomicOr(&cnt->err, bad);
 }
 
 // ---------------------------------------------------------------- K_b: first appearance + sum_j w_ij
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 // atomicAdd (sum of squares) per frontier edge, ~14 edges per candidate on a Reddit-like layer, at the ~20 G atomics/s
 // the memory side sustains.  When |V| / n_bins node slots fit in LDS the same two reductions are done there instead:
 //   k_col_sums     one workgroup per seed column: sum_j w_ij, then sum_k q_ik with the column held in registers
-//   k_bin_scatter  every edge becomes a record (position, source, (q/sum q)^2), multisplit in LDS by source % n_bins and
+//   k_bin_scatter  every edge becomes one 64-bit record (position, source, (q/sum q)^2), multisplit in LDS by source % n_bins and
 //                  appended to its bin with ONE global atomic per (workgroup, bin)
 //   k_bin_reduce   one workgroup per bin: min position and exact fixed-point sum per source with LDS atomics; sets one
 //                  bit per first appearance in a bitmap over frontier positions and lists the touched sources
@@ -392,9 +396,8 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
                                                      const int* __restrict__ seg_ptr, LayerCounts* cnt,
                                                      const unsigned long long* __restrict__ acc_w,
                                                      const unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                                     int uniform_nodes, int n_bins, long long bin_cap, int* bin_cursor,
-                                                     unsigned long long* __restrict__ bin_rec, bf16_t* __restrict__ bin_t,
-                                                     unsigned* __restrict__ bitmap) {
+                                                     int uniform_nodes, int n_bins, int log2_bins, long long bin_cap, int* bin_cursor,
+                                                     unsigned long long* __restrict__ bin_rec, unsigned* __restrict__ bitmap) {
   __shared__ int hist[MAX_BINS];
   __shared__ int gbase[MAX_BINS];
   const int S = cnt->S, E = cnt->E, tid = threadIdx.x;
@@ -452,8 +455,8 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
         if (idx < bin_cap) {
           const size_t o = (size_t)b * (size_t)bin_cap + (size_t)idx;
           const unsigned e = (unsigned)(wbase + j * 64 + lane_id());
-          bin_rec[o] = ((unsigned long long)e << 32) | (unsigned)srcs[j];
-          bin_t[o] = ts[j];
+          // position (32) | slot = source / n_bins (17) | term (15: squares are non-negative) -- one 8-byte store per edge
+          bin_rec[o] = ((unsigned long long)e << 32) | ((unsigned long long)((unsigned)srcs[j] >> log2_bins) << 15) | (ts[j] & 0x7fffu);
         }
       }
     }
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
 
 __global__ void __launch_bounds__(BINRED_TPB) k_bin_reduce(LayerCounts* cnt, int n_bins, int log2_bins, long long bin_cap,
                                                            int* bin_cursor, const unsigned long long* __restrict__ bin_rec,
-                                                           const bf16_t* __restrict__ bin_t, int num_nodes, int slots,
+                                                           int num_nodes, int slots,
                                                            const int* __restrict__ local_id, unsigned long long* __restrict__ seed_p2,
                                                            unsigned long long* __restrict__ touched_key,
                                                            unsigned long long* __restrict__ touched_sum, unsigned* bitmap, int cap_c) {
@@ -479,13 +482,12 @@ __global__ void __launch_bounds__(BINRED_TPB) k_bin_reduce(LayerCounts* cnt, int
   long long n = bin_cursor[b];
   if (n > bin_cap) n = bin_cap;
   const unsigned long long* rec = bin_rec + (size_t)b * (size_t)bin_cap;
-  const bf16_t* tt = bin_t + (size_t)b * (size_t)bin_cap;
   int bad = 0;
   for (long long i = tid; i < n; i += BINRED_TPB) {
     const unsigned long long r = rec[i];
-    const int li = (int)((unsigned)r >> log2_bins);
+    const int li = (int)(((unsigned)r) >> 15);
     atomicMin(&mn[li], (unsigned)(r >> 32));
-    const int64_t fx = bf_to_fixed(tt[i], FRAC_SRC, &bad);
+    const int64_t fx = bf_to_fixed((bf16_t)(r & 0x7fffu), FRAC_SRC, &bad);
     if (fx) atomicAdd(&sm[li], (unsigned long long)fx);                         // :73 copy_e_sum by SOURCE
   }
   __syncthreads();
@@ -690,7 +692,7 @@ __global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ 
                                                       const bf16_t* __restrict__ P, const int* __restrict__ chunk_off,
                                                       const int* __restrict__ cand_nid, int* __restrict__ new_id,
                                                       int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
-                                                      int cap_c, int cap_k) {
+                                                      int cap_c, int cap_k, int* __restrict__ kept_map) {
   __shared__ int sh4[TPB / 64];
   const float* __restrict__ uniforms = uniforms_base + (u_off ? *u_off : 0);
   const int C = min(cnt->C, cap_c);
@@ -716,8 +718,11 @@ __global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ 
       if (j < C) {
         const bool keep = (mask[i] >> lane_id()) & 1ull;
         const int r = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
-        if (keep && r < cap_k) { kept_nid[r] = cand_nid[j]; node_prob[r] = Pv[i]; new_id[j] = r; }   // :306,:309
-        else new_id[j] = -1;
+        if (keep && r < cap_k) {
+          const int g = cand_nid[j];
+          kept_nid[r] = g; node_prob[r] = Pv[i]; new_id[j] = r;   // :306,:309
+          if (kept_map) kept_map[g] = r;                 // dense: the block passes find a kept source with ONE gather
+        } else new_id[j] = -1;
       }
       run += __popcll(mask[i]);
     }
@@ -746,7 +751,8 @@ __global__ void __launch_bounds__(TPB) k_mn_mark(LayerCounts* cnt, const int* __
 template <bool EMIT>
 __global__ void __launch_bounds__(TPB) k_mn_select(LayerCounts* cnt, const bf16_t* __restrict__ P, int* __restrict__ chunk_io,
                                                    const int* __restrict__ cand_nid, int* __restrict__ new_id,
-                                                   int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob, int cap_c, int cap_k) {
+                                                   int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob, int cap_c, int cap_k,
+                                                   int* __restrict__ kept_map) {
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, C = min(cnt->C, cap_c);
   const int nchunks = (C + CHUNK - 1) / CHUNK;
@@ -771,8 +777,11 @@ __global__ void __launch_bounds__(TPB) k_mn_select(LayerCounts* cnt, const bf16_
       if (j < C) {
         const bool in_u = (mask[i] >> lane_id()) & 1ull;
         const int r = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
-        if (in_u && r < cap_k) { kept_nid[r] = cand_nid[j]; node_prob[r] = P[j]; new_id[j] = drawn[i] == 1 ? r : -2 - r; }
-        else new_id[j] = -1;
+        if (in_u && r < cap_k) {
+          const int g = cand_nid[j];
+          kept_nid[r] = g; node_prob[r] = P[j]; new_id[j] = drawn[i] == 1 ? r : -2 - r;
+          if (kept_map && drawn[i] == 1) kept_map[g] = r;
+        } else new_id[j] = -1;
       }
       run += __popcll(mask[i]);
     }
@@ -791,7 +800,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      const unsigned long long* __restrict__ acc_w,
                                                      const int* __restrict__ local_id, const int* __restrict__ new_id,
                                                      const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
-                                                     int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f) {
+                                                     int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f,
+                                                     const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob) {
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -806,14 +816,15 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
       int kept = 0;
       int64_t term = 0;
       if (a.k >= 0) {
-        const int lid = local_id[a.src];
-        const int nid = new_id[lid];
+        int lid = 0, nid;
+        if (kept_map) nid = kept_map[a.src];           // one gather; only ~B/E of the edges go on
+        else { lid = local_id[a.src]; nid = new_id[lid]; }
         kept = nid >= 0;                               // :289-298 source was drawn (seeds always are)
         if (kept && src_cnt) atomicAdd(src_cnt + nid, 1);   // out-degree inside the block: sizes the by-source index
         if (kept && BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
           bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
-          bf16_t wt = f2bf(bf2f(q) / bf2f(P[lid]));    // :314 e_div_u(sg, W, P)
+          bf16_t wt = f2bf(bf2f(q) / bf2f(kept_map ? node_prob[nid] : P[lid]));    // :314 e_div_u(sg, W, P)
           term = bf_to_fixed(wt, FRAC_BLK, &bad);      // :316 copy_e_sum
         }
       }
@@ -887,7 +898,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      int* __restrict__ out_dst, int* __restrict__ out_pos,
                                                      int* __restrict__ out_eid, bf16_t* __restrict__ out_w,
                                                      bf16_t* __restrict__ out_q, int* src_cursor, int* __restrict__ t_unsorted,
-                                                     float eta_f, float ome_f, int cap_b) {
+                                                     float eta_f, float ome_f, int cap_b, const int* __restrict__ kept_map,
+                                                     const bf16_t* __restrict__ node_prob) {
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -904,8 +916,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
       if (base >= E) continue;
       ed[i] = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
       if (ed[i].k >= 0) {
-        lids[i] = local_id[ed[i].src];
-        nids[i] = new_id[lids[i]];
+        if (kept_map) nids[i] = kept_map[ed[i].src];
+        else { lids[i] = local_id[ed[i].src]; nids[i] = new_id[lids[i]]; }
       }
       mask[i] = __ballot(nids[i] >= 0);
       wave_total += __popcll(mask[i]);
@@ -923,7 +935,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
           q = edge_q(w[pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
         } else q = w[pos];
-        float wt = rbf(bf2f(q) / bf2f(P[lids[i]]));                    // :314
+        float wt = rbf(bf2f(q) / bf2f(kept_map ? node_prob[nids[i]] : P[lids[i]]));   // :314
         float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
         float out;
         if (BANDIT) {
@@ -947,6 +959,15 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
   if (bad) atomicOr(&cnt->err, bad);
 }
 
+// leave the dense node maps clean (every touched entry back to -1)
+__device__ __forceinline__ void maps_cleanup(LayerCounts* cnt, const int* __restrict__ cand_nid, int* local_id, int cap_c,
+                                             const int* __restrict__ kept_nid, int* kept_map, int cap_k) {
+  const int C = min(cnt->C, cap_c), K = min(cnt->K, cap_k);
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+  for (int id = t0; id < C; id += step) local_id[cand_nid[id]] = -1;
+  if (kept_map) for (int r = t0; r < K; r += step) kept_map[kept_nid[r]] = -1;
+}
+
 // ---------------------------------------------------------------- by-source lists into ascending edge order
 // One wave per source.  A source has at most one edge per destination, so an edge's rank inside its list is the
 // number of list members with a smaller destination: short lists (<= 64) rank in registers, longer ones through a
@@ -954,8 +975,10 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
 #define TSORT_MAX_S 32768
 __global__ void __launch_bounds__(TPB) k_tr_sort_lists(const int* __restrict__ t_indptr, const int* __restrict__ t_unsorted,
                                                        const int* __restrict__ dst, LayerCounts* cnt, int cap_k, int cap_s,
-                                                       int* __restrict__ t_edge) {
+                                                       int* __restrict__ t_edge, const int* __restrict__ cand_nid, int* local_id,
+                                                       int cap_c, const int* __restrict__ kept_nid, int* kept_map) {
   extern __shared__ unsigned bm_all[];
+  maps_cleanup(cnt, cand_nid, local_id, cap_c, kept_nid, kept_map, cap_k);   // independent of the lists below
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int words = (cap_s + 31) / 32;
   unsigned* bm = bm_all + (size_t)wave * (words + 1);
@@ -1002,9 +1025,9 @@ __global__ void __launch_bounds__(TPB) k_tr_sort_lists(const int* __restrict__ t
 }
 
 // ---------------------------------------------------------------- K_o: leave the dense id map clean
-__global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __restrict__ cand_nid, int* local_id, int cap_c) {
-  const int C = min(cnt->C, cap_c);
-  for (int id = blockIdx.x * TPB + threadIdx.x; id < C; id += gridDim.x * TPB) local_id[cand_nid[id]] = -1;
+__global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __restrict__ cand_nid, int* local_id, int cap_c,
+                                                 const int* __restrict__ kept_nid, int* kept_map, int cap_k) {
+  maps_cleanup(cnt, cand_nid, local_id, cap_c, kept_nid, kept_map, cap_k);
 }
 
 inline int grid_for(int64_t n, int per_block, int max_blocks = 2048) {
@@ -1044,10 +1067,10 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     while ((1 << log2_bins) < ws->n_bins) ++log2_bins;
     slots = (g->num_nodes + ws->n_bins - 1) >> log2_bins;
     if ((1 << log2_bins) != ws->n_bins || ws->n_bins > MAX_BINS || (size_t)slots * 12 > 64 * 1024 || ws->bin_cap <= 0 ||
-        !ws->bin_cursor || !ws->bin_rec || !ws->bin_t || !ws->bitmap || !ws->word_prefix || !ws->touched_key || !ws->touched_sum)
+        !ws->bin_cursor || !ws->bin_rec || !ws->bitmap || !ws->word_prefix || !ws->touched_key || !ws->touched_sum)
       return BLISS_EINVAL;
   }
-  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
+  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
                                                             binned ? ws->bin_cursor : nullptr, ws->n_bins));
   if (binned) {
@@ -1057,16 +1080,16 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
       PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f));
     if (mode == BLISS_MODE_BANDIT)
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
     else
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (bf16_t*)ws->bin_t, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
-        cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, (const bf16_t*)ws->bin_t, g->num_nodes, slots, m->local_id, seed_p2,
+        cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
     if (frontier_bound > (int64_t)MAX_TILES * BTILE * 32) return BLISS_EINVAL;
     int* tile_sum = ws->word_prefix + ((frontier_bound + 4095) / 4096 + 1) * 128 + 4;    // the tile totals live behind the word prefixes
     PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_tiles<<<grid_for(frontier_bound, (int64_t)BTILE * 32, MAX_TILES), 1024, 0, st>>>(ws->bitmap, ws->word_prefix, tile_sum, cnt));
-    int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);
+    int gf = (ws->cap_c + FIN_TPB * 2 - 1) / (FIN_TPB * 2);          // one 128 KiB-LDS workgroup per CU: spread the latency-bound items
     if (gf < 1) gf = 1;
     if (gf > 256) gf = 256;
     PROF_LAUNCH(BK_CAND_NUMBER, st, k_cand_number<<<gf, FIN_TPB, 0, st>>>(
@@ -1109,7 +1132,7 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
   PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, uniforms_offset_dev, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
-                                     ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k));
+                                     ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map));
   return (int)hipGetLastError();
 }
 
@@ -1120,9 +1143,9 @@ int bliss_multinomial_select(const bliss_layer_ws_t* ws, const int32_t* chosen, 
   const int gc = grid_for(ws->cap_c, CHUNK), ge = grid_for(ws->cap_c, TPB);
   k_mn_prepare<<<ge, TPB, 0, st>>>(cnt, (const bf16_t*)ws->p, (bf16_t*)ws->P, ws->new_id, ws->cap_c);
   if (n_chosen > 0) k_mn_mark<<<grid_for(n_chosen, TPB), TPB, 0, st>>>(cnt, chosen, n_chosen, ws->new_id, ws->cap_c);
-  k_mn_select<false><<<gc, TPB, 0, st>>>(cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k);
+  k_mn_select<false><<<gc, TPB, 0, st>>>(cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map);
   k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k);
-  k_mn_select<true><<<gc, TPB, 0, st>>>(cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k);
+  k_mn_select<true><<<gc, TPB, 0, st>>>(cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map);
   return (int)hipGetLastError();
 }
 
@@ -1145,19 +1168,20 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   if (want_t && cap_s > TSORT_MAX_S) return BLISS_EINVAL;                    // caller falls back to bliss_block_transpose
   int* sc = want_t ? src_cnt : nullptr;
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
   else
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
   PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<want_t ? 3 : 2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b, src_cnt, out->t_indptr, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
   else
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b));
-  if (want_t) {
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
+  if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
     const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
-    PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge));
+    PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map));
+  } else {
+    PROF_LAUNCH(BK_CLEANUP, st, k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map, ws->cap_k));
   }
-  PROF_LAUNCH(BK_CLEANUP, st, k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c));
   return (int)hipGetLastError();
 }
 

@@ -80,12 +80,13 @@ typedef struct {
   int32_t n_bins;
   int64_t bin_cap;          /* records per bin; a bin that overflows raises BLISS_ERR_CAP_CAND */
   int32_t* bin_cursor;      /* [n_bins + 1] */
-  uint64_t* bin_rec;        /* [n_bins * bin_cap] (frontier position << 32 | source id) */
-  void* bin_t;              /* bf16 [n_bins * bin_cap] the edge's term of p_j^2 */
+  uint64_t* bin_rec;        /* [n_bins * bin_cap] frontier position (32) | source / n_bins (17) | bf16 term of p_j^2 (15) */
   uint32_t* bitmap;         /* [frontier_bound / 32 rounded up to 128 words, + 4] first appearances by frontier position */
   int32_t* word_prefix;     /* [same length + 2048] exclusive popcount prefix of the bitmap words (per 4096-word tile) + tile totals */
   uint64_t* touched_key;    /* [cap_c] (first position << 32 | source id) of every non-seed frontier source */
   uint64_t* touched_sum;    /* [cap_c] its exact sum */
+  int32_t* kept_map;        /* [num_nodes] block-local id of a kept node, -1 everywhere on entry and on exit of
+                               bliss_build_block; NULL = look kept sources up through local_id + new_id (two gathers) */
 } bliss_layer_ws_t;
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
