@@ -42,7 +42,7 @@ class _LayerWs:
     def __init__(self, dev, cap_s, cap_c):
         self.cap_s, self.cap_c = cap_s, cap_c
         self.seg_ptr = torch.empty(cap_s + 1, dtype=torch.int32, device=dev)
-        self.seed_acc = torch.empty(40 * cap_s, dtype=torch.uint8, device=dev)
+        self.seed_acc = torch.empty(48 * cap_s, dtype=torch.uint8, device=dev)
         self.cand_nid = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.new_id = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)
@@ -69,6 +69,7 @@ class LayerEngine:
         self.first_pos = torch.full((V,), -1, dtype=torch.int32, device=dev)      # 0xFFFFFFFF
         self.acc_p2 = torch.zeros(V, dtype=torch.int64, device=dev)
         self.kept_map = torch.full((V,), -1, dtype=torch.int32, device=dev)
+        self.span_seg = torch.zeros(self.Eg // 256 + 2, dtype=torch.int32, device=dev)
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
@@ -303,7 +304,7 @@ class LayerEngine:
                             ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
                             kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
                             ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
-        c_ws.kept_map = self.kept_map.data_ptr()
+        c_ws.kept_map, c_ws.span_seg = self.kept_map.data_ptr(), self.span_seg.data_ptr()
         if self.n_bins:
             b = self._bin_buffers()
             c_ws.n_bins, c_ws.bin_cap = self.n_bins, b["cap"]

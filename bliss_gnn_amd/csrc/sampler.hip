@@ -39,14 +39,13 @@ struct EdgeAt {
 
 // lane's edge at frontier position e = base + lane (base wave-uniform)
 __device__ __forceinline__ EdgeAt decode(int base, int E, int S, const int* __restrict__ seg_ptr,
-                                         const int* __restrict__ seeds, const int64_t* __restrict__ indptr,
-                                         const int* __restrict__ indices, int* k_hint) {
+                                         const long long* __restrict__ col_base, const int* __restrict__ indices, int* k_hint) {
   EdgeAt r;
   const int e = base + lane_id();
   r.k = wave_segment(seg_ptr, S, base, k_hint);
   r.pos = 0; r.src = 0;
   if (e < E) {
-    r.pos = indptr[seeds[r.k]] + (e - seg_ptr[r.k]);
+    r.pos = col_base[r.k] + e;                       // = indptr[seeds[k]] + (e - seg_ptr[k]), folded by k_seg_scan
     r.src = indices[r.pos];
   } else r.k = -1;
   return r;
@@ -82,7 +81,8 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
                                                    LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
                                                    unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
                                                    int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
-                                                   int* __restrict__ bin_cursor, int n_bins) {
+                                                   int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
+                                                   int* __restrict__ span_seg) {
   __shared__ int sh[17];
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
@@ -108,7 +108,14 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
       }
     }
     int tot, ex = block_excl_scan(deg, sh, &tot);
-    if (k < S) seg_ptr[k] = (int)(run + ex);
+    if (k < S) {
+      const long long start = run + ex;
+      seg_ptr[k] = (int)start;
+      // what every frontier pass needs to find its edges without a search and without chasing seeds -> indptr:
+      col_base[k] = deg > 0 ? (long long)indptr[seeds[k]] - start : 0;            // CSC position = col_base[k] + frontier position
+      if (start + deg <= 0x7fffffffll)
+        for (long long sp = (start + SPAN - 1) / SPAN; sp * SPAN < start + deg; ++sp) span_seg[sp] = k;   // segment of position sp * 256
+    }
     run += tot;
     if (run > 0x7fffffffll) bad |= BLISS_ERR_CAP_FRONTIER;
   }
@@ -125,20 +132,21 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                         const bf16_t* __restrict__ w, const int* __restrict__ seeds,
-                                                        const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                        const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt,
                                                         const int* __restrict__ local_id, unsigned* first_pos,
                                                         unsigned long long* acc_w) {
   const int S = cnt->S, E = cnt->E;
   const int nspans = (E + SPAN - 1) / SPAN;
   int bad = 0;
   for (int sp = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); sp < nspans; sp += gridDim.x * (TPB / 64)) {
-    int hint = -1;
+    int hint = span_seg[sp];                                 // the segment this span starts in (k_seg_scan)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int base = sp * SPAN + i * 64;
       if (base >= E) break;                                 // wave-uniform
       const int e = base + lane_id();
-      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
       int64_t term = 0;
       if (a.k >= 0) {
         if (local_id[a.src] < 0) {                          // not a seed: seeds are numbered already
@@ -159,7 +167,8 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restric
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                         const bf16_t* __restrict__ w, const int* __restrict__ seeds,
-                                                        const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                        const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt,
                                                         const unsigned* __restrict__ first_pos,
                                                         const unsigned long long* __restrict__ acc_w,
                                                         unsigned long long* acc_q, int* __restrict__ chunk_cnt,
@@ -169,13 +178,13 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restric
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int nfirst = 0, hint = -1;
+    int nfirst = 0, hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
       if (base >= E) break;
       const int e = base + lane_id();
-      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
       int64_t term = 0;
       bool first = false;
       if (a.k >= 0) {
@@ -222,7 +231,8 @@ __global__ void __launch_bounds__(1024) k_chunk_scan(int* __restrict__ chunk_cnt
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                         const bf16_t* __restrict__ w, const int* __restrict__ seeds,
-                                                        const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                        const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt,
                                                         const unsigned* __restrict__ first_pos,
                                                         const unsigned long long* __restrict__ acc_w,
                                                         const unsigned long long* __restrict__ acc_q,
@@ -234,7 +244,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int hint = -1, wave_total = 0;
+    int hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)], wave_total = 0;
     unsigned long long mask[ITEMS];
     int srcs[ITEMS];
 #pragma unroll
@@ -243,7 +253,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
       const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
       if (base >= E) continue;
       const int e = base + lane_id();
-      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
       bool first = false;
       if (a.k >= 0) {
         srcs[i] = a.src;
@@ -354,7 +364,8 @@ __device__ __forceinline__ long long block_sum_i64(long long v, long long* sh) {
 }
 
 __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt,
                                                       unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
                                                       float eta_f, float ome_f) {
   __shared__ long long sh[COL_TPB / 64];
@@ -393,7 +404,8 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
 template <bool BANDIT>
 __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                      const bf16_t* __restrict__ w, const int* __restrict__ seeds,
-                                                     const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                     const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt,
                                                      const unsigned long long* __restrict__ acc_w,
                                                      const unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
                                                      int uniform_nodes, int n_bins, int log2_bins, long long bin_cap, int* bin_cursor,
@@ -410,14 +422,14 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
     __syncthreads();
     int srcs[BIN_ITEMS], ranks[BIN_ITEMS];
     bf16_t ts[BIN_ITEMS];
-    int hint = -1;
-    const int wbase = batch * BIN_BATCH + (tid >> 6) * (64 * BIN_ITEMS);       // a wave owns 256 consecutive positions
+    const int wbase = batch * BIN_BATCH + (tid >> 6) * (64 * BIN_ITEMS);
+    int hint = span_seg[wbase >> 8];       // a wave owns 256 consecutive positions
 #pragma unroll
     for (int j = 0; j < BIN_ITEMS; ++j) {
       ranks[j] = -1; srcs[j] = 0; ts[j] = 0;
       const int base = wbase + j * 64;
       if (base >= E) continue;                                                  // wave-uniform
-      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
       if (a.k >= 0) {
         bf16_t t;
         if (uniform_nodes) {
@@ -796,7 +808,8 @@ __global__ void __launch_bounds__(TPB) k_mn_select(LayerCounts* cnt, const bf16_
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                      const bf16_t* __restrict__ w, const int* __restrict__ seeds,
-                                                     const int* __restrict__ seg_ptr, LayerCounts* cnt,
+                                                     const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt,
                                                      const unsigned long long* __restrict__ acc_w,
                                                      const int* __restrict__ local_id, const int* __restrict__ new_id,
                                                      const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
@@ -807,12 +820,12 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int nkept = 0, hint = -1;
+    int nkept = 0, hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
       if (base >= E) break;
-      EdgeAt a = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
       int kept = 0;
       int64_t term = 0;
       if (a.k >= 0) {
@@ -889,8 +902,8 @@ __global__ void __launch_bounds__(1024) k_block_scans(int* __restrict__ chunk_cn
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
                                                      const int* __restrict__ eid_map, const bf16_t* __restrict__ w,
-                                                     const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
-                                                     LayerCounts* cnt, const unsigned long long* __restrict__ acc_w,
+                                                     const int* __restrict__ seeds, const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
+    const int* __restrict__ span_seg, LayerCounts* cnt, const unsigned long long* __restrict__ acc_w,
                                                      const int* __restrict__ local_id, const int* __restrict__ new_id,
                                                      const bf16_t* __restrict__ P, const int* __restrict__ deg_blk,
                                                      const unsigned long long* __restrict__ acc_wt,
@@ -905,7 +918,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
   const int nchunks = (E + CHUNK - 1) / CHUNK;
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int hint = -1, wave_total = 0;
+    int hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)], wave_total = 0;
     unsigned long long mask[ITEMS];
     EdgeAt ed[ITEMS];
     int nids[ITEMS], lids[ITEMS];
@@ -914,7 +927,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
       mask[i] = 0; nids[i] = -1; lids[i] = 0; ed[i].k = -1; ed[i].pos = 0; ed[i].src = 0;
       const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
       if (base >= E) continue;
-      ed[i] = decode(base, E, S, seg_ptr, seeds, indptr, indices, &hint);
+      ed[i] = decode(base, E, S, seg_ptr, col_base, indices, &hint);
       if (ed[i].k >= 0) {
         if (kept_map) nids[i] = kept_map[ed[i].src];
         else { lids[i] = local_id[ed[i].src]; nids[i] = new_id[lids[i]]; }
@@ -1048,7 +1061,7 @@ int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
                         int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode, float eta_f,
                         float one_minus_eta_f, int64_t frontier_bound, const bliss_layer_ws_t* ws, void* stream_) {
-  if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0 || !ws->hist) return BLISS_EINVAL;
+  if (!g || !m || !seeds || !ws || !w_pos || cap_s <= 0 || !ws->hist || !ws->span_seg) return BLISS_EINVAL;
   if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
   if (n_seeds > cap_s) return BLISS_EINVAL;
   const int uniform_nodes = (mode & BLISS_MODE_UNIFORM_NODES) ? 1 : 0;
@@ -1059,6 +1072,7 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   const bf16_t* w = (const bf16_t*)w_pos;
   unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;            // [cap_s]
   unsigned long long* acc_q = acc_w + cap_s;                                // [cap_s]
+  const long long* col_base = (const long long*)(acc_w + 5 * (size_t)cap_s);   // [cap_s], written by k_seg_scan
   if (frontier_bound < 1) frontier_bound = 1;
   const int ge = grid_for(frontier_bound, TPB), gc = grid_for(frontier_bound, CHUNK);
   const bool binned = ws->n_bins > 0;
@@ -1072,17 +1086,17 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   }
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
-                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins));
+                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
     if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f));
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f));
     if (mode == BLISS_MODE_BANDIT)
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
     else
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
         cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
@@ -1098,17 +1112,17 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     return (int)hipGetLastError();
   }
   if (mode == BLISS_MODE_BANDIT) {
-    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
-    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->local_id, m->first_pos, acc_w));
+    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
   } else {
-    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->local_id, m->first_pos, acc_w));
-    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->local_id, m->first_pos, acc_w));
+    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
   }
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 0, ws->cap_c));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
   else
-    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
   {
     int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);          // ~8 candidates per thread: amortise the 128 KiB LDS zero/flush
     if (gf < 1) gf = 1;
@@ -1152,7 +1166,7 @@ int bliss_multinomial_select(const bliss_layer_ws_t* ws, const int32_t* chosen, 
 int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
                       int32_t cap_s, int mode, float eta_f, float one_minus_eta_f, int64_t frontier_bound,
                       const bliss_layer_ws_t* ws, const bliss_block_out_t* out, void* stream_) {
-  if (!g || !m || !seeds || !ws || !out || !w_pos || cap_s <= 0) return BLISS_EINVAL;
+  if (!g || !m || !seeds || !ws || !out || !w_pos || cap_s <= 0 || !ws->span_seg) return BLISS_EINVAL;
   mode &= ~BLISS_MODE_UNIFORM_NODES;
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
@@ -1161,6 +1175,7 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   unsigned long long* acc_w = (unsigned long long*)ws->seed_acc;
   unsigned long long* acc_wt = acc_w + 2 * (size_t)cap_s;
   int* deg_blk = (int*)(acc_w + 3 * (size_t)cap_s);
+  const long long* col_base = (const long long*)(acc_w + 5 * (size_t)cap_s);
   if (frontier_bound < 1) frontier_bound = 1;
   const int gc = grid_for(frontier_bound, CHUNK);
   int* src_cnt = ws->src_cnt;
@@ -1168,14 +1183,14 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   if (want_t && cap_s > TSORT_MAX_S) return BLISS_EINVAL;                    // caller falls back to bliss_block_transpose
   int* sc = want_t ? src_cnt : nullptr;
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
   else
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
   PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<want_t ? 3 : 2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b, src_cnt, out->t_indptr, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
   else
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
   if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
     const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
     PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map));

@@ -63,7 +63,7 @@ typedef struct {
 typedef struct {
   void* counts;             /* bliss_layer_counts_t */
   int32_t* seg_ptr;         /* [cap_s + 1] start of every seed's column in the frontier */
-  void* seed_acc;           /* [40 * cap_s bytes] exact per-seed accumulators */
+  void* seed_acc;           /* [48 * cap_s bytes] exact per-seed accumulators + column bases */
   int32_t* chunk_cnt;       /* [max(frontier_bound, cap_c) / 1024 + 2] */
   int32_t* cand_nid;        /* [cap_c] global id of every candidate, seeds first (ndata[NID]) */
   void* p;                  /* bf16 [cap_c] LADIES importance p_j */
@@ -85,6 +85,7 @@ typedef struct {
   int32_t* word_prefix;     /* [same length + 2048] exclusive popcount prefix of the bitmap words (per 4096-word tile) + tile totals */
   uint64_t* touched_key;    /* [cap_c] (first position << 32 | source id) of every non-seed frontier source */
   uint64_t* touched_sum;    /* [cap_c] its exact sum */
+  int32_t* span_seg;        /* [frontier_bound / 256 + 2] seed column in which every 256th frontier position lies */
   int32_t* kept_map;        /* [num_nodes] block-local id of a kept node, -1 everywhere on entry and on exit of
                                bliss_build_block; NULL = look kept sources up through local_id + new_id (two gathers) */
 } bliss_layer_ws_t;
