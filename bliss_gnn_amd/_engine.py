@@ -129,7 +129,7 @@ class LayerEngine:
             self._bins = dict(cap=cap, cursor=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                               rec=torch.empty(nb * cap, dtype=torch.int64, device=dev),
                               bitmap=torch.zeros(words, dtype=torch.int32, device=dev),
-                              prefix=torch.empty(words + 2048, dtype=torch.int32, device=dev),
+                              prefix=torch.empty(2048 + words, dtype=torch.int32, device=dev),
                               tkey=torch.empty(self.V, dtype=torch.int64, device=dev),
                               tsum=torch.empty(self.V, dtype=torch.int64, device=dev))
         return self._bins
@@ -325,7 +325,10 @@ class LayerEngine:
         for n, f in enumerate(fanouts):
             k = min(self.V, int(k_margin * max_sizes[n]["K"]) + 256)
             b = int(min(self.Eg, int(b_margin * max_sizes[n]["B"]) + 4096))
-            caps.append(dict(S=s, C=self.V, K=k, B=b))
+            # E only sizes launch grids (every kernel strides over the true count): a tight bound lets the hardware balance
+            # the workgroups instead of a capped grid looping unevenly
+            e = int(min(self.Eg, int(1.5 * max_sizes[n].get("E", self.Eg)) + 65536))
+            caps.append(dict(S=s, C=self.V, K=k, B=b, E=e))
             s = k
         self.caps, self.ws = caps, None
         self._ensure(S0, fanouts)
@@ -425,7 +428,7 @@ class LayerEngine:
             w_pos = w_rows[n]
             _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
                                                     cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
-                                                    self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
+                                                    cap.get("E", self.Eg), C.byref(c_ws), st), "bliss_frontier_prob")
             if use_rng:
                 off_ptr = self.rng_ctl.data_ptr() + 4 * (8 + n)
                 _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), self.rng_out.data_ptr(),
@@ -438,7 +441,7 @@ class LayerEngine:
                 _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
                                                          0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
             _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
-                                                  cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, self.Eg, C.byref(c_ws),
+                                                  cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, cap.get("E", self.Eg), C.byref(c_ws),
                                                   C.byref(c_out), st), "bliss_build_block")
             layers.append(lay)
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K

@@ -804,6 +804,37 @@ __global__ void __launch_bounds__(TPB) k_mn_select(LayerCounts* cnt, const bf16_
   }
 }
 
+// ---------------------------------------------------------------- kept edges of a wave's span, compacted
+// Only ~B/E (6 % on a Reddit-like layer) of the frontier edges have a kept source, but with 64 lanes almost every wave has
+// one, so per-edge work guarded by `if (kept)` is paid by everybody.  Both block passes therefore first compact the kept
+// edges of the wave's 256 positions into LDS (frontier order preserved) and run the arithmetic on the dense list.
+struct KeptRec { int k, pos, nid, lid; };               // seed index, CSC position, block-local source id, candidate id
+__device__ __forceinline__ int span_collect(int chunk, int E, int S, const int* __restrict__ seg_ptr,
+                                            const long long* __restrict__ col_base, const int* __restrict__ span_seg,
+                                            const int* __restrict__ indices, const int* __restrict__ kept_map,
+                                            const int* __restrict__ local_id, const int* __restrict__ new_id, KeptRec* buf) {
+  int n = 0, hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
+    if (base >= E) break;                               // wave-uniform
+    EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
+    int lid = 0, nid = -1;
+    if (a.k >= 0) {
+      if (kept_map) nid = kept_map[a.src];              // one gather
+      else { lid = local_id[a.src]; nid = new_id[lid]; }
+    }
+    const unsigned long long mask = __ballot(nid >= 0); // :289-298 source was drawn (seeds always are)
+    if (nid >= 0) {
+      KeptRec r; r.k = a.k; r.pos = (int)a.pos; r.nid = nid; r.lid = lid;
+      buf[n + __popcll(mask & ((1ull << lane_id()) - 1ull))] = r;
+    }
+    n += __popcll(mask);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+  return n;
+}
+
 // ---------------------------------------------------------------- K_l: kept in-degree, sum of q/P per destination
 template <bool BANDIT>
 __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__ indptr, const int* __restrict__ indices,
@@ -816,37 +847,33 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f,
                                                      const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob) {
   __shared__ int sh4[TPB / 64];
+  __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
+  KeptRec* buf = sh_kept[threadIdx.x >> 6];
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int nkept = 0, hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
-      if (base >= E) break;
-      EdgeAt a = decode(base, E, S, seg_ptr, col_base, indices, &hint);
-      int kept = 0;
+    const int n = span_collect(chunk, E, S, seg_ptr, col_base, span_seg, indices, kept_map, local_id, new_id, buf);
+    for (int j0 = 0; j0 < n; j0 += 64) {                // ~B/E of the span's 256 edges: usually one trip
+      const int j = j0 + lane_id();
+      int key = -1;
       int64_t term = 0;
-      if (a.k >= 0) {
-        int lid = 0, nid;
-        if (kept_map) nid = kept_map[a.src];           // one gather; only ~B/E of the edges go on
-        else { lid = local_id[a.src]; nid = new_id[lid]; }
-        kept = nid >= 0;                               // :289-298 source was drawn (seeds always are)
-        if (kept && src_cnt) atomicAdd(src_cnt + nid, 1);   // out-degree inside the block: sizes the by-source index
-        if (kept && BANDIT) {
-          bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
-          bf16_t wt = f2bf(bf2f(q) / bf2f(kept_map ? node_prob[nid] : P[lid]));    // :314 e_div_u(sg, W, P)
+      if (j < n) {
+        const KeptRec r = buf[j];
+        key = r.k;
+        if (src_cnt) atomicAdd(src_cnt + r.nid, 1);     // out-degree inside the block: sizes the by-source index
+        if (BANDIT) {
+          bf16_t wsum = fixed_to_bf((int64_t)acc_w[r.k], FRAC_DST, &bad);
+          bf16_t q = edge_q(w[r.pos], wsum, seg_ptr[r.k + 1] - seg_ptr[r.k], eta_f, ome_f);
+          bf16_t wt = f2bf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));    // :314 e_div_u(sg, W, P)
           term = bf_to_fixed(wt, FRAC_BLK, &bad);      // :316 copy_e_sum
         }
       }
-      nkept += __popcll(__ballot(kept));
-      wave_segsum_atomic_i32(a.k, kept, deg_blk);      // :318 sg.in_degrees()
-      if (BANDIT) wave_segsum_atomic_i64(a.k, term, acc_wt);
+      wave_segsum_atomic_i32(key, key >= 0, deg_blk);  // :318 sg.in_degrees()
+      if (BANDIT) wave_segsum_atomic_i64(key, term, acc_wt);
     }
     int tot;
-    chunk_wave_offset(nkept, sh4, &tot);
+    chunk_wave_offset(n, sh4, &tot);                    // (its barriers also fence buf for the next chunk)
     if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
   }
   if (bad) atomicOr(&cnt->err, bad);
@@ -914,60 +941,44 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      float eta_f, float ome_f, int cap_b, const int* __restrict__ kept_map,
                                                      const bf16_t* __restrict__ node_prob) {
   __shared__ int sh4[TPB / 64];
+  __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
+  KeptRec* buf = sh_kept[threadIdx.x >> 6];
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int hint = span_seg[chunk * ITEMS + (threadIdx.x >> 6)], wave_total = 0;
-    unsigned long long mask[ITEMS];
-    EdgeAt ed[ITEMS];
-    int nids[ITEMS], lids[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      mask[i] = 0; nids[i] = -1; lids[i] = 0; ed[i].k = -1; ed[i].pos = 0; ed[i].src = 0;
-      const int base = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64;
-      if (base >= E) continue;
-      ed[i] = decode(base, E, S, seg_ptr, col_base, indices, &hint);
-      if (ed[i].k >= 0) {
-        if (kept_map) nids[i] = kept_map[ed[i].src];
-        else { lids[i] = local_id[ed[i].src]; nids[i] = new_id[lids[i]]; }
-      }
-      mask[i] = __ballot(nids[i] >= 0);
-      wave_total += __popcll(mask[i]);
-    }
+    const int n = span_collect(chunk, E, S, seg_ptr, col_base, span_seg, indices, kept_map, local_id, new_id, buf);
     int tot;
-    int run = chunk_off[chunk] + chunk_wave_offset(wave_total, sh4, &tot);
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int idx = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
-      if (nids[i] >= 0 && idx < cap_b) {
-        const int k = ed[i].k;
-        const int64_t pos = ed[i].pos;
-        bf16_t q;
-        if (BANDIT) {
-          bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
-          q = edge_q(w[pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
-        } else q = w[pos];
-        float wt = rbf(bf2f(q) / bf2f(kept_map ? node_prob[nids[i]] : P[lids[i]]));   // :314
-        float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
-        float out;
-        if (BANDIT) {
-          bf16_t wts = fixed_to_bf((int64_t)acc_wt[k], FRAC_BLK, &bad);
-          float ratio = rbf(d / bf2f(wts));                            // :320  d / W_tilde_sum
-          out = wt * ratio;                                            // :320  e_mul_v
-        } else {
-          out = wt * d;                                                // ladies_sampler.py:97
-        }
-        out_src[idx] = nids[i];
-        if (src_cursor) t_unsorted[atomicAdd(src_cursor + nids[i], 1)] = idx;   // its source's list, arbitrary order for now
-        out_dst[idx] = k;
-        out_pos[idx] = (int)pos;
-        out_eid[idx] = eid_map ? eid_map[pos] : (int)pos;              // :335-337
-        out_w[idx] = f2bf(out);                                        // :324 edge_weights
-        out_q[idx] = q;                                                // :326 q_ij
+    const int run = chunk_off[chunk] + chunk_wave_offset(n, sh4, &tot);
+    for (int j = lane_id(); j < n; j += 64) {
+      const int idx = run + j;
+      if (idx >= cap_b) break;
+      const KeptRec r = buf[j];
+      const int k = r.k;
+      bf16_t q;
+      if (BANDIT) {
+        bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
+        q = edge_q(w[r.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+      } else q = w[r.pos];
+      float wt = rbf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));   // :314
+      float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
+      float out;
+      if (BANDIT) {
+        bf16_t wts = fixed_to_bf((int64_t)acc_wt[k], FRAC_BLK, &bad);
+        float ratio = rbf(d / bf2f(wts));                            // :320  d / W_tilde_sum
+        out = wt * ratio;                                            // :320  e_mul_v
+      } else {
+        out = wt * d;                                                // ladies_sampler.py:97
       }
-      run += __popcll(mask[i]);
+      out_src[idx] = r.nid;
+      if (src_cursor) t_unsorted[atomicAdd(src_cursor + r.nid, 1)] = idx;   // its source's list, arbitrary order for now
+      out_dst[idx] = k;
+      out_pos[idx] = r.pos;
+      out_eid[idx] = eid_map ? eid_map[r.pos] : r.pos;               // :335-337
+      out_w[idx] = f2bf(out);                                        // :324 edge_weights
+      out_q[idx] = q;                                                // :326 q_ij
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // buf is rewritten by the next chunk
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -1043,7 +1054,7 @@ __global__ void __launch_bounds__(TPB) k_cleanup(LayerCounts* cnt, const int* __
   maps_cleanup(cnt, cand_nid, local_id, cap_c, kept_nid, kept_map, cap_k);
 }
 
-inline int grid_for(int64_t n, int per_block, int max_blocks = 2048) {
+inline int grid_for(int64_t n, int per_block, int max_blocks = 8192) {
   int64_t g = (n + per_block - 1) / per_block;
   if (g < 1) g = 1;
   if (g > max_blocks) g = max_blocks;
@@ -1100,15 +1111,15 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
         cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
-    if (frontier_bound > (int64_t)MAX_TILES * BTILE * 32) return BLISS_EINVAL;
-    int* tile_sum = ws->word_prefix + ((frontier_bound + 4095) / 4096 + 1) * 128 + 4;    // the tile totals live behind the word prefixes
-    PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_tiles<<<grid_for(frontier_bound, (int64_t)BTILE * 32, MAX_TILES), 1024, 0, st>>>(ws->bitmap, ws->word_prefix, tile_sum, cnt));
+    int* tile_sum = ws->word_prefix;                     // [MAX_TILES] tile totals, then the word prefixes
+    int* word_prefix = ws->word_prefix + MAX_TILES;
+    PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_tiles<<<grid_for(frontier_bound, (int64_t)BTILE * 32, MAX_TILES), 1024, 0, st>>>(ws->bitmap, word_prefix, tile_sum, cnt));
     int gf = (ws->cap_c + FIN_TPB * 2 - 1) / (FIN_TPB * 2);          // one 128 KiB-LDS workgroup per CU: spread the latency-bound items
     if (gf < 1) gf = 1;
     if (gf > 256) gf = 256;
     PROF_LAUNCH(BK_CAND_NUMBER, st, k_cand_number<<<gf, FIN_TPB, 0, st>>>(
         seeds, cnt, ws->cand_nid, m->local_id, seed_p2, (const unsigned long long*)ws->touched_key,
-        (const unsigned long long*)ws->touched_sum, ws->bitmap, ws->word_prefix, tile_sum, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
+        (const unsigned long long*)ws->touched_sum, ws->bitmap, word_prefix, tile_sum, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
     return (int)hipGetLastError();
   }
   if (mode == BLISS_MODE_BANDIT) {

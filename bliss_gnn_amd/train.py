@@ -119,17 +119,18 @@ class GraphedTrainStep:
     def calibrate(self, loader, steps=8, k_margin=1.5, b_margin=3.0):
         """Run eager sampling to learn per-layer sizes, then fix the static capacities."""
         L = len(self.sampler.nodes_per_layer)
-        mx = [dict(K=0, B=0) for _ in range(L)]
+        mx = [dict(K=0, B=0, E=0) for _ in range(L)]
         for _ in range(steps):
             _, _, blocks = self.sampler.sample_blocks(self.g, next(loader))
             for n, b in enumerate(reversed(blocks)):                      # sampling order
                 mx[n]["K"] = max(mx[n]["K"], b.num_src_nodes())
                 mx[n]["B"] = max(mx[n]["B"], b.num_edges())
+                mx[n]["E"] = max(mx[n]["E"], b._counts.E)
         if self.distributed:                       # the exchanged lists are capacity-sized: every rank needs the same capacities
             import torch.distributed as dist
-            t = torch.tensor([[m["K"], m["B"]] for m in mx], dtype=torch.int64, device=self.g.device)
+            t = torch.tensor([[m["K"], m["B"], m["E"]] for m in mx], dtype=torch.int64, device=self.g.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mx = [dict(K=int(k), B=int(b)) for k, b in t.tolist()]
+            mx = [dict(K=int(k), B=int(b), E=int(e)) for k, b, e in t.tolist()]
         fan = [self.sampler.nodes_per_layer[b] for b in reversed(range(L))]
         self.sampler._engine.set_static_caps(self.bs, fan, mx, k_margin, b_margin)
 

@@ -82,7 +82,7 @@ typedef struct {
   int32_t* bin_cursor;      /* [n_bins + 1] */
   uint64_t* bin_rec;        /* [n_bins * bin_cap] frontier position (32) | source / n_bins (17) | bf16 term of p_j^2 (15) */
   uint32_t* bitmap;         /* [frontier_bound / 32 rounded up to 128 words, + 4] first appearances by frontier position */
-  int32_t* word_prefix;     /* [same length + 2048] exclusive popcount prefix of the bitmap words (per 4096-word tile) + tile totals */
+  int32_t* word_prefix;     /* [2048 + same length] 2048 tile totals, then the exclusive popcount prefix of the bitmap words (per 4096-word tile) */
   uint64_t* touched_key;    /* [cap_c] (first position << 32 | source id) of every non-seed frontier source */
   uint64_t* touched_sum;    /* [cap_c] its exact sum */
   int32_t* span_seg;        /* [frontier_bound / 256 + 2] seed column in which every 256th frontier position lies */
