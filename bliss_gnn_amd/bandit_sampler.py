@@ -76,7 +76,7 @@ class BanditLadiesSampler(BlockSampler):
         self.delta = 0.01                      # bandit_sampler.py:233
         self._delta_f = float(torch.tensor(self.delta, dtype=torch.float32))
         self._w_pos = None                     # exp3 weights [L, |E|] bf16 in CSC-position order
-        self._row_sum = None                   # exact row sums, int64 [L, 3]
+        self._row_sum = None                   # exact row sums, int64 [L, 3 * 32 replicas]
         self._engine = None
 
     def _mode(self):
@@ -92,10 +92,10 @@ class BanditLadiesSampler(BlockSampler):
         if self._w_pos is None:                                         # bandit_sampler.py:342-343
             L, E = len(self.nodes_per_layer), g.num_edges()
             self._w_pos = torch.ones(L, E, dtype=torch.bfloat16, device=g.device)
-            rs = torch.zeros(L, 3, dtype=torch.int64, device=g.device)
+            rs = torch.zeros(L, 96, dtype=torch.int64, device=g.device)      # 32 replicas of three limbs, summed by the readers
             rs[:, 2] = E                                                # sum of E ones = E * 2^64
             self._row_sum = rs
-            self._scratch = torch.zeros(L, 6, dtype=torch.int64, device=g.device)
+            self._scratch = torch.zeros(L, 98, dtype=torch.int64, device=g.device)
             self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
             self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
 
@@ -114,8 +114,8 @@ class BanditLadiesSampler(BlockSampler):
         g = self._engine.g
         self._w_pos = g.by_position(value.to(torch.bfloat16)).contiguous().clone()
         L = self._w_pos.shape[0]
-        self._row_sum = torch.zeros(L, 3, dtype=torch.int64, device=g.device)
-        self._scratch = torch.zeros(L, 6, dtype=torch.int64, device=g.device)
+        self._row_sum = torch.zeros(L, 96, dtype=torch.int64, device=g.device)
+        self._scratch = torch.zeros(L, 98, dtype=torch.int64, device=g.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
         self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
         for l in range(L):

@@ -40,16 +40,27 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
   return v;
 }
 
+// The exact sum lives in BLISS_ROWSUM_SLOTS replicas of three limbs (its value is the sum over the replicas): every wave
+// adds its total to the replica picked by its global wave id, so that thousands of waves do not serialise on three
+// addresses (a same-address memory-side atomic costs ~8 ns; 49 K of them made one renormalisation pass take 470 us).
+#define ROWSUM_SLOTS BLISS_ROWSUM_SLOTS
 __device__ __forceinline__ void flush_digits(int64_t d[3], int64_t* limbs) {
+  const int slot = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % ROWSUM_SLOTS);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     int64_t s = wave_sum_i64(d[i]);
-    if (lane_id() == 0 && s != 0) atomicAdd((unsigned long long*)(limbs + i), (unsigned long long)s);
+    if (lane_id() == 0 && s != 0) atomicAdd((unsigned long long*)(limbs + 3 * slot + i), (unsigned long long)s);
   }
+}
+__device__ __forceinline__ void gather_limbs(const int64_t* limbs, int64_t out[3]) {
+  out[0] = out[1] = out[2] = 0;
+  for (int s = 0; s < ROWSUM_SLOTS; ++s) { out[0] += limbs[3 * s]; out[1] += limbs[3 * s + 1]; out[2] += limbs[3 * s + 2]; }
 }
 
 // exact (l0 + l1*2^32 + l2*2^64) * 2^-64 -> bf16 RNE
-__device__ bf16_t limbs_to_bf16(const int64_t* limbs, int* bad) {
+__device__ bf16_t limbs_to_bf16(const int64_t* replicas, int* bad) {
+  int64_t limbs[3];
+  gather_limbs(replicas, limbs);
   __int128 t = (__int128)limbs[0] + ((__int128)limbs[1] << 32) + ((__int128)limbs[2] << 64);
   if (t < 0) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
   if (t == 0) return 0;
@@ -160,10 +171,10 @@ __global__ void __launch_bounds__(E3_TPB) k_row_sum(const bf16_t* __restrict__ w
 
 __global__ void k_zero_i64(int64_t* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0; }
 
-// F.normalize(row, p=1) in ONE launch.  scratch (int64[6], zero between calls): [0] = norm bits | skip << 16 |
-// err << 20 (for the host), [1..3] limbs of the renormalised row, [4] ticket.  Every workgroup derives the norm from
-// the (read-only) exact row sum; if it is 1.0 nothing is touched.  Otherwise the last workgroup to finish installs the
-// new exact sum -- the others have all read row_sum long before (they read it first thing).
+// F.normalize(row, p=1) in ONE launch.  scratch (int64[BLISS_NORM_SCRATCH], zero between calls): [0] = norm bits |
+// skip << 16 | err << 20 (for the host), [1] ticket, [2 ..] replicas of the renormalised row's exact sum.  Every workgroup
+// derives the norm from the (read-only) exact row sum; if it is 1.0 nothing is touched.  Otherwise the last workgroup to
+// finish installs the new exact sum -- the others have all read row_sum long before (they read it first thing).
 __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
   __shared__ int sh_norm, sh_last;
   if (threadIdx.x == 0) {
@@ -188,20 +199,20 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
     row_digits(v, a, &bad);
     dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
   }
-  flush_digits(dg, scratch + 1);
+  flush_digits(dg, scratch + 2);
   if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
   // last workgroup installs the new exact sum (release / ticket / acquire, cdna guide G16)
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) sh_last = (atomicAdd((unsigned long long*)(scratch + 4), 1ull) == (unsigned long long)gridDim.x - 1);
+  if (threadIdx.x == 0) sh_last = (atomicAdd((unsigned long long*)(scratch + 1), 1ull) == (unsigned long long)gridDim.x - 1);
   __syncthreads();
-  if (sh_last && threadIdx.x == 0) {
+  if (sh_last) {
     __threadfence();
-    for (int k = 0; k < 3; ++k) {
-      row_sum[k] = (int64_t)__hip_atomic_load((unsigned long long*)(scratch + 1 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store((unsigned long long*)(scratch + 1 + k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = threadIdx.x; k < 3 * ROWSUM_SLOTS; k += E3_TPB) {
+      row_sum[k] = (int64_t)__hip_atomic_load((unsigned long long*)(scratch + 2 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((unsigned long long*)(scratch + 2 + k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store((unsigned long long*)(scratch + 4), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(scratch + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -266,7 +277,7 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
 int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream) {
   if (!w_pos || !row_sum || num_edges <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  k_zero_i64<<<1, 64, 0, st>>>(row_sum, 3);          // not hipMemsetAsync: see k_init_counts in sampler.hip
+  k_zero_i64<<<1, 128, 0, st>>>(row_sum, 3 * ROWSUM_SLOTS);          // not hipMemsetAsync: see k_init_counts in sampler.hip
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   if (grid > 4096) grid = 4096;
   PROF_LAUNCH(BK_ROW_SUM, st, k_row_sum<<<(int)grid, E3_TPB, 0, st>>>((const bf16_t*)w_pos, num_edges, row_sum, nullptr));

@@ -31,6 +31,8 @@ extern "C" {
 
 #define BLISS_MODE_BANDIT 0   /* EXP3 edge probabilities  (bandit_sampler.py) */
 #define BLISS_MODE_LADIES 1   /* static edge weights      (ladies_sampler.py) */
+#define BLISS_ROWSUM_SLOTS 32
+#define BLISS_NORM_SCRATCH (2 + 3 * BLISS_ROWSUM_SLOTS)
 #define BLISS_MODE_UNIFORM_NODES 4   /* OR-ed in: importance_sampling=False, p_j = [j has an out-edge] (bandit_sampler.py:77-81) */
 
 /* The message graph g as the sampler sees it (train_lightning.py:373: CSC only). */
@@ -209,7 +211,8 @@ int bliss_graph_prepare(const int32_t* coo_src, const int32_t* coo_dst, int64_t 
 /* calculate_alpha (SAGE/GCN) + calculate_rewards + update_exp3_weights up to the scatter,
  * bandit_sampler.py:157, :180-193, :221-248.  One launch per block.
  * edge_w_pos: g.edata['w'] by CSC position.  w_pos: the layer's exp3 row (updated in place).
- * row_sum: int64[3] exact running sum of the row (32-bit limbs, value * 2^64), updated.
+ * row_sum: int64[3 * BLISS_ROWSUM_SLOTS] exact running sum of the row (32-bit limbs, value * 2^64; the sum is the total
+ * over BLISS_ROWSUM_SLOTS replicas of three limbs, which keeps concurrent waves off a single address), updated.
  * rewards_out: bf16 [n_edges] edata['rewards'] or NULL.  factor_out: bf16 [n_edges] exp(min(1, delta r/(P n)))
  * or NULL.  apply == 0 computes rewards/factors only and leaves w_pos and row_sum untouched. */
 int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_pos, int64_t* row_sum,
@@ -226,12 +229,12 @@ int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const vo
                      int32_t n_bound, int32_t* err, void* stream);
 
 /* F.normalize(row, p=1, dim=0), bandit_sampler.py:249, bit-exact: norm = bf16(exact sum).  The pass
- * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[6], zero-initialised
+ * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[BLISS_NORM_SCRATCH], zero-initialised
  * once by the caller and left zero ([0] afterwards holds norm bits | skip << 16 | err << 20). */
 int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64_t* scratch, void* norm_out_bf16,
                          void* stream);
 
-/* Exact row sum from scratch (initialisation / verification): row_sum int64[3]. */
+/* Exact row sum from scratch (initialisation / verification): row_sum int64[3 * BLISS_ROWSUM_SLOTS]. */
 int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* stream);
 
 /* ---- GATv2 attention path (custom_GATv2Conv.forward, model.py:48-112) ------------------------------------------

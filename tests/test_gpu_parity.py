@@ -281,7 +281,7 @@ def test_exp3_update_exp_table(cuda):
     ar = torch.arange(n, dtype=torch.int32, device=dev)
     w = torch.full((n,), 0.5, dtype=torch.bfloat16, device=dev)
     ones = torch.ones(n, dtype=torch.bfloat16, device=dev)
-    row_sum = torch.zeros(3, dtype=torch.int64, device=dev)
+    row_sum = torch.zeros(96, dtype=torch.int64, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     nE = torch.tensor([n], dtype=torch.int32, device=dev)
     rewards = torch.empty(n, dtype=torch.bfloat16, device=dev)
@@ -296,9 +296,9 @@ def test_exp3_update_exp_table(cuda):
     assert torch.equal(w.cpu().view(torch.int16), expect.view(torch.int16)), \
         f"{(w.cpu().view(torch.int16) != expect.view(torch.int16)).sum().item()} exp() results differ from torch CPU"
     # and the incrementally maintained exact row sum equals a from-scratch one
-    rs2 = torch.zeros(3, dtype=torch.int64, device=dev)
+    rs2 = torch.zeros(96, dtype=torch.int64, device=dev)
     _lib.check(_lib.lib.bliss_row_sum(w.data_ptr(), n, rs2.data_ptr(), 0), "row_sum")
-    tot = lambda r: int(r[0]) + (int(r[1]) << 32) + (int(r[2]) << 64)
+    tot = lambda r: sum(int(r[3 * s]) + (int(r[3 * s + 1]) << 32) + (int(r[3 * s + 2]) << 64) for s in range(32))
     assert tot(row_sum.cpu()) == tot(rs2.cpu())
     from oracle import numerics as nx
     assert tot(rs2.cpu()) == nx.row_exact_sum(w.cpu())
@@ -319,7 +319,7 @@ def test_exp_exhaustive_over_unit_interval(cuda):
     ar = torch.arange(n, dtype=torch.int32, device=dev)
     w = torch.full((n,), 0.75, dtype=torch.bfloat16, device=dev)
     ones = torch.ones(n, dtype=torch.bfloat16, device=dev)
-    row_sum = torch.zeros(3, dtype=torch.int64, device=dev)
+    row_sum = torch.zeros(96, dtype=torch.int64, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     nE = torch.tensor([1], dtype=torch.int32, device=dev)
     for i, y in enumerate(ys.float().tolist()):
