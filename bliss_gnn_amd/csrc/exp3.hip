@@ -26,10 +26,14 @@ __device__ __forceinline__ void row_digits(bf16_t b, int64_t d[3], int* bad) {
   if (e == 0) e = 1; else m |= 0x80;
   int shift = (int)e - 134 + 64;                 // value*2^64 = m << shift
   if (shift > 80) { *bad |= BLISS_ERR_FIXED_RANGE; return; }
-  unsigned __int128 t = shift >= 0 ? ((unsigned __int128)m << shift) : ((-shift >= 8) ? 0 : (unsigned __int128)(m >> (-shift)));
-  d[0] = (int64_t)(uint64_t)(t & 0xffffffffu);
-  d[1] = (int64_t)(uint64_t)((t >> 32) & 0xffffffffu);
-  d[2] = (int64_t)(uint64_t)(t >> 64);
+  if (shift < 0) { d[0] = (-shift >= 8) ? 0 : (int64_t)(m >> (-shift)); return; }
+  // an 8-bit mantissa shifted into three 32-bit digits: it straddles at most two of them
+  const int idx = shift >> 5, off = shift & 31;
+  const uint64_t v = (uint64_t)m << off;         // < 2^39
+  const int64_t lo = (int64_t)(v & 0xffffffffu), hi = (int64_t)(v >> 32);
+  if (idx == 0) { d[0] = lo; d[1] = hi; }
+  else if (idx == 1) { d[1] = lo; d[2] = hi; }
+  else { d[2] = (int64_t)v; }                    // the top digit is not reduced mod 2^32 (as before)
 }
 
 __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
@@ -201,13 +205,14 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
   }
   flush_digits(dg, scratch + 2);
   if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
-  // last workgroup installs the new exact sum (release / ticket / acquire, cdna guide G16)
-  __threadfence();
+  // The last workgroup installs the new exact sum.  Everything it needs from the others went through memory-side
+  // atomics, which are device-coherent by themselves: draining them (vmcnt) before the ticket is all the release this
+  // hand-off needs.  (__threadfence() here cost a full L2 write-back per workgroup: 470 us per pass on a 15 M-edge row.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) sh_last = (atomicAdd((unsigned long long*)(scratch + 1), 1ull) == (unsigned long long)gridDim.x - 1);
   __syncthreads();
   if (sh_last) {
-    __threadfence();
     for (int k = threadIdx.x; k < 3 * ROWSUM_SLOTS; k += E3_TPB) {
       row_sum[k] = (int64_t)__hip_atomic_load((unsigned long long*)(scratch + 2 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store((unsigned long long*)(scratch + 2 + k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

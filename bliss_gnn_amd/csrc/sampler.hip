@@ -74,6 +74,13 @@ __device__ __forceinline__ bf16_t edge_q(bf16_t w, bf16_t wsum, int n, float eta
   return f2bf(a + b);                       // :137 v_add_e
 }
 
+// the same with the per-seed part a = rbf((1/n) * eta) taken from k_col_sums' per-seed record
+__device__ __forceinline__ bf16_t edge_q_pre(bf16_t w, bf16_t wsum, float a, float ome_f) {
+  float wd = rbf(bf2f(w) / bf2f(wsum));
+  float b = rbf(ome_f * wd);
+  return f2bf(a + b);
+}
+
 // ---------------------------------------------------------------- K_a: seed columns -> seg_ptr
 // also resets the counts record and zeroes the per-seed accumulators (a kernel, not hipMemsetAsync: memset nodes
 // of a captured HIP graph were observed to leave this buffer stale on replay -- ROCm 7.2)
@@ -344,7 +351,7 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 #define BIN_BATCH (BIN_TPB * BIN_ITEMS)      // frontier positions per workgroup step: 4096 (16 waves keep the loads in flight)
 #define MAX_BINS 1024
 #define COL_TPB 512
-#define COL_R 4
+#define COL_R 16
 #define BINRED_TPB 512
 
 template <int NT>
@@ -367,7 +374,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
                                                       const int* __restrict__ seeds, const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
     const int* __restrict__ span_seg, LayerCounts* cnt,
                                                       unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
-                                                      float eta_f, float ome_f) {
+                                                      float eta_f, float ome_f, uint2* __restrict__ seed_coef) {
   __shared__ long long sh[COL_TPB / 64];
   const int S = cnt->S, tid = threadIdx.x;
   if (cnt->E == 0) return;
@@ -396,7 +403,12 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int i = tid + COL_R * COL_TPB; i < n; i += COL_TPB)
       part += bf_to_fixed(edge_q(w[p0 + i], wsum, n, eta_f, ome_f), FRAC_DST, &bad);
     const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
-    if (tid == 0) { acc_w[k] = (unsigned long long)ws_fixed; acc_q[k] = (unsigned long long)qs_fixed; }
+    if (tid == 0) {
+      acc_w[k] = (unsigned long long)ws_fixed; acc_q[k] = (unsigned long long)qs_fixed;
+      // what the per-edge passes need of this seed, converted once: bf16 sums and the eta / n_i term of q_ij (:137)
+      const bf16_t qsum = fixed_to_bf(qs_fixed, FRAC_DST, &bad);
+      seed_coef[k] = make_uint2((unsigned)wsum | ((unsigned)qsum << 16), __float_as_uint(rbf((1.0f / (float)n) * eta_f)));
+    }
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -409,7 +421,8 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
                                                      const unsigned long long* __restrict__ acc_w,
                                                      const unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
                                                      int uniform_nodes, int n_bins, int log2_bins, long long bin_cap, int* bin_cursor,
-                                                     unsigned long long* __restrict__ bin_rec, unsigned* __restrict__ bitmap) {
+                                                     unsigned long long* __restrict__ bin_rec, unsigned* __restrict__ bitmap,
+                                                     const uint2* __restrict__ seed_coef) {
   __shared__ int hist[MAX_BINS];
   __shared__ int gbase[MAX_BINS];
   const int S = cnt->S, E = cnt->E, tid = threadIdx.x;
@@ -435,10 +448,9 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
         if (uniform_nodes) {
           t = (bf16_t)0x3f80;                           // importance_sampling=False (:77-81): only "has an out-edge" matters
         } else if (BANDIT) {
-          bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
-          bf16_t qsum = fixed_to_bf((int64_t)acc_q[a.k], FRAC_DST, &bad);
-          float r = rbf(bf2f(q) / bf2f(qsum));          // :71 e_div_u on the reversed frontier
+          const uint2 cf = seed_coef[a.k];              // per-seed: bf16 sum_j w_ij | bf16 sum_k q_ik, eta / n_i
+          bf16_t q = edge_q_pre(w[a.pos], (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f);
+          float r = rbf(bf2f(q) / bf2f((bf16_t)(cf.x >> 16)));   // :71 e_div_u on the reversed frontier
           t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
         } else {
           float x = bf2f(w[a.pos]);                     // ladies_sampler.py:46-47  weight ** 2
@@ -845,7 +857,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      const int* __restrict__ local_id, const int* __restrict__ new_id,
                                                      const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
                                                      int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f,
-                                                     const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob) {
+                                                     const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob,
+                                                     const uint2* __restrict__ seed_coef) {
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
@@ -863,8 +876,9 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
         key = r.k;
         if (src_cnt) atomicAdd(src_cnt + r.nid, 1);     // out-degree inside the block: sizes the by-source index
         if (BANDIT) {
-          bf16_t wsum = fixed_to_bf((int64_t)acc_w[r.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(w[r.pos], wsum, seg_ptr[r.k + 1] - seg_ptr[r.k], eta_f, ome_f);
+          bf16_t q;
+          if (seed_coef) { const uint2 cf = seed_coef[r.k]; q = edge_q_pre(w[r.pos], (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
+          else q = edge_q(w[r.pos], fixed_to_bf((int64_t)acc_w[r.k], FRAC_DST, &bad), seg_ptr[r.k + 1] - seg_ptr[r.k], eta_f, ome_f);
           bf16_t wt = f2bf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));    // :314 e_div_u(sg, W, P)
           term = bf_to_fixed(wt, FRAC_BLK, &bad);      // :316 copy_e_sum
         }
@@ -939,7 +953,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      int* __restrict__ out_eid, bf16_t* __restrict__ out_w,
                                                      bf16_t* __restrict__ out_q, int* src_cursor, int* __restrict__ t_unsorted,
                                                      float eta_f, float ome_f, int cap_b, const int* __restrict__ kept_map,
-                                                     const bf16_t* __restrict__ node_prob) {
+                                                     const bf16_t* __restrict__ node_prob, const uint2* __restrict__ seed_coef) {
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
@@ -957,8 +971,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
       const int k = r.k;
       bf16_t q;
       if (BANDIT) {
-        bf16_t wsum = fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad);
-        q = edge_q(w[r.pos], wsum, seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+        if (seed_coef) { const uint2 cf = seed_coef[k]; q = edge_q_pre(w[r.pos], (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
+        else q = edge_q(w[r.pos], fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad), seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
       } else q = w[r.pos];
       float wt = rbf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));   // :314
       float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
@@ -1100,14 +1114,15 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
                                                             binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
+    uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
     if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f));
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef));
     if (mode == BLISS_MODE_BANDIT)
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
     else
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
         cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
@@ -1187,6 +1202,8 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   unsigned long long* acc_wt = acc_w + 2 * (size_t)cap_s;
   int* deg_blk = (int*)(acc_w + 3 * (size_t)cap_s);
   const long long* col_base = (const long long*)(acc_w + 5 * (size_t)cap_s);
+  // per-seed coefficients exist only where k_col_sums ran (binned pipeline, bandit mode)
+  const uint2* seed_coef = (ws->n_bins > 0 && mode == BLISS_MODE_BANDIT) ? (const uint2*)(acc_w + 6 * (size_t)cap_s) : nullptr;
   if (frontier_bound < 1) frontier_bound = 1;
   const int gc = grid_for(frontier_bound, CHUNK);
   int* src_cnt = ws->src_cnt;
@@ -1194,14 +1211,14 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   if (want_t && cap_s > TSORT_MAX_S) return BLISS_EINVAL;                    // caller falls back to bliss_block_transpose
   int* sc = want_t ? src_cnt : nullptr;
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
   else
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
   PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<want_t ? 3 : 2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b, src_cnt, out->t_indptr, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
   else
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
   if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
     const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
     PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map));

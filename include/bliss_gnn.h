@@ -65,7 +65,7 @@ typedef struct {
 typedef struct {
   void* counts;             /* bliss_layer_counts_t */
   int32_t* seg_ptr;         /* [cap_s + 1] start of every seed's column in the frontier */
-  void* seed_acc;           /* [48 * cap_s bytes] exact per-seed accumulators + column bases */
+  void* seed_acc;           /* [56 * cap_s bytes] exact per-seed accumulators, column bases, per-seed coefficients */
   int32_t* chunk_cnt;       /* [max(frontier_bound, cap_c) / 1024 + 2] */
   int32_t* cand_nid;        /* [cap_c] global id of every candidate, seeds first (ndata[NID]) */
   void* p;                  /* bf16 [cap_c] LADIES importance p_j */
