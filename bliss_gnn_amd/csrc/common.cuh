@@ -89,10 +89,46 @@ __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) {
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// ---- wave reductions on the DPP data path (no LDS round trip per step, unlike __shfl = ds_bpermute) ----
+// inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows
+// 0-1 -> 2-3 (row_bcast:31): lane 63 ends up with the wave total.  Lanes without a source receive 0 (old = 0).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_mov0_i64(long long v) {
+  const int lo = dpp_mov0<CTRL, ROW_MASK>((int)(v & 0xffffffffll)), hi = dpp_mov0<CTRL, ROW_MASK>((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ int wave_total_i32(int v) {
+  v += dpp_mov0<0x111, 0xf>(v); v += dpp_mov0<0x112, 0xf>(v); v += dpp_mov0<0x114, 0xf>(v); v += dpp_mov0<0x118, 0xf>(v);
+  v += dpp_mov0<0x142, 0xa>(v); v += dpp_mov0<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ long long wave_total_i64(long long v) {
+  v += dpp_mov0_i64<0x111, 0xf>(v); v += dpp_mov0_i64<0x112, 0xf>(v); v += dpp_mov0_i64<0x114, 0xf>(v);
+  v += dpp_mov0_i64<0x118, 0xf>(v); v += dpp_mov0_i64<0x142, 0xa>(v); v += dpp_mov0_i64<0x143, 0xc>(v);
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+// all lanes with key >= 0 carry the same key (the common case: a wave's 64 edges lie inside one seed column)
+__device__ __forceinline__ bool wave_single_key(int key, int* k0) {
+  const unsigned long long act = __ballot(key >= 0);
+  if (!act) { *k0 = -1; return true; }
+  *k0 = __builtin_amdgcn_readlane(key, __ffsll((long long)act) - 1);
+  return __ballot(key >= 0 && key != *k0) == 0ull;
+}
+
 // Wave-level segmented sum of 64-bit terms keyed by a NON-DECREASING int key; the last lane of
 // every key run adds the run's total to acc[key] with one atomic.  Lanes with key < 0 are idle.
 __device__ __forceinline__ void wave_segsum_atomic_i64(int key, int64_t v, unsigned long long* acc) {
   const int lane = lane_id();
+  int k0;
+  if (wave_single_key(key, &k0)) {                   // one segment: a DPP reduction and one atomic
+    if (k0 < 0) return;
+    const long long tot = wave_total_i64(key >= 0 ? v : 0);
+    if (lane == 0 && tot != 0) atomicAdd(acc + k0, (unsigned long long)tot);
+    return;
+  }
 #pragma unroll
   for (int d = 1; d < BLISS_WAVE; d <<= 1) {
     int64_t vu = shfl_up_i64(v, d);
@@ -105,6 +141,13 @@ __device__ __forceinline__ void wave_segsum_atomic_i64(int key, int64_t v, unsig
 }
 __device__ __forceinline__ void wave_segsum_atomic_i32(int key, int v, int* acc) {
   const int lane = lane_id();
+  int k0;
+  if (wave_single_key(key, &k0)) {
+    if (k0 < 0) return;
+    const int tot = wave_total_i32(key >= 0 ? v : 0);
+    if (lane == 0 && tot != 0) atomicAdd(acc + k0, tot);
+    return;
+  }
 #pragma unroll
   for (int d = 1; d < BLISS_WAVE; d <<= 1) {
     int vu = __shfl_up(v, d);

@@ -36,13 +36,7 @@ __device__ __forceinline__ void row_digits(bf16_t b, int64_t d[3], int* bad) {
   else { d[2] = (int64_t)v; }                    // the top digit is not reduced mod 2^32 (as before)
 }
 
-__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
-  for (int d = 32; d >= 1; d >>= 1) {
-    int lo = __shfl_xor((int)(v & 0xffffffffll), d), hi = __shfl_xor((int)(v >> 32), d);
-    v += ((int64_t)hi << 32) | (uint32_t)lo;
-  }
-  return v;
-}
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) { return wave_total_i64(v); }
 
 // The exact sum lives in BLISS_ROWSUM_SLOTS replicas of three limbs (its value is the sum over the replicas): every wave
 // adds its total to the replica picked by its global wave id, so that thousands of waves do not serialise on three

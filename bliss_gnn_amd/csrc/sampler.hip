@@ -352,15 +352,13 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 #define MAX_BINS 1024
 #define COL_TPB 512
 #define COL_R 16
+#define COL_RB 32
+#define COL_BIG (COL_R * 64)              // a wave keeps a whole column of up to 1024 edges in registers
 #define BINRED_TPB 512
 
 template <int NT>
 __device__ __forceinline__ long long block_sum_i64(long long v, long long* sh) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const int lo = __shfl_down((int)(v & 0xffffffffll), d), hi = __shfl_down((int)(v >> 32), d);
-    v += ((long long)hi << 32) | (unsigned)lo;
-  }
+  v = wave_total_i64(v);
   __syncthreads();                                    // sh free again
   if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -370,45 +368,80 @@ __device__ __forceinline__ long long block_sum_i64(long long v, long long* sh) {
   return t;
 }
 
+// one WAVE per seed column (typical columns hold a few hundred to a few thousand edges: several columns in flight per
+// workgroup hide the pointer-chasing latency, and the two sums are DPP wave reductions with no barrier); columns longer
+// than COL_BIG are left to a second loop in which the whole workgroup shares one column
+__device__ __forceinline__ void col_store(int k, long long ws_fixed, long long qs_fixed, bf16_t wsum, int n, float eta_f,
+                                          unsigned long long* acc_w, unsigned long long* acc_q, uint2* seed_coef, int* bad) {
+  acc_w[k] = (unsigned long long)ws_fixed; acc_q[k] = (unsigned long long)qs_fixed;
+  // what the per-edge passes need of this seed, converted once: bf16 sums and the eta / n_i term of q_ij (:137)
+  const bf16_t qsum = fixed_to_bf(qs_fixed, FRAC_DST, bad);
+  seed_coef[k] = make_uint2((unsigned)wsum | ((unsigned)qsum << 16), __float_as_uint(rbf((1.0f / (float)n) * eta_f)));
+}
+
 __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
-    const int* __restrict__ span_seg, LayerCounts* cnt,
-                                                      unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
-                                                      float eta_f, float ome_f, uint2* __restrict__ seed_coef) {
+                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
+                                                      const long long* __restrict__ col_base, const int* __restrict__ span_seg,
+                                                      LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
+                                                      unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
+                                                      uint2* __restrict__ seed_coef) {
   __shared__ long long sh[COL_TPB / 64];
-  const int S = cnt->S, tid = threadIdx.x;
+  const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
   if (cnt->E == 0) return;
   int bad = 0;
-  for (int k = blockIdx.x; k < S; k += gridDim.x) {
-    const int n = seg_ptr[k + 1] - seg_ptr[k];
-    if (n == 0) continue;                             // block-uniform; the accumulators stay 0
-    const int64_t p0 = indptr[seeds[k]];
+  // ---- columns up to COL_BIG edges: one per wave
+  for (int k = blockIdx.x * (COL_TPB / 64) + (tid >> 6); k < S; k += gridDim.x * (COL_TPB / 64)) {
+    const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
+    if (n == 0 || n > COL_BIG) continue;              // wave-uniform
+    const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_R];
     long long part = 0;
 #pragma unroll
     for (int r = 0; r < COL_R; ++r) {
-      const int i = tid + r * COL_TPB;
+      const int i = lane + r * 64;
       wr[r] = 0;
       if (i < n) { wr[r] = w[p0 + i]; part += bf_to_fixed(wr[r], FRAC_DST, &bad); }          // :129 copy_e_sum over exp3 weights
     }
-    for (int i = tid + COL_R * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], FRAC_DST, &bad);
-    const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
+    const long long ws_fixed = wave_total_i64(part);
     const bf16_t wsum = fixed_to_bf(ws_fixed, FRAC_DST, &bad);
+    const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll
     for (int r = 0; r < COL_R; ++r) {
+      const int i = lane + r * 64;
+      if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);     // :67 copy_e_sum(insg, edge_prob)
+    }
+    const long long qs_fixed = wave_total_i64(part);
+    if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
+  }
+  // ---- the long columns: one per workgroup, the first COL_RB * COL_TPB edges held in registers between the two sums
+  for (int k = blockIdx.x; k < S; k += gridDim.x) {
+    const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
+    if (n <= COL_BIG) continue;                       // block-uniform
+    const long long p0 = col_base[k] + s0;
+    bf16_t wr[COL_RB];
+    long long part = 0;
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r) {
       const int i = tid + r * COL_TPB;
-      if (i < n) part += bf_to_fixed(edge_q(wr[r], wsum, n, eta_f, ome_f), FRAC_DST, &bad);  // :67 copy_e_sum(insg, edge_prob)
+      wr[r] = 0;
+      if (i < n) { wr[r] = w[p0 + i]; part += bf_to_fixed(wr[r], FRAC_DST, &bad); }
     }
-    for (int i = tid + COL_R * COL_TPB; i < n; i += COL_TPB)
-      part += bf_to_fixed(edge_q(w[p0 + i], wsum, n, eta_f, ome_f), FRAC_DST, &bad);
+#pragma unroll 8
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], FRAC_DST, &bad);
+    const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
+    const bf16_t wsum = fixed_to_bf(ws_fixed, FRAC_DST, &bad);
+    const float a = rbf((1.0f / (float)n) * eta_f);
+    part = 0;
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r) {
+      const int i = tid + r * COL_TPB;
+      if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
+    }
+#pragma unroll 8
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(w[p0 + i], wsum, a, ome_f), FRAC_DST, &bad);
     const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
-    if (tid == 0) {
-      acc_w[k] = (unsigned long long)ws_fixed; acc_q[k] = (unsigned long long)qs_fixed;
-      // what the per-edge passes need of this seed, converted once: bf16 sums and the eta / n_i term of q_ij (:137)
-      const bf16_t qsum = fixed_to_bf(qs_fixed, FRAC_DST, &bad);
-      seed_coef[k] = make_uint2((unsigned)wsum | ((unsigned)qsum << 16), __float_as_uint(rbf((1.0f / (float)n) * eta_f)));
-    }
+    if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -634,9 +667,11 @@ __device__ __forceinline__ double block_sum_f64(double v, double* shd) {
 }
 
 __global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps, int* rng_ctl,
-                                                        int* layer_off, int is_last, int rng_cap_total) {
+                                                        int* layer_off, int is_last, int rng_cap_total, int* __restrict__ sel_state) {
   __shared__ double shd[16];
   const int C = cnt->C;
+  // ticket + one status word per 1024-candidate chunk for k_select_fused's look-back
+  for (int i = threadIdx.x; i < (C + CHUNK - 1) / CHUNK + 2; i += 1024) sel_state[i] = 0;
   // the random numbers of this layer come from the streaming generator: one lane waits for them while the others work
   if (rng_ctl && threadIdx.x == 1023) rng_stream_acquire(rng_ctl, C, layer_off, is_last, rng_cap_total);
   // every thread owns 32 bins; load the counts and leave the histogram zero for the next layer
@@ -681,79 +716,93 @@ __device__ __forceinline__ bf16_t incl_prob(const bf16_t* __restrict__ p, int j,
   return (v < 1.0f || v != v) ? f2bf(v) : (bf16_t)0x3f80;
 }
 
-// ---------------------------------------------------------------- K_i: P_j, Bernoulli compare, count per chunk
-__global__ void __launch_bounds__(TPB) k_select_pass1(const bf16_t* __restrict__ p, const float* __restrict__ uniforms_base,
+// ---------------------------------------------------------------- K_i + scan + K_k in ONE launch
+// Bernoulli compare and ORDERED compaction in a single pass: every workgroup takes the next 1024-candidate chunk from a
+// ticket counter, publishes its kept count and looks back over its predecessors' status words (aggregate / inclusive
+// prefix) for its base rank.  Tickets are handed out in execution order, so a predecessor is always running or done.
+// Saves two launches (>= 4 us each inside a graph) per layer over pass1 + chunk scan + pass2.
+#define SEL_AGG 1
+#define SEL_PFX 2
+__global__ void __launch_bounds__(TPB) k_select_fused(const bf16_t* __restrict__ p, const float* __restrict__ uniforms_base,
                                                       const int* __restrict__ u_off, LayerCounts* cnt, bf16_t* __restrict__ P,
-                                                      int* __restrict__ chunk_cnt, int cap_c) {
+                                                      int* state, const int* __restrict__ cand_nid, int* __restrict__ new_id,
+                                                      int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob, int cap_c, int cap_k,
+                                                      int* __restrict__ kept_map) {
   __shared__ int sh4[TPB / 64];
+  __shared__ int sh_chunk, sh_base, sh_K;
   const float* __restrict__ uniforms = uniforms_base + (u_off ? *u_off : 0);
   const int S = cnt->S, C = min(cnt->C, cap_c), all_one = cnt->all_one;
   const float c32 = (float)cnt->c;
   const int nchunks = (C + CHUNK - 1) / CHUNK;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    int kept = 0;
+  if (threadIdx.x == 0) sh_chunk = atomicAdd(state, 1);
+  __syncthreads();
+  const int chunk = sh_chunk;
+  if (chunk >= nchunks) return;
+  unsigned long long mask[ITEMS];
+  bf16_t Pv[ITEMS];
+  int wave_total = 0;
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
-      bool keep = false;
-      if (j < C) {
-        bf16_t Pj = incl_prob(p, j, S, all_one, c32);
-        P[j] = Pj;
-        // the numbers may come from a generator kernel that is still running: agent-scope (sc1) load
-        keep = __hip_atomic_load(uniforms + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bf2f(Pj);   // :422-424  u24 < float(P)
-      }
-      kept += __popcll(__ballot(keep));
+  for (int i = 0; i < ITEMS; ++i) {
+    const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
+    bool keep = false;
+    Pv[i] = 0;
+    if (j < C) {
+      Pv[i] = incl_prob(p, j, S, all_one, c32);
+      P[j] = Pv[i];
+      // the numbers may come from a generator kernel that is still running: agent-scope (sc1) load
+      keep = __hip_atomic_load(uniforms + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bf2f(Pv[i]);   // :422-424  u24 < float(P)
     }
-    int tot;
-    chunk_wave_offset(kept, sh4, &tot);
-    if (threadIdx.x == 0) chunk_cnt[chunk] = tot;
+    mask[i] = __ballot(keep);
+    wave_total += __popcll(mask[i]);
   }
-}
-
-// ---------------------------------------------------------------- K_k: ordered compaction of the kept nodes
-__global__ void __launch_bounds__(TPB) k_select_pass2(const float* __restrict__ uniforms_base, const int* __restrict__ u_off,
-                                                      LayerCounts* cnt,
-                                                      const bf16_t* __restrict__ P, const int* __restrict__ chunk_off,
-                                                      const int* __restrict__ cand_nid, int* __restrict__ new_id,
-                                                      int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
-                                                      int cap_c, int cap_k, int* __restrict__ kept_map) {
-  __shared__ int sh4[TPB / 64];
-  const float* __restrict__ uniforms = uniforms_base + (u_off ? *u_off : 0);
-  const int C = min(cnt->C, cap_c);
-  const int nchunks = (C + CHUNK - 1) / CHUNK;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    unsigned long long mask[ITEMS];
-    bf16_t Pv[ITEMS];
-    int wave_total = 0;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
-      bool keep = false;
-      Pv[i] = 0;
-      if (j < C) { Pv[i] = P[j]; keep = __hip_atomic_load(uniforms + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bf2f(Pv[i]); }
-      mask[i] = __ballot(keep);
-      wave_total += __popcll(mask[i]);
-    }
-    int tot;
-    int run = chunk_off[chunk] + chunk_wave_offset(wave_total, sh4, &tot);
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
-      if (j < C) {
-        const bool keep = (mask[i] >> lane_id()) & 1ull;
-        const int r = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
-        if (keep && r < cap_k) {
-          const int g = cand_nid[j];
-          kept_nid[r] = g; node_prob[r] = Pv[i]; new_id[j] = r;   // :306,:309
-          if (kept_map) kept_map[g] = r;                 // dense: the block passes find a kept source with ONE gather
-        } else new_id[j] = -1;
+  int tot;
+  const int woff = chunk_wave_offset(wave_total, sh4, &tot);
+  if (threadIdx.x == 0) {
+    int excl = 0, bad = 0;
+    if (chunk > 0) {
+      __hip_atomic_store(state + 1 + chunk, (tot << 2) | SEL_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long spins = 0;
+      for (int j = chunk - 1; j >= 0;) {
+        const int v = __hip_atomic_load(state + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v & 3) == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1ll << 24)) { bad = BLISS_ERR_CAP_KEPT; break; }     // never hang the GPU; the step is flagged invalid
+          continue;
+        }
+        excl += v >> 2;
+        if ((v & 3) == SEL_PFX) break;
+        --j;
       }
-      run += __popcll(mask[i]);
     }
+    __hip_atomic_store(state + 1 + chunk, ((excl + tot) << 2) | SEL_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_base = excl;
+    if (chunk == nchunks - 1) {
+      int K = excl + tot;
+      if (K > cap_k) { bad |= BLISS_ERR_CAP_KEPT; K = cap_k; }                 // clamp: results invalid but in bounds
+      cnt->K = K;
+      sh_K = K;
+    }
+    if (bad) atomicOr(&cnt->err, bad);
   }
-  // capacity padding: ids past K stay valid node ids (0) so that padded feature gathers are harmless
-  const int K = min(cnt->K, cap_k);
-  for (int r = K + blockIdx.x * TPB + threadIdx.x; r < cap_k; r += gridDim.x * TPB) { kept_nid[r] = 0; node_prob[r] = 0x3f80; }
+  __syncthreads();
+  int run = sh_base + woff;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int j = chunk * CHUNK + (threadIdx.x >> 6) * SPAN + i * 64 + lane_id();
+    if (j < C) {
+      const bool keep = (mask[i] >> lane_id()) & 1ull;
+      const int r = run + __popcll(mask[i] & ((1ull << lane_id()) - 1ull));
+      if (keep && r < cap_k) {
+        const int g = cand_nid[j];
+        kept_nid[r] = g; node_prob[r] = Pv[i]; new_id[j] = r;   // :306,:309
+        if (kept_map) kept_map[g] = r;                 // dense: the block passes find a kept source with ONE gather
+      } else new_id[j] = -1;
+    }
+    run += __popcll(mask[i]);
+  }
+  // capacity padding (by the workgroup that knows K): ids past K stay valid node ids (0) so that padded feature gathers are harmless
+  if (chunk == nchunks - 1)
+    for (int r = sh_K + threadIdx.x; r < cap_k; r += TPB) { kept_nid[r] = 0; node_prob[r] = 0x3f80; }
 }
 
 // ---------------------------------------------------------------- multinomial variants (BanditLadiesSampler / LadiesSampler)
@@ -1167,12 +1216,10 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   LayerCounts* cnt = (LayerCounts*)ws->counts;
   if (cand_bound < 1) cand_bound = 1;
   if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
-  const int gc = grid_for(cand_bound, CHUNK);
-  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps, rng_ctl, uniforms_offset_dev, is_last, rng_cap_total));
-  PROF_LAUNCH(BK_SELECT1, st, k_select_pass1<<<gc, TPB, 0, st>>>((const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cap_c));
-  PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 1, ws->cap_k));
-  PROF_LAUNCH(BK_SELECT2, st, k_select_pass2<<<gc, TPB, 0, st>>>(uniforms, uniforms_offset_dev, cnt, (const bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id,
-                                     ws->kept_nid, (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map));
+  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps, rng_ctl, uniforms_offset_dev, is_last, rng_cap_total, ws->chunk_cnt));
+  PROF_LAUNCH(BK_SELECT2, st, k_select_fused<<<grid_for(cand_bound, CHUNK, 1 << 20), TPB, 0, st>>>(
+      (const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid,
+      (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map));
   return (int)hipGetLastError();
 }
 
