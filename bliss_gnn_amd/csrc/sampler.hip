@@ -757,32 +757,40 @@ __global__ void __launch_bounds__(TPB) k_select_fused(const bf16_t* __restrict__
   }
   int tot;
   const int woff = chunk_wave_offset(wave_total, sh4, &tot);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {                              // wave 0 looks back 64 predecessors at a time
+    const int lane = lane_id();
     int excl = 0, bad = 0;
     if (chunk > 0) {
-      __hip_atomic_store(state + 1 + chunk, (tot << 2) | SEL_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(state + 1 + chunk, (tot << 2) | SEL_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long spins = 0;
-      for (int j = chunk - 1; j >= 0;) {
-        const int v = __hip_atomic_load(state + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v & 3) == 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1ll << 24)) { bad = BLISS_ERR_CAP_KEPT; break; }     // never hang the GPU; the step is flagged invalid
+      for (int top = chunk - 1; top >= 0;) {
+        const int j = top - lane;                       // lane 0 = nearest predecessor
+        const int v = j >= 0 ? __hip_atomic_load(state + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SEL_PFX;
+        const unsigned long long ready = __ballot((v & 3) != 0), pfx = __ballot((v & 3) == SEL_PFX);
+        // usable lanes: 0 .. first prefix (inclusive), all of them published
+        const int stop = pfx ? __ffsll((long long)pfx) - 1 : 63;
+        const unsigned long long need = stop == 63 ? ~0ull : ((1ull << (stop + 1)) - 1ull);
+        if ((ready & need) != need) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1ll << 22)) { bad = BLISS_ERR_CAP_KEPT; break; }     // never hang the GPU; the step is flagged invalid
           continue;
         }
-        excl += v >> 2;
-        if ((v & 3) == SEL_PFX) break;
-        --j;
+        excl += wave_total_i32(lane <= stop && j >= 0 ? (v >> 2) : 0);
+        if (pfx) break;
+        top -= 64;
       }
     }
-    __hip_atomic_store(state + 1 + chunk, ((excl + tot) << 2) | SEL_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_base = excl;
-    if (chunk == nchunks - 1) {
-      int K = excl + tot;
-      if (K > cap_k) { bad |= BLISS_ERR_CAP_KEPT; K = cap_k; }                 // clamp: results invalid but in bounds
-      cnt->K = K;
-      sh_K = K;
+    if (lane == 0) {
+      __hip_atomic_store(state + 1 + chunk, ((excl + tot) << 2) | SEL_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh_base = excl;
+      if (chunk == nchunks - 1) {
+        int K = excl + tot;
+        if (K > cap_k) { bad |= BLISS_ERR_CAP_KEPT; K = cap_k; }                 // clamp: results invalid but in bounds
+        cnt->K = K;
+        sh_K = K;
+      }
+      if (bad) atomicOr(&cnt->err, bad);
     }
-    if (bad) atomicOr(&cnt->err, bad);
   }
   __syncthreads();
   int run = sh_base + woff;
