@@ -952,3 +952,49 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
     assert a["losses"][-3:] == b["losses"][-3:] and a["losses"][-7:-5] == b["losses"][-7:-5]
     for pa, pb in zip(a["params"], b["params"]):
         assert torch.equal(pa, pb)
+
+
+def test_hub_columns_match_oracle(cuda):
+    """Seed columns of 30 000, 5 000 and 1 500 in-edges (k_col_sums' one-workgroup path with and without the register
+    cache overflowing, and its one-wave path for the rest; multi-batch scatter; hubs with thousands of appearances as
+    sources) -- blocks, probabilities and the EXP3 update bit-exact against the oracle."""
+    from oracle import bliss_oracle as bo
+    bg = _bg()
+    gen = torch.Generator().manual_seed(77)
+    V = 40000
+    parts_src, parts_dst = [], []
+    for node, deg in ((0, 30000), (1, 5000), (2, 1500)):
+        parts_src.append(torch.randperm(V - 3, generator=gen)[:deg] + 3)
+        parts_dst.append(torch.full((deg,), node))
+    n_rest = 300000
+    parts_src.append(torch.randint(0, V, (n_rest,), generator=gen))
+    parts_dst.append(torch.randint(3, V, (n_rest,), generator=gen))
+    og = bo.prepare_graph(torch.cat(parts_src), torch.cat(parts_dst), V)
+    g = bg.Graph(og.indptr.to(cuda), og.indices.to(cuda), og.eid.to(cuda))
+    g.edata["w"] = bg.normalized_edata(g)
+    edge_w = bo.normalized_edata(og)
+    fan, eta = [3000, 1500], 0.1
+    sampler = bg.PoissonBanditLadiesSampler(fan, eta=eta)
+    o_w = torch.ones(2, og.num_edges, dtype=torch.bfloat16)
+    for step in range(2):
+        seeds = torch.cat([torch.tensor([0, 1, 2]), torch.randperm(V - 3, generator=gen)[:61] + 3]).to(torch.int32)
+        torch.manual_seed(step)
+        inp, _, blocks = sampler.sample_blocks(g, seeds.to(cuda))
+        torch.manual_seed(step)
+        o_inp, _, o_blocks = bo.sample_blocks_bandit(og, seeds, fan, o_w, eta)
+        assert torch.equal(inp.cpu().long(), o_inp)
+        embed = []
+        for b, ob in zip(blocks, o_blocks):
+            assert b._counts.E == ob.trace["E"] and b._counts.c == ob.trace["c"]
+            assert torch.equal(b._trace["cand_nid"].cpu().long(), ob.trace["cand_nid"])
+            assert torch.equal(b._trace["p"].cpu().view(torch.int16), ob.trace["p"].view(torch.int16))
+            assert torch.equal(b.src.cpu().long(), ob.src) and torch.equal(b.dst.cpu().long(), ob.dst)
+            for mine, ref in ((b.edata["edge_weights"], ob.edge_weights), (b.edata["q_ij"], ob.q_ij), (b.srcdata["node_prob"], ob.node_prob)):
+                assert torch.equal(mine.cpu().view(torch.int16), ref.view(torch.int16))
+            en = (torch.rand(ob.n_src, generator=gen) * 40).bfloat16()
+            b.srcdata["embed_norm"] = en.to(cuda)
+            embed.append(en)
+        sampler.exp3(blocks, g)
+        sampler.check_errors()
+        o_w, _ = bo.exp3(og, o_blocks, o_w, edge_w, embed)
+        assert torch.equal(sampler.exp3_weights.cpu().view(torch.int16), o_w.view(torch.int16))
