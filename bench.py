@@ -204,13 +204,21 @@ def main():
         per_launch = alg_dom / dom_timing["launches"]
         achieved = per_launch / (dom_timing["avg_us"] * 1e-6) / 1e9
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")     # separate rocprofv3 --pmc passes
+        pmc_file = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")     # separate rocprofv3 --pmc passes
         if os.path.exists(pmc_file):
-            pmc = {k.split("<")[0]: v for k, v in json.load(open(pmc_file)).items()}
-            if dominant in pmc:
-                # KiB counters; FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request on gfx950)
-                traffic = 1024.0 * (pmc[dominant]["fetch_KiB_x2_corrected"] + pmc[dominant]["write_KiB_per_launch"])
-                traffic_src = "profiles/r01_e_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), bytes per launch"
+            raw = json.load(open(pmc_file))
+            # profiler symbol(s) of the timed kernel id: k_spmm_fwd / k_spmm_bwd are the BWD = false / true instantiations of k_spmm<>
+            if dominant in ("k_spmm_fwd", "k_spmm_bwd"):
+                want = "true>" if dominant == "k_spmm_bwd" else "false>"
+                rows = [v for k, v in raw.items() if k.startswith("k_spmm<") and k.endswith(want)]
+            else:
+                rows = [v for k, v in raw.items() if k.split("<")[0] == dominant]
+            if rows:
+                # KiB counters; FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request on gfx950);
+                # launch-weighted mean over the instantiations
+                n = sum(r["launches"] for r in rows)
+                traffic = 1024.0 * sum(r["launches"] * (r["fetch_KiB_x2_corrected"] + r["write_KiB_per_launch"]) for r in rows) / max(n, 1)
+                traffic_src = "profiles/r01_f_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), bytes per launch"
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / roofline.HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": dom_timing["avg_us"], "launches": dom_timing["launches"],

@@ -13,6 +13,8 @@
 #include "bliss_gnn.h"
 #include "prof.h"
 
+extern "C" int bliss_spmm_chunk_edges(int32_t nnz_bound);
+
 namespace {
 
 #define SP_TPB 256
@@ -39,14 +41,13 @@ __device__ __forceinline__ void store4(void* out, int64_t off, f4 a) {
   }
 }
 
-// Balanced ("merge-style") traversal: a wave owns EC = 64 consecutive entries of the edge list, whatever
+// Balanced ("merge-style") traversal: a wave owns EC consecutive entries of the edge list (bliss_spmm_chunk_edges), whatever
 // rows they belong to, so a 30 000-edge hub row and a 3-edge row cost the same per wave.  Rows that lie
 // inside one chunk are finished and stored by that wave; a row cut by chunk boundaries leaves fp32
 // partials (one "head" and one "tail" slot per chunk) that k_spmm_fixup adds IN CHUNK ORDER -- the sum
 // order is fixed, so results are bitwise reproducible without float atomics.
 // FWD: row = destination (CSR row), neighbour = src[e], coefficient = w[e]            (x 1/deg at the store)
 // BWD: row = source (t_edge groups the edges by source), neighbour = dst[e], coefficient = w[e]/deg(dst[e])
-#define EC 64
 
 template <bool VEC4, bool OUT_F32>
 __device__ __forceinline__ void store_row(void* out, int64_t off, f4 a, float scale) {
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
                                                 const int* __restrict__ blk_indptr, const bf16_t* __restrict__ w,
                                                 const bf16_t* __restrict__ h, int64_t h_stride, int n_rows,
                                                 const int* __restrict__ nnz_dev, int nnz_host, int dim,
-                                                int mean, void* out, int64_t out_stride, float* __restrict__ part) {
+                                                int mean, void* out, int64_t out_stride, float* __restrict__ part, int EC) {
   const int nnz = nnz_dev ? min(*nnz_dev, nnz_host) : nnz_host;
   const int lane = lane_id();
   const int chunk = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
 // rows without edges (isolated or capacity-padded) are cleared here, one wave per row
 template <bool OUT_F32, bool BWD>
 __global__ void __launch_bounds__(SP_TPB) k_spmm_fixup(const int* __restrict__ row_ptr, int n_rows, int dim, int mean,
-                                                      const float* __restrict__ part, void* out, int64_t out_stride) {
+                                                      const float* __restrict__ part, void* out, int64_t out_stride, int EC) {
   const int lane = lane_id();
   const int r = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
@@ -190,18 +191,19 @@ int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int
                 const void* h, int64_t h_stride, int n_rows, const int* nnz_dev, int nnz, int dim, int mean, void* out,
                 int64_t out_stride, int out_fp32, float* part, hipStream_t st) {
   if (n_rows <= 0 || dim <= 0) return 0;
+  const int EC = bliss_spmm_chunk_edges(nnz);
   if (nnz > EC && !part) return BLISS_EINVAL;
   const bool vec4 = (dim % 4 == 0) && (h_stride % 4 == 0) && (out_stride % 4 == 0) &&
                     (((uintptr_t)h) % 8 == 0) && (((uintptr_t)out) % (out_fp32 ? 16 : 8) == 0);
   const int nchunks = nnz > 0 ? (nnz + EC - 1) / EC : 1;
   dim3 grid((nchunks + SP_TPB / 64 - 1) / (SP_TPB / 64)), block(SP_TPB), gfix((n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64));
-#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, t_edge, src, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, nnz_dev, nnz, dim, mean, out, out_stride, part))
+#define GO(V, F) PROF_LAUNCH(BWD ? BK_SPMM_BWD : BK_SPMM_FWD, st, k_spmm<V, F, BWD><<<grid, block, 0, st>>>(row_ptr, t_edge, src, dst, blk_indptr, (const bf16_t*)w, (const bf16_t*)h, h_stride, n_rows, nnz_dev, nnz, dim, mean, out, out_stride, part, EC))
   if (vec4) { if (out_fp32) GO(true, true); else GO(true, false); }
   else      { if (out_fp32) GO(false, true); else GO(false, false); }
 #undef GO
   {
-    if (out_fp32) PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<true, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride));
-    else PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<false, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride));
+    if (out_fp32) PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<true, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride, EC));
+    else PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<false, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride, EC));
   }
   return (int)hipGetLastError();
 }
@@ -209,6 +211,11 @@ int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int
 }  // namespace
 
 extern "C" {
+
+// A wave walks its chunk edge by edge (a dependent chain of broadcasts and row loads), so the chunk length trades
+// parallelism against per-chunk overhead: the sampled blocks of this path hold 2 K - 500 K edges, far too few for
+// 64-edge chunks to fill the chip: 64 edges per wave from 200 K edges up, 32 from 50 K, 16 below.
+int bliss_spmm_chunk_edges(int32_t nnz_bound) { return nnz_bound >= 200000 ? 64 : (nnz_bound >= 50000 ? 32 : 16); }
 
 int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const int32_t* dst, const void* w, const void* h,
                    int64_t h_stride, int32_t n_dst, const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* out,

@@ -45,7 +45,8 @@ class _WeightedAggregate(torch.autograd.Function):
             w = w.contiguous()
             assert w.numel() == block.num_edges()
         B = block.num_edges()
-        part = torch.empty(2 * ((B + 63) // 64) * D, dtype=torch.float32, device=h.device) if B > 0 else None
+        ec = _lib.lib.bliss_spmm_chunk_edges(B)
+        part = torch.empty(2 * ((B + ec - 1) // ec) * D, dtype=torch.float32, device=h.device) if B > 0 else None
         _lib.check(_lib.lib.bliss_spmm_fwd(block.indptr.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
                                            0 if w is None else w.data_ptr(), h.data_ptr(), h.stride(0), S, block._nnz_ptr, B, D,
                                            int(mean),
@@ -64,7 +65,8 @@ class _WeightedAggregate(torch.autograd.Function):
         t_indptr, t_edge = block.transposed()
         gh = torch.empty(ctx.n_src, D, dtype=torch.bfloat16, device=gout.device)
         B = block.num_edges()
-        part = torch.empty(2 * ((B + 63) // 64) * D, dtype=torch.float32, device=gout.device) if B > 0 else None
+        ec = _lib.lib.bliss_spmm_chunk_edges(B)
+        part = torch.empty(2 * ((B + ec - 1) // ec) * D, dtype=torch.float32, device=gout.device) if B > 0 else None
         _lib.check(_lib.lib.bliss_spmm_bwd(t_indptr.data_ptr(), t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
                                            block.indptr.data_ptr(), 0 if w is None else w.data_ptr(), gout.data_ptr(),
                                            gout.stride(0), ctx.n_src, block._nnz_ptr, B, D, int(ctx.mean), gh.data_ptr(),

@@ -176,13 +176,15 @@ int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_str
  * [nnz] or NULL (= 1), out bf16 (out_fp32 == 0) or fp32 [n_dst, dim]; src/dst [nnz] = the block's edges
  * (CSR order: dst non-decreasing).  nnz_dev (optional): the true edge count on the device, with nnz an
  * upper bound (capacity-padded arrays; rows past the true n_dst must be empty in indptr). */
+int bliss_spmm_chunk_edges(int32_t nnz_bound);
 int bliss_spmm_fwd(const int32_t* indptr, const int32_t* src, const int32_t* dst, const void* w, const void* h,
                    int64_t h_stride, int32_t n_dst, const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* out,
                    int64_t out_stride, int out_fp32, float* partials, void* stream);
 
 /* Backward of the above w.r.t. h: gh[j,:] = sum_{e: src_e = j} (w_e / max(deg_dst(e),1)) * gout[dst_e,:].
  * t_indptr [n_src+1], t_edge [nnz]: the block's edges grouped by SOURCE in ascending edge order.
- * partials (both calls): fp32 scratch [2 * ceil(nnz/64) * dim] for rows cut by the 64-edge work chunks. */
+ * partials (both calls): fp32 scratch [2 * ceil(nnz / EC) * dim] for rows cut by the EC-edge work chunks,
+ * EC = bliss_spmm_chunk_edges(nnz) with the same nnz (bound) as passed to the call. */
 int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
                    const int32_t* indptr, const void* w, const void* gout, int64_t gout_stride, int32_t n_src,
                    const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32,
