@@ -384,13 +384,17 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
                                                       const long long* __restrict__ col_base, const int* __restrict__ span_seg,
                                                       LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
                                                       unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                                      uint2* __restrict__ seed_coef) {
+                                                      uint2* __restrict__ seed_coef, int n_wave_wgs) {
   __shared__ long long sh[COL_TPB / 64];
   const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
   if (cnt->E == 0) return;
   int bad = 0;
+  // the first n_wave_wgs workgroups take the short columns (one per wave), the others the long ones (one per workgroup):
+  // both kinds are latency chains, so they run side by side instead of one after the other
+  const int n_block_wgs = (int)gridDim.x - n_wave_wgs;
   // ---- columns up to COL_BIG edges: one per wave
-  for (int k = blockIdx.x * (COL_TPB / 64) + (tid >> 6); k < S; k += gridDim.x * (COL_TPB / 64)) {
+  if ((int)blockIdx.x < n_wave_wgs)
+  for (int k = blockIdx.x * (COL_TPB / 64) + (tid >> 6); k < S; k += n_wave_wgs * (COL_TPB / 64)) {
     const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
     if (n == 0 || n > COL_BIG) continue;              // wave-uniform
     const long long p0 = col_base[k] + s0;
@@ -415,7 +419,8 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
   // ---- the long columns: one per workgroup, the first COL_RB * COL_TPB edges held in registers between the two sums
-  for (int k = blockIdx.x; k < S; k += gridDim.x) {
+  if ((int)blockIdx.x >= n_wave_wgs)
+  for (int k = (int)blockIdx.x - n_wave_wgs; k < S; k += n_block_wgs) {
     const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
     if (n <= COL_BIG) continue;                       // block-uniform
     const long long p0 = col_base[k] + s0;
@@ -1174,8 +1179,9 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
+    const int n_wave_wgs = grid_for(cap_s, COL_TPB / 64, 2048);
     if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<cap_s < 4096 ? cap_s : 4096, COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef));
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs));
     if (mode == BLISS_MODE_BANDIT)
       PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
     else
