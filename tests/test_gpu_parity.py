@@ -998,3 +998,78 @@ def test_hub_columns_match_oracle(cuda):
         sampler.check_errors()
         o_w, _ = bo.exp3(og, o_blocks, o_w, edge_w, embed)
         assert torch.equal(sampler.exp3_weights.cpu().view(torch.int16), o_w.view(torch.int16))
+
+
+def test_gat_steps_replay_from_graphs(cuda):
+    """The GATv2 train step (attention logits -> bandit alpha, model.py:207-234 + bandit_sampler.py:146-154) also runs
+    with static shapes: one-graph and pipelined two-stream replays leave identical EXP3 rows and parameters."""
+    from bliss_gnn_amd.model import GATv2
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, PipelinedTrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(6000, 90000, seed=31)
+    feats = torch.randn(6000, 32, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 4, (6000,), generator=torch.Generator().manual_seed(3))
+    ids = torch.arange(6000, dtype=torch.int32, device=cuda)
+    outs = []
+    for cls in (GraphedTrainStep, PipelinedTrainStep):
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler([300, 150, 80], eta=0.1, model="gat")
+        torch.manual_seed(0)
+        model = GATv2(3, 32, 8, 4, [2, 2, 1], torch.relu, 0.0, 0.0, 0.2, True).to(cuda).bfloat16()
+        step = cls(g, sampler, model, 48)
+        loader = BatchLoader(ids, 48, seed=5).forever()
+        torch.manual_seed(9)
+        step.calibrate(loader, steps=3)
+        if cls is GraphedTrainStep:
+            step.capture(loader, warmup=2)               # 3 trained
+            for _ in range(4):
+                step(next(loader))                       # 7 trained
+            loss = float(step.loss)
+        else:
+            step.capture(loader, warmup=1)               # 4 trained, 5 sampled
+            step.run(loader, 1)                          # 6 trained
+            loss = float(step.drain())                   # 7 trained
+        sampler.check_errors()
+        assert loss == loss                              # finite
+        outs.append((sampler.exp3_weights.cpu().view(torch.int16).clone(), [p.detach().cpu().clone() for p in model.parameters()], loss))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0][0][0], torch.full_like(outs[0][0][0], 0x3F80))      # the bandit did move some weights
+
+
+def test_gat_static_step_matches_exact_step(cuda):
+    """One GATv2 train step on capacity-padded (static-shape) blocks == the same step on exact-size blocks: loss and the
+    EXP3 rows it leaves are identical (padded rows / edges are inert in every GAT kernel)."""
+    from bliss_gnn_amd.model import GATv2
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, TrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(6000, 90000, seed=31)
+    feats = torch.randn(6000, 32, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 4, (6000,), generator=torch.Generator().manual_seed(3))
+    ids = torch.arange(6000, dtype=torch.int32, device=cuda)
+    outs = []
+    for static in (False, True):
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler([300, 150, 80], eta=0.1, model="gat")
+        torch.manual_seed(0)
+        model = GATv2(3, 32, 8, 4, [2, 2, 1], torch.relu, 0.0, 0.0, 0.2, True).to(cuda).bfloat16()
+        loader = BatchLoader(ids, 48, seed=5).forever()
+        torch.manual_seed(9)
+        if static:
+            step = GraphedTrainStep(g, sampler, model, 48)
+            step.calibrate(loader, steps=3)
+            loss = step.eager_step(next(loader))
+        else:
+            for _ in range(3):
+                sampler.sample_blocks(g, next(loader))
+            step = TrainStep(g, sampler, model)
+            loss = step(next(loader))
+        sampler.check_errors()
+        outs.append((float(loss), sampler.exp3_weights.cpu().view(torch.int16).clone(), torch.get_rng_state()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
