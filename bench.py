@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="reddit", choices=["cora", "pubmed", "reddit", "yelp"])
+    ap.add_argument("--model", default="sage", choices=["sage", "gat"], help="gat = SURVEY config 4 (GATv2, heads 4/4/1, hidden 256)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=-1, help="-1: auto (bounded sample), 0: skip")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune-gemm", type=int, default=1, help="1: TunableOp picks the library GEMM solutions during warm-up")
@@ -77,9 +78,13 @@ def main():
 
     fan, eta, hidden = cfg["fanouts"], 0.1, 256
     sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000, eta=eta,
-                                            model="sage")
+                                            model=args.model)
     torch.manual_seed(1234)
-    model = SAGE(cfg["feat"], hidden, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()   # train_lightning.py:609-618
+    if args.model == "gat":                                  # train_lightning.py:245-249, 504-511
+        from bliss_gnn_amd.model import GATv2
+        model = GATv2(3, cfg["feat"], hidden, cfg["classes"], [4, 4, 1], torch.relu, 0.1, 0.1, 0.2, False).to(dev).bfloat16()
+    else:
+        model = SAGE(cfg["feat"], hidden, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()   # train_lightning.py:609-618
     grad_sync = exp3_sync = None
     if world > 1:
         bdist.broadcast_parameters(model)
@@ -87,7 +92,7 @@ def main():
     # every rank draws its own batches (different loader seed) and its own sampler stream
     loader = BatchLoader(train_nid, cfg["batch"], shuffle=True, drop_last=True, seed=2 + rank).forever()
     torch.manual_seed(3 + rank)                                                          # sampler stream (CPU generator)
-    dims = [hidden, hidden, cfg["classes"]]
+    dims = [hidden, hidden, cfg["classes"]] if args.model == "sage" else [4 * hidden, 4 * hidden, cfg["classes"]]
     from bliss_gnn_amd import roofline
     timer = roofline.KernelTimer()
     graphed = not args.eager
@@ -184,12 +189,13 @@ def main():
     alg = algorithmic_bytes(mean_sizes, cfg["feat"], dims)
 
     out = {
-        "metric": "steps/sec (train step: sample_blocks + gather + SAGE fwd/bwd + Adam + exp3), %s-like" % args.config,
+        "metric": "steps/sec (train step: sample_blocks + gather + %s fwd/bwd + Adam + exp3), %s-like" % ("SAGE" if args.model == "sage" else "GATv2", args.config),
         "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer SAGE hidden %d, poisson-bandit eta %.1f, "
-                               "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"], hidden, eta,
+        "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer %s hidden %d, poisson-bandit eta %.1f, "
+                               "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"],
+                                                                 "SAGE" if args.model == "sage" else "GATv2 (heads 4/4/1)", hidden, eta,
                                                                  "/".join(map(str, fan)), cfg["batch"]),
                    "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather over RCCL)" % world if world > 1 else "single GPU",
                    "launch": launch,
