@@ -21,6 +21,10 @@ namespace {
 
 struct f4 { float x, y, z, w; };
 
+// broadcast from a lane whose index is wave-uniform: v_readlane (scalar result, no LDS round trip like __shfl's ds_bpermute)
+__device__ __forceinline__ int bcast_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float bcast_f(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+
 __device__ __forceinline__ f4 load4(const bf16_t* p) {
   uint2 v = *reinterpret_cast<const uint2*>(p);
   f4 r;
@@ -100,16 +104,16 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
       }
     };
     if (cnt == 0) continue;                                 // rows without edges are cleared by k_spmm_fixup
-    int cur = __shfl(my_row, 0);
+    int cur = bcast_i(my_row, 0);
     f4 acc = zero;
     for (int j = 0; j < cnt;) {
-      const int r = __shfl(my_row, j);
+      const int r = bcast_i(my_row, j);
       if (r != cur) { flush(cur, acc); acc = zero; cur = r; }
       const int run = __popcll(__ballot(my_row == r && lane >= j));
       const int end = j + run;
       for (; j + 4 <= end; j += 4) {
-        int n0 = __shfl(my_n, j), n1 = __shfl(my_n, j + 1), n2 = __shfl(my_n, j + 2), n3 = __shfl(my_n, j + 3);
-        float k0 = __shfl(my_c, j), k1 = __shfl(my_c, j + 1), k2 = __shfl(my_c, j + 2), k3 = __shfl(my_c, j + 3);
+        int n0 = bcast_i(my_n, j), n1 = bcast_i(my_n, j + 1), n2 = bcast_i(my_n, j + 2), n3 = bcast_i(my_n, j + 3);
+        float k0 = bcast_f(my_c, j), k1 = bcast_f(my_c, j + 1), k2 = bcast_f(my_c, j + 2), k3 = bcast_f(my_c, j + 3);
         if (act) {
           if (VEC4) {
             f4 a0 = load4(h + n0 * h_stride + col), a1 = load4(h + n1 * h_stride + col);
@@ -126,8 +130,8 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
         }
       }
       for (; j < end; ++j) {
-        int n0 = __shfl(my_n, j);
-        float k0 = __shfl(my_c, j);
+        int n0 = bcast_i(my_n, j);
+        float k0 = bcast_f(my_c, j);
         if (act) {
           if (VEC4) {
             f4 a0 = load4(h + n0 * h_stride + col);
