@@ -24,7 +24,17 @@ __device__ __forceinline__ float lrelu(float x, float s) { return x > 0.f ? x : 
 // per-edge, per-head dot product of two gathered rows.
 //   MODE 0 (logits):  e[e,h]  = sum_d attn[h,d] * lrelu(feat[src_e,h,d] + feat[dst_e,h,d])
 //   MODE 1 (d_a):     out[e,h] = sum_d g[dst_e,h,d] * feat[src_e,h,d]
-template <int MODE>
+struct g4 { float x, y, z, w; };
+__device__ __forceinline__ g4 gload4(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  g4 r;
+  r.x = __uint_as_float(v.x << 16); r.y = __uint_as_float(v.x & 0xffff0000u);
+  r.z = __uint_as_float(v.y << 16); r.w = __uint_as_float(v.y & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ int gb_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }    // wave-uniform lane index
+
+template <int MODE, bool VEC4>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict__ src, const int* __restrict__ dst,
                                                          const int* __restrict__ nnz_dev, int nnz_host,
                                                          const bf16_t* __restrict__ feat, int64_t feat_stride,
@@ -36,15 +46,28 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict_
   const int chunk = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
   const int e0 = chunk * GAT_EC, e1 = min(nnz, e0 + GAT_EC);
   const int HD = H * D;
+  constexpr int W = VEC4 ? 4 : 1;
+  // the chunk's endpoints once, coalesced; broadcast per edge with v_readlane
+  int my_s = 0, my_d = 0;
+  if (e0 + lane < e1) { my_s = src[e0 + lane]; my_d = dst[e0 + lane]; }
   for (int e = e0; e < e1; ++e) {
-    const bf16_t* a = feat + (int64_t)src[e] * feat_stride;
-    const bf16_t* b = (MODE == 0 ? feat + (int64_t)dst[e] * feat_stride : g + (int64_t)dst[e] * g_stride);
+    const bf16_t* a = feat + (int64_t)gb_i(my_s, e - e0) * feat_stride;
+    const bf16_t* b = (MODE == 0 ? feat + (int64_t)gb_i(my_d, e - e0) * feat_stride : g + (int64_t)gb_i(my_d, e - e0) * g_stride);
     float part[GAT_MAXH];
 #pragma unroll
     for (int h = 0; h < GAT_MAXH; ++h) part[h] = 0.f;
-    for (int idx = lane; idx < HD; idx += 64) {
-      const float x = bf2f(a[idx]), y = bf2f(b[idx]);
-      const float v = MODE == 0 ? bf2f(attn[idx]) * lrelu(x + y, slope) : x * y;
+    for (int idx = lane * W; idx < HD; idx += 64 * W) {
+      float v;
+      if (VEC4) {                                       // D % 4 == 0: the four columns belong to one head
+        const g4 x = gload4(a + idx), y = gload4(b + idx);
+        if (MODE == 0) {
+          const g4 t = gload4(attn + idx);
+          v = t.x * lrelu(x.x + y.x, slope) + t.y * lrelu(x.y + y.y, slope) + t.z * lrelu(x.z + y.z, slope) + t.w * lrelu(x.w + y.w, slope);
+        } else v = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      } else {
+        const float x = bf2f(a[idx]), y = bf2f(b[idx]);
+        v = MODE == 0 ? bf2f(attn[idx]) * lrelu(x + y, slope) : x * y;
+      }
       const int hd = idx / D;
 #pragma unroll
       for (int h = 0; h < GAT_MAXH; ++h) if (h == hd) part[h] += v;
@@ -96,8 +119,9 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_softmax(const int* __restrict__
 // rows = destinations (BY_SRC == false, CSR order) or sources (BY_SRC == true, through t_edge).  Merge-style chunks of
 // 64 edges per wave; rows cut by chunk boundaries leave partials for k_gat_fixup (same scheme as csrc/spmm.hip).
 // With LBWD && !BY_SRC the kernel also accumulates d_attn[col] = sum_e de[e,h] * lrelu(x) (fp32 atomics per workgroup).
-#define GEC 64
-template <bool LBWD, bool BY_SRC>
+#define GEC 16                                          // edges per wave: every edge costs up to 2 KB of row gathers, so short
+                                                        // chunks (many waves in flight) beat long serial ones
+template <bool LBWD, bool BY_SRC, bool VEC4>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ row_ptr, const int* __restrict__ t_edge,
                                                      const int* __restrict__ src, const int* __restrict__ dst,
                                                      const int* __restrict__ nnz_dev, int nnz_host,
@@ -111,47 +135,77 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
   const int chunk = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
   const int nchunks = nnz > 0 ? (nnz + GEC - 1) / GEC : 1;
   const int HD = H * D;
+  constexpr int W = VEC4 ? 4 : 1;
   const bool do_attn = LBWD && !BY_SRC && d_attn != nullptr;
   if (do_attn) { for (int i = threadIdx.x; i < HD && i < 2048; i += GAT_TPB) sh_attn[i] = 0.f; __syncthreads(); }
   if (chunk < nchunks && nnz > 0) {
     const int c0 = chunk * GEC, c1 = min(nnz, c0 + GEC), cnt = c1 - c0;
-    int my_row = -1, my_e = 0;
+    int my_row = -1, my_e = 0, my_s = 0, my_d = 0;       // the chunk's edges once, coalesced; broadcast per edge with v_readlane
     if (lane < cnt) {
       my_e = BY_SRC ? t_edge[c0 + lane] : c0 + lane;
-      my_row = BY_SRC ? src[my_e] : dst[my_e];
+      my_s = src[my_e]; my_d = dst[my_e];
+      my_row = BY_SRC ? my_s : my_d;
     }
-    for (int col0 = 0; col0 < HD; col0 += 64) {
-      const int col = col0 + lane;
+    for (int col0 = 0; col0 < HD; col0 += 64 * W) {
+      const int col = col0 + lane * W;
       const bool act = col < HD;
-      const int hd = act ? col / D : 0;
-      const float at = (LBWD && act) ? bf2f(attn[col]) : 0.f;
-      float attn_acc = 0.f, acc = 0.f;
-      int cur = __shfl(my_row, 0);
-      auto flush = [&](int r, float v) {
-        const int rb = row_ptr[r], re = row_ptr[r + 1];
-        const bool starts = rb >= c0, ends = re <= c1;
-        if (!act) return;
-        if (starts && ends) out[r * out_stride + col] = f2bf(v);
-        else part[((int64_t)chunk * 2 + (starts ? 1 : 0)) * HD + col] = v;
+      const int hd = act ? col / D : 0;                 // VEC4 requires D % 4 == 0: the lane's columns share a head
+      float at[W], acc[W], attn_acc[W];
+#pragma unroll
+      for (int i = 0; i < W; ++i) { at[i] = (LBWD && act) ? bf2f(attn[col + i]) : 0.f; acc[i] = 0.f; attn_acc[i] = 0.f; }
+      int cur = gb_i(my_row, 0);
+      auto flush = [&](int r) {
+        if (act) {
+          const int rb = row_ptr[r], re = row_ptr[r + 1];
+          const bool starts = rb >= c0, ends = re <= c1;
+          if (starts && ends) {
+            if (VEC4) {
+              uint2 v;
+              v.x = (uint32_t)f2bf(acc[0]) | ((uint32_t)f2bf(acc[1 % W]) << 16);
+              v.y = (uint32_t)f2bf(acc[2 % W]) | ((uint32_t)f2bf(acc[3 % W]) << 16);
+              *reinterpret_cast<uint2*>(out + r * out_stride + col) = v;
+            } else out[r * out_stride + col] = f2bf(acc[0]);
+          } else {
+            float* q = part + ((int64_t)chunk * 2 + (starts ? 1 : 0)) * HD + col;
+#pragma unroll
+            for (int i = 0; i < W; ++i) q[i] = acc[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) acc[i] = 0.f;
       };
       for (int j = 0; j < cnt; ++j) {
-        const int r = __shfl(my_row, j), e = __shfl(my_e, j);
-        if (r != cur) { flush(cur, acc); acc = 0.f; cur = r; }
+        const int r = gb_i(my_row, j), e = gb_i(my_e, j), s_ = gb_i(my_s, j), d_ = gb_i(my_d, j);
+        if (r != cur) { flush(cur); cur = r; }
         if (act) {
-          const int s_ = src[e], d_ = dst[e];
+          const float cf = bf2f(coef[(int64_t)e * H + hd]);
           if (LBWD) {
-            const float x = bf2f(feat[(int64_t)s_ * feat_stride + col]) + bf2f(feat[(int64_t)d_ * feat_stride + col]);
-            const float de = bf2f(coef[(int64_t)e * H + hd]);
-            acc += de * at * (x > 0.f ? 1.f : slope);
-            if (do_attn) attn_acc += de * lrelu(x, slope);
+            float xs[W], xd[W];
+            if (VEC4) {
+              const g4 a = gload4(feat + (int64_t)s_ * feat_stride + col), b = gload4(feat + (int64_t)d_ * feat_stride + col);
+              xs[0] = a.x; xs[1 % W] = a.y; xs[2 % W] = a.z; xs[3 % W] = a.w;
+              xd[0] = b.x; xd[1 % W] = b.y; xd[2 % W] = b.z; xd[3 % W] = b.w;
+            } else { xs[0] = bf2f(feat[(int64_t)s_ * feat_stride + col]); xd[0] = bf2f(feat[(int64_t)d_ * feat_stride + col]); }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+              const float x = xs[i] + xd[i];
+              acc[i] += cf * at[i] * (x > 0.f ? 1.f : slope);
+              if (do_attn) attn_acc[i] += cf * lrelu(x, slope);
+            }
           } else {
             const int nb = BY_SRC ? d_ : s_;
-            acc += bf2f(coef[(int64_t)e * H + hd]) * bf2f(feat[(int64_t)nb * feat_stride + col]);
+            if (VEC4) {
+              const g4 f = gload4(feat + (int64_t)nb * feat_stride + col);
+              acc[0] += cf * f.x; acc[1 % W] += cf * f.y; acc[2 % W] += cf * f.z; acc[3 % W] += cf * f.w;
+            } else acc[0] += cf * bf2f(feat[(int64_t)nb * feat_stride + col]);
           }
         }
       }
-      flush(cur, acc);
-      if (do_attn && act && col < 2048) atomicAdd(&sh_attn[col], attn_acc);
+      flush(cur);
+      if (do_attn && act) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) if (col + i < 2048) atomicAdd(&sh_attn[col + i], attn_acc[i]);
+      }
     }
   }
   if (do_attn) {
@@ -210,6 +264,8 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_alpha(const int* __restrict__ i
 
 extern "C" {
 
+int bliss_gat_chunk_edges(void) { return GEC; }
+
 int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
                      int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
                      void* stream) {
@@ -217,7 +273,10 @@ int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_
   if (nnz == 0) return 0;
   if (!src || !dst) return BLISS_EINVAL;
   const int chunks = (nnz + GAT_EC - 1) / GAT_EC;
-  k_gat_edge_dot<0><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0,
+  const bool v4 = head_dim % 4 == 0 && feat_stride % 4 == 0 && ((uintptr_t)feat) % 8 == 0 && ((uintptr_t)attn) % 8 == 0;
+  if (v4) k_gat_edge_dot<0, true><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0,
+                                                                        (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)e_out);
+  else k_gat_edge_dot<0, false><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0,
                                                                         (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)e_out);
   return (int)hipGetLastError();
 }
@@ -228,7 +287,10 @@ int bliss_gat_edge_dot(const int32_t* src, const int32_t* dst, const int32_t* nn
   if (nnz == 0) return 0;
   if (!src || !dst) return BLISS_EINVAL;
   const int chunks = (nnz + GAT_EC - 1) / GAT_EC;
-  k_gat_edge_dot<1><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
+  const bool v4 = head_dim % 4 == 0 && feat_stride % 4 == 0 && g_stride % 4 == 0 && ((uintptr_t)feat) % 8 == 0 && ((uintptr_t)g) % 8 == 0;
+  if (v4) k_gat_edge_dot<1, true><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
+                                                                        g_stride, nullptr, heads, head_dim, 0.f, (bf16_t*)out);
+  else k_gat_edge_dot<1, false><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
                                                                         g_stride, nullptr, heads, head_dim, 0.f, (bf16_t*)out);
   return (int)hipGetLastError();
 }
@@ -256,13 +318,17 @@ int bliss_gat_rows(int which, const int32_t* row_ptr, int32_t n_rows, const int3
   const int chunks = nnz > 0 ? (nnz + GEC - 1) / GEC : 1;
   dim3 grid((chunks + 3) / 4), block(GAT_TPB);
 #define ARGS row_ptr, t_edge, src, dst, nnz_dev, nnz, (const bf16_t*)coef, (const bf16_t*)feat, feat_stride, (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)out, out_stride, partials, d_attn
+  const bool v4 = head_dim % 4 == 0 && feat_stride % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)feat) % 8 == 0 &&
+                  ((uintptr_t)out) % 8 == 0 && (!attn || ((uintptr_t)attn) % 8 == 0);
+#define GO(L, S) do { if (v4) k_gat_rows<L, S, true><<<grid, block, 0, st>>>(ARGS); else k_gat_rows<L, S, false><<<grid, block, 0, st>>>(ARGS); } while (0)
   switch (which) {             // bit 0: rows are sources (through t_edge); bit 1: logits backward
-    case 0: k_gat_rows<false, false><<<grid, block, 0, st>>>(ARGS); break;
-    case 1: k_gat_rows<false, true><<<grid, block, 0, st>>>(ARGS); break;
-    case 2: k_gat_rows<true, false><<<grid, block, 0, st>>>(ARGS); break;
-    case 3: k_gat_rows<true, true><<<grid, block, 0, st>>>(ARGS); break;
+    case 0: GO(false, false); break;
+    case 1: GO(false, true); break;
+    case 2: GO(true, false); break;
+    case 3: GO(true, true); break;
     default: return BLISS_EINVAL;
   }
+#undef GO
 #undef ARGS
   k_gat_fixup<<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
   return (int)hipGetLastError();

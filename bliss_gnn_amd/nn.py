@@ -178,7 +178,7 @@ class _GatLogits(torch.autograd.Function):
         de = de.contiguous().bfloat16()
         nnz_ptr, B = _nnz(block)
         K, S, HD = feat.shape[0], block.num_dst_nodes(), H * D
-        part = torch.empty(max(2 * ((B + 63) // 64) * HD, 1), dtype=torch.float32, device=feat.device)
+        part = torch.empty(max(2 * (-(-B // _lib.lib.bliss_gat_chunk_edges())) * HD, 1), dtype=torch.float32, device=feat.device)
         d_attn = torch.zeros(HD, dtype=torch.float32, device=feat.device)
         d_el = torch.empty(K, HD, dtype=torch.bfloat16, device=feat.device)
         d_er = torch.empty(S, HD, dtype=torch.bfloat16, device=feat.device)
@@ -225,7 +225,7 @@ class _GatAggregate(torch.autograd.Function):
         nnz_ptr, B = _nnz(block)
         S, HD = block.num_dst_nodes(), H * D
         out = torch.empty(S, HD, dtype=torch.bfloat16, device=feat.device)
-        part = torch.empty(max(2 * ((B + 63) // 64) * HD, 1), dtype=torch.float32, device=feat.device)
+        part = torch.empty(max(2 * (-(-B // _lib.lib.bliss_gat_chunk_edges())) * HD, 1), dtype=torch.float32, device=feat.device)
         _lib.check(_lib.lib.bliss_gat_rows(0, block.indptr.data_ptr(), S, 0, block.src.data_ptr(), block.dst.data_ptr(), nnz_ptr, B,
                                            a.data_ptr(), feat.data_ptr(), feat.stride(0), 0, H, D, 0.0, out.data_ptr(),
                                            out.stride(0), part.data_ptr(), 0, _stream()), "bliss_gat_rows")
@@ -245,7 +245,7 @@ class _GatAggregate(torch.autograd.Function):
                                                dout.data_ptr(), dout.stride(0), H, D, da.data_ptr(), _stream()), "bliss_gat_edge_dot")
         t_indptr, t_edge = block.transposed()
         d_feat = torch.empty(K, HD, dtype=torch.bfloat16, device=feat.device)
-        part = torch.empty(max(2 * ((B + 63) // 64) * HD, 1), dtype=torch.float32, device=feat.device)
+        part = torch.empty(max(2 * (-(-B // _lib.lib.bliss_gat_chunk_edges())) * HD, 1), dtype=torch.float32, device=feat.device)
         _lib.check(_lib.lib.bliss_gat_rows(1, t_indptr.data_ptr(), K, t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
                                            nnz_ptr, B, a.data_ptr(), dout.data_ptr(), dout.stride(0), 0, H, D, 0.0,
                                            d_feat.data_ptr(), d_feat.stride(0), part.data_ptr(), 0, _stream()), "bliss_gat_rows")

@@ -250,9 +250,11 @@ int bliss_row_sum(const void* w_pos, int64_t num_edges, int64_t* row_sum, void* 
  *                           backward  coef[e,h]*attn[col]*lrelu'(feat[src]+feat[dst])  instead of  coef[e,h]*feat[nbr,col]
  *                           (which = 0 is the forward aggregation of :98, 1 its backward w.r.t. feat, 2 / 3 the two halves of
  *                           the logits backward; with which = 2 and d_attn != NULL also d_attn[col] += sum_e coef*lrelu(x)).
- *                           partials: fp32 [2 * ceil(nnz/64) * heads*head_dim].
+ *                           partials: fp32 [2 * ceil(nnz / bliss_gat_chunk_edges()) * heads*head_dim].
  *   bliss_gat_edge_dot      out[e,h] = g[dst_e,h,:] . feat[src_e,h,:]   (d_a of the aggregation)
  *   bliss_gat_alpha         calculate_alpha, model == 'gat' (bandit_sampler.py:146-154), exact sums, bf16 [nnz]. */
+/* edges per work chunk of bliss_gat_rows: its partials buffer holds 2 * ceil(nnz / chunk) * heads * head_dim floats */
+int bliss_gat_chunk_edges(void);
 int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
                      int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
                      void* stream);
