@@ -215,19 +215,40 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
 }
 
 // rows without edges -> 0; rows cut by chunk boundaries -> tail partial of their first chunk + head partials of the rest
+// (added in chunk order: deterministic).  VEC4: a lane owns four consecutive columns (float4 partials, 8-byte stores).
+template <bool VEC4>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_fixup(const int* __restrict__ row_ptr, int n_rows, int HD,
                                                       const float* __restrict__ part, bf16_t* __restrict__ out, int64_t out_stride) {
   const int lane = lane_id();
   const int r = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
   const int rb = row_ptr[r], re = row_ptr[r + 1];
-  if (re <= rb) { for (int col = lane; col < HD; col += 64) out[r * out_stride + col] = 0; return; }
+  constexpr int W = VEC4 ? 4 : 1;
+  if (re <= rb) {
+    for (int col = lane * W; col < HD; col += 64 * W) {
+      if (VEC4) *reinterpret_cast<uint2*>(out + r * out_stride + col) = make_uint2(0u, 0u); else out[r * out_stride + col] = 0;
+    }
+    return;
+  }
   const int c = rb / GEC, c_end = (re - 1) / GEC;
   if (c_end == c) return;
-  for (int col = lane; col < HD; col += 64) {
-    float sum = part[((int64_t)c * 2 + 1) * HD + col];
-    for (int cc = c + 1; cc <= c_end; ++cc) sum += part[((int64_t)cc * 2) * HD + col];
-    out[r * out_stride + col] = f2bf(sum);
+  for (int col = lane * W; col < HD; col += 64 * W) {
+    if (VEC4) {
+      float4 sum = *reinterpret_cast<const float4*>(part + ((int64_t)c * 2 + 1) * HD + col);
+#pragma unroll 4
+      for (int cc = c + 1; cc <= c_end; ++cc) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)cc * 2) * HD + col);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      uint2 o;
+      o.x = (uint32_t)f2bf(sum.x) | ((uint32_t)f2bf(sum.y) << 16);
+      o.y = (uint32_t)f2bf(sum.z) | ((uint32_t)f2bf(sum.w) << 16);
+      *reinterpret_cast<uint2*>(out + r * out_stride + col) = o;
+    } else {
+      float sum = part[((int64_t)c * 2 + 1) * HD + col];
+      for (int cc = c + 1; cc <= c_end; ++cc) sum += part[((int64_t)cc * 2) * HD + col];
+      out[r * out_stride + col] = f2bf(sum);
+    }
   }
 }
 
@@ -330,7 +351,8 @@ int bliss_gat_rows(int which, const int32_t* row_ptr, int32_t n_rows, const int3
   }
 #undef GO
 #undef ARGS
-  k_gat_fixup<<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
+  if (v4 && ((uintptr_t)partials) % 16 == 0) k_gat_fixup<true><<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
+  else k_gat_fixup<false><<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
   return (int)hipGetLastError();
 }
 
