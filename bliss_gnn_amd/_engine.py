@@ -352,6 +352,7 @@ class LayerEngine:
         _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
                                                  self.rng_cap, self._slot_counts[slot].data_ptr() + 20, _stream()), "bliss_rng_stream_end")
         self.mt_back.copy_(self.mt_dev, non_blocking=True)
+        self._slot_counts_host[slot].copy_(self._slot_counts[slot], non_blocking=True)
 
     def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
@@ -365,8 +366,8 @@ class LayerEngine:
         counts_dev, layers = out
         if slot not in self._slot_counts_host:
             self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
-        self._slot_counts_host[slot].copy_(counts_dev, non_blocking=True)
-        if not external_rng:
+        if not external_rng:                     # (external: static_rng_end copies both, off the consumer's critical path)
+            self._slot_counts_host[slot].copy_(counts_dev, non_blocking=True)
             self.mt_back.copy_(self.mt_dev, non_blocking=True)
         blocks = []
         for n, lay in enumerate(layers):

@@ -236,6 +236,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
         self.mfgs = [None, None]
         self.side = torch.cuda.Stream()
+        self._smp_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.losses = None
         self.last_counts2 = None
 
@@ -353,10 +354,11 @@ class PipelinedTrainStep(GraphedTrainStep):
                 self.g_fwd[cur].replay()                 # F + X
             main.wait_stream(side)                       # the sampler needs the EXP3 weights X just wrote
             self.g_smp[nxt].replay()                     # S, beside ...
+            self._smp_done[nxt].record(main)             # (the generator's commit below is not something F waits for)
             eng.static_rng_end(nxt)
             with torch.cuda.stream(side):
                 self.g_bwd[cur].replay()                 # ... B
-                side.wait_stream(main)                   # the next forward needs the blocks S built
+                side.wait_event(self._smp_done[nxt])     # the next forward needs the blocks S built
         main.wait_stream(side)
 
     def __call__(self, loader):
