@@ -146,27 +146,37 @@ __global__ void __launch_bounds__(SP_TPB) k_spmm(const int* __restrict__ row_ptr
 
 // rows cut by chunk boundaries: tail partial of the chunk they start in + head partials of the following chunks;
 // rows without edges (isolated or capacity-padded) are cleared here, one wave per row
-template <bool OUT_F32, bool BWD>
+template <bool OUT_F32, bool BWD, bool VEC4>
 __global__ void __launch_bounds__(SP_TPB) k_spmm_fixup(const int* __restrict__ row_ptr, int n_rows, int dim, int mean,
                                                       const float* __restrict__ part, void* out, int64_t out_stride, int EC) {
   const int lane = lane_id();
   const int r = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
   const int rb = row_ptr[r], re = row_ptr[r + 1];
+  constexpr int W = VEC4 ? 4 : 1;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
   if (re <= rb) {                                           // no edges (incl. capacity-padded rows): the output row is zero
-    for (int col = lane; col < dim; col += 64) {
-      if (OUT_F32) ((float*)out)[r * out_stride + col] = 0.f; else ((bf16_t*)out)[r * out_stride + col] = 0;
-    }
+    for (int col = lane * W; col < dim; col += 64 * W) store_row<VEC4, OUT_F32>(out, r * out_stride + col, zero, 1.0f);
     return;
   }
   const int c = rb / EC, c_end = (re - 1) / EC;
   if (c_end == c) return;                                   // finished by its chunk
   const float scale = (!BWD && mean) ? 1.0f / (float)(re - rb) : 1.0f;
-  for (int col = lane; col < dim; col += 64) {
-    float sum = part[((int64_t)c * 2 + 1) * dim + col];
-    for (int cc = c + 1; cc <= c_end; ++cc) sum += part[((int64_t)cc * 2) * dim + col];
-    sum *= scale;
-    if (OUT_F32) ((float*)out)[r * out_stride + col] = sum; else ((bf16_t*)out)[r * out_stride + col] = f2bf(sum);
+  for (int col = lane * W; col < dim; col += 64 * W) {
+    f4 sum = zero;
+    if (VEC4) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)c * 2 + 1) * dim + col);
+      sum.x = v.x; sum.y = v.y; sum.z = v.z; sum.w = v.w;
+#pragma unroll 4
+      for (int cc = c + 1; cc <= c_end; ++cc) {
+        const float4 u = *reinterpret_cast<const float4*>(part + ((int64_t)cc * 2) * dim + col);
+        sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
+      }
+    } else {
+      sum.x = part[((int64_t)c * 2 + 1) * dim + col];
+      for (int cc = c + 1; cc <= c_end; ++cc) sum.x += part[((int64_t)cc * 2) * dim + col];
+    }
+    store_row<VEC4, OUT_F32>(out, r * out_stride + col, sum, scale);
   }
 }
 
@@ -206,8 +216,11 @@ int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int
   else      { if (out_fp32) GO(false, true); else GO(false, false); }
 #undef GO
   {
-    if (out_fp32) PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<true, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride, EC));
-    else PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<false, BWD><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride, EC));
+    const bool fv = vec4 && (((uintptr_t)part) % 16 == 0);
+#define FIX(F, V) PROF_LAUNCH(BK_SPMM_FIXUP, st, k_spmm_fixup<F, BWD, V><<<gfix, block, 0, st>>>(row_ptr, n_rows, dim, mean, part, out, out_stride, EC))
+    if (out_fp32) { if (fv) FIX(true, true); else FIX(true, false); }
+    else          { if (fv) FIX(false, true); else FIX(false, false); }
+#undef FIX
   }
   return (int)hipGetLastError();
 }
