@@ -267,7 +267,7 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
   if (!w_pos || !row_sum || !scratch || num_edges <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
-  if (grid > 4096) grid = 4096;
+  if (grid > 1024) grid = 1024;                      // usually every workgroup returns at once (norm == 1.0): keep the launch small
   if (grid < 1) grid = 1;
   PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16));
   return (int)hipGetLastError();
