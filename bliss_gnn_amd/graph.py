@@ -103,7 +103,7 @@ class _LazyFrame(dict):
 
     def __missing__(self, key):
         if self._parent is not None and key in self._parent:
-            v = self._parent[key][self._index_fn()]
+            v = torch.index_select(self._parent[key], 0, self._index_fn())      # int32 ids are fine: no widening pass
             self[key] = v
             return v
         raise KeyError(key)
@@ -128,9 +128,9 @@ class Block:
         self._n_src, self._n_dst = int(n_src), int(n_dst)
         self.indptr, self.src, self.dst, self.pos = indptr, src, dst, pos
         self.idtype = torch.int32
-        self.srcdata = _LazyFrame(g.ndata if g is not None else None, lambda: self.srcdata[NID].long())
-        self.dstdata = _LazyFrame(g.ndata if g is not None else None, lambda: self.dstdata[NID].long())
-        self.edata = _LazyFrame(g.edata if g is not None else None, lambda: self.edata[EID].long())
+        self.srcdata = _LazyFrame(g.ndata if g is not None else None, lambda: self.srcdata[NID])
+        self.dstdata = _LazyFrame(g.ndata if g is not None else None, lambda: self.dstdata[NID])
+        self.edata = _LazyFrame(g.edata if g is not None else None, lambda: self.edata[EID])
         self.srcdata[NID] = src_nid
         self.dstdata[NID] = src_nid[: self._n_dst]
         self.edata[EID] = eid
