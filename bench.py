@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="reddit", choices=["cora", "pubmed", "reddit", "yelp"])
+    ap.add_argument("--sampler", default="poisson-bandit", choices=["poisson-bandit", "poisson-ladies"],
+                    help="train_lightning.py:536-540; poisson-ladies = the static-weight baseline sampler (no EXP3 update)")
     ap.add_argument("--model", default="sage", choices=["sage", "gat"], help="gat = SURVEY config 4 (GATv2, heads 4/4/1, hidden 256)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=-1, help="-1: auto (bounded sample), 0: skip")
     ap.add_argument("--no-roofline", action="store_true")
@@ -77,8 +79,11 @@ def main():
     t_setup = time.time() - t0
 
     fan, eta, hidden = cfg["fanouts"], 0.1, 256
-    sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000, eta=eta,
-                                            model=args.model)
+    if args.sampler == "poisson-ladies":
+        sampler = bg.PoissonLadiesSampler(fan)
+    else:
+        sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000, eta=eta,
+                                                model=args.model)
     torch.manual_seed(1234)
     if args.model == "gat":                                  # train_lightning.py:245-249, 504-511
         from bliss_gnn_amd.model import GATv2
@@ -194,9 +199,10 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer %s hidden %d, poisson-bandit eta %.1f, "
-                               "fanouts %s, batch %d per GPU" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"],
+                               "fanouts %s, batch %d per GPU%s" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"],
                                                                  "SAGE" if args.model == "sage" else "GATv2 (heads 4/4/1)", hidden, eta,
-                                                                 "/".join(map(str, fan)), cfg["batch"]),
+                                                                 "/".join(map(str, fan)), cfg["batch"],
+                                                                 "" if args.sampler == "poisson-bandit" else " [sampler: poisson-ladies, no EXP3 update]"),
                    "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather over RCCL)" % world if world > 1 else "single GPU",
                    "launch": launch,
                    "global_batch": cfg["batch"] * world},

@@ -33,8 +33,7 @@ class LadiesSampler(BlockSampler):
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """ladies_sampler.py:109-123."""
-        if self._engine is None or self._engine.g is not g:
-            self._engine = LayerEngine(g)
+        self._bind(g)
         w_pos = g.edata_by_position(self.edge_weight)                    # :114
         output_nodes = seed_nodes
         order = list(reversed(range(len(self.nodes_per_layer))))         # :112
@@ -48,6 +47,33 @@ class LadiesSampler(BlockSampler):
             blk.edata[self.output_weight] = blk._edge_weights            # :100
             blocks.insert(0, blk)
         return blocks[0].srcdata[NID], output_nodes, blocks              # :121,:123
+
+
+    # -- static-shape variant (graph-capturable; Poisson only): same contract as PoissonBanditLadiesSampler's ------------
+    def _bind(self, g):
+        if self._engine is None or self._engine.g is not g:
+            self._engine = LayerEngine(g)
+        return self._engine
+
+    def sample_blocks_static(self, g, seed_nodes, slot=0, chain_rng=False, external_rng=False):
+        if not self._poisson:
+            raise NotImplementedError("the multinomial draw is torch.multinomial on the host: no static-shape variant")
+        eng = self._bind(g)
+        w_pos = g.edata_by_position(self.edge_weight)
+        order = list(reversed(range(len(self.nodes_per_layer))))
+        blks = eng.enqueue_static([w_pos] * len(order), seed_nodes, [self.nodes_per_layer[b] for b in order], self._mode(), 0.0,
+                                  self.eps, slot=slot, chain_rng=chain_rng, external_rng=external_rng)
+        blocks = []
+        for blk in blks:
+            blk.edata[self.output_weight] = blk._edge_weights
+            blocks.insert(0, blk)
+        return blocks[0].srcdata[NID], seed_nodes, blocks
+
+    def finish_static(self, slot=0, commit=True):
+        return self._engine.finish(slot, commit)
+
+    def check_errors(self):
+        pass                                               # no bandit state; sampler errors surface through finish()
 
 
 class PoissonLadiesSampler(LadiesSampler):

@@ -51,7 +51,7 @@ class TrainStep:
         self.g, self.sampler, self.model = g, sampler, model
         self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()   # :77-79
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)                           # :206
-        self.bandit = bandit
+        self.bandit = bandit and hasattr(sampler, "exp3")          # train_lightning.py:469: only for the bandit samplers
         self.grad_sync, self.exp3_sync = grad_sync, exp3_sync
         self.num_steps = 0
         self.w = 0.99                                                                    # :76
@@ -142,14 +142,17 @@ class GraphedTrainStep:
         loss = self.loss_fn(pred, y)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
+        bandit = hasattr(self.sampler, "exp3")                     # train_lightning.py:469: only for the bandit samplers
         if self.distributed:
             from . import dist as bdist
             bdist.allreduce_gradients(self.model)
             self.opt.step()
-            bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
+            if bandit:
+                bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
         else:
             self.opt.step()
-            self.sampler.exp3(mfgs, self.g)
+            if bandit:
+                self.sampler.exp3(mfgs, self.g)
         # detach: a live autograd graph would pin the warm-up stream's AccumulateGrad nodes into the capture
         return loss.detach()
 
@@ -246,6 +249,8 @@ class PipelinedTrainStep(GraphedTrainStep):
     def _forward(self, mfgs):
         pred = self.model(mfgs, mfgs[0].srcdata["features"])
         loss = self.loss_fn(pred, mfgs[-1].dstdata["labels"])
+        if not hasattr(self.sampler, "exp3"):                      # LADIES samplers keep no bandit state
+            return loss
         if self.distributed:
             from . import dist as bdist
             bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)

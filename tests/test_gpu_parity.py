@@ -1073,3 +1073,67 @@ def test_gat_static_step_matches_exact_step(cuda):
         outs.append((float(loss), sampler.exp3_weights.cpu().view(torch.int16).clone(), torch.get_rng_state()))
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_poisson_ladies_static_and_pipelined(cuda):
+    """PoissonLadiesSampler on static shapes: padded blocks == exact blocks (trimmed), and the graph-replayed / pipelined
+    loops (no EXP3 update for this sampler, train_lightning.py:469) leave identical parameters and generator state."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, PipelinedTrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(8000, 160000, seed=12)
+    feats = torch.randn(8000, 64, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 5, (8000,), generator=torch.Generator().manual_seed(3))
+    ids = torch.arange(8000, dtype=torch.int32, device=cuda)
+    fan, bs = [400, 200, 100], 64
+
+    def build():
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        torch.manual_seed(0)
+        return g, bg.PoissonLadiesSampler(fan), SAGE(64, 32, 5, 3, torch.relu, 0.0).to(cuda).bfloat16()
+
+    # padded == exact on one batch, same generator state
+    g, sampler, model = build()
+    step = GraphedTrainStep(g, sampler, model, bs)
+    loader = BatchLoader(ids, bs, seed=5).forever()
+    torch.manual_seed(9)
+    step.calibrate(loader, steps=3)
+    seeds = next(loader)
+    state = torch.get_rng_state()
+    _, _, exact = sampler.sample_blocks(g, seeds)
+    after = torch.get_rng_state()
+    torch.set_rng_state(state)
+    step.seeds.copy_(seeds)
+    sampler._engine.stage_rng_from_torch()
+    _, _, padded = sampler.sample_blocks_static(g, step.seeds)
+    torch.cuda.synchronize()
+    cnts = sampler.finish_static()
+    assert torch.equal(torch.get_rng_state(), after)
+    for a, b, c in zip(exact, padded, reversed(cnts)):
+        assert (a.num_edges(), a.num_src_nodes()) == (c.B, c.K)
+        assert torch.equal(a.src, b.src[:c.B]) and torch.equal(a.dst, b.dst[:c.B])
+        assert torch.equal(a.edata["edge_weights"].view(torch.int16), b.edata["edge_weights"][:c.B].view(torch.int16))
+
+    outs = []
+    for cls in (GraphedTrainStep, PipelinedTrainStep):
+        g, sampler, model = build()
+        step = cls(g, sampler, model, bs)
+        loader = BatchLoader(ids, bs, seed=5).forever()
+        torch.manual_seed(9)
+        step.calibrate(loader, steps=3)
+        if cls is GraphedTrainStep:
+            step.capture(loader, warmup=2)               # 3 trained
+            for _ in range(4):
+                step(next(loader))                       # 7 trained
+            sampler.sample_blocks(g, next(loader))       # the pipelined loop samples one batch ahead
+        else:
+            step.capture(loader, warmup=1)               # 4 trained, 5 sampled
+            step.run(loader, 1)                          # 6 trained, 7 sampled
+            step.drain()                                 # 7 trained
+            sampler.sample_blocks(g, next(loader))       # 8 sampled on both sides
+        outs.append(([p.detach().cpu().clone() for p in model.parameters()], torch.get_rng_state()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
