@@ -216,7 +216,7 @@ def main():
         per_launch = alg_dom / dom_timing["launches"]
         achieved = per_launch / (dom_timing["avg_us"] * 1e-6) / 1e9
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")     # separate rocprofv3 --pmc passes
+        pmc_file = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")     # separate rocprofv3 --pmc passes
         if os.path.exists(pmc_file):
             raw = json.load(open(pmc_file))
             # profiler symbol(s) of the timed kernel id: k_spmm_fwd / k_spmm_bwd are the BWD = false / true instantiations of k_spmm<>
@@ -230,7 +230,7 @@ def main():
                 # launch-weighted mean over the instantiations
                 n = sum(r["launches"] for r in rows)
                 traffic = 1024.0 * sum(r["launches"] * (r["fetch_KiB_x2_corrected"] + r["write_KiB_per_launch"]) for r in rows) / max(n, 1)
-                traffic_src = "profiles/r01_f_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), bytes per launch"
+                traffic_src = "profiles/r01_g_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), bytes per launch"
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / roofline.HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": dom_timing["avg_us"], "launches": dom_timing["launches"],
