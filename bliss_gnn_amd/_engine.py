@@ -70,6 +70,7 @@ class LayerEngine:
         self.acc_p2 = torch.zeros(V, dtype=torch.int64, device=dev)
         self.kept_map = torch.full((V,), -1, dtype=torch.int32, device=dev)
         self.span_seg = torch.zeros(self.Eg // 256 + 2, dtype=torch.int32, device=dev)
+        self._kept_rec = self._span_cnt = None
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
         self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
@@ -305,6 +306,13 @@ class LayerEngine:
                             kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
                             ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
         c_ws.kept_map, c_ws.span_seg = self.kept_map.data_ptr(), self.span_seg.data_ptr()
+        e_bound = max(c.get("E", self.Eg) for c in self.caps)        # one buffer for all layers (descriptors of earlier layers stay valid)
+        if e_bound <= (1 << 24):        # spill buffer for the block passes: 16 B per frontier position, only for bounded frontiers
+            pos = -(-e_bound // 1024) * 1024
+            if self._kept_rec is None or self._kept_rec.numel() < pos * 2:
+                self._kept_rec = torch.empty(pos * 2, dtype=torch.int64, device=dev)
+                self._span_cnt = torch.zeros(pos // 256 + 4, dtype=torch.int32, device=dev)
+            c_ws.kept_rec, c_ws.span_cnt, c_ws.kept_rec_positions = self._kept_rec.data_ptr(), self._span_cnt.data_ptr(), self._kept_rec.numel() // 2
         if self.n_bins:
             b = self._bin_buffers()
             c_ws.n_bins, c_ws.bin_cap = self.n_bins, b["cap"]

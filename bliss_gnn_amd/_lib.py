@@ -44,7 +44,8 @@ class LayerWs(C.Structure):
                 ("kept_nid", C.c_void_p), ("node_prob", C.c_void_p), ("hist", C.c_void_p), ("src_cnt", C.c_void_p), ("cap_c", C.c_int32), ("cap_k", C.c_int32),
                 ("n_bins", C.c_int32), ("bin_cap", C.c_int64), ("bin_cursor", C.c_void_p), ("bin_rec", C.c_void_p),
                 ("bitmap", C.c_void_p), ("word_prefix", C.c_void_p), ("touched_key", C.c_void_p), ("touched_sum", C.c_void_p),
-                ("span_seg", C.c_void_p), ("kept_map", C.c_void_p)]
+                ("span_seg", C.c_void_p), ("kept_rec", C.c_void_p), ("span_cnt", C.c_void_p), ("kept_rec_positions", C.c_int64),
+                ("kept_map", C.c_void_p)]
 
 
 class BlockOut(C.Structure):

@@ -920,7 +920,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      const bf16_t* __restrict__ P, int* deg_blk, unsigned long long* acc_wt,
                                                      int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f,
                                                      const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob,
-                                                     const uint2* __restrict__ seed_coef) {
+                                                     const uint2* __restrict__ seed_coef, KeptRec* __restrict__ kept_rec,
+                                                     int* __restrict__ span_cnt) {
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
@@ -929,6 +930,11 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int n = span_collect(chunk, E, S, seg_ptr, col_base, span_seg, indices, kept_map, local_id, new_id, buf);
+    if (kept_rec) {                                     // leave the compacted list for pass 2: it will not walk the frontier again
+      const int span = chunk * ITEMS + (threadIdx.x >> 6);
+      if (lane_id() == 0) span_cnt[span] = n;
+      for (int j = lane_id(); j < n; j += 64) kept_rec[(size_t)span * SPAN + j] = buf[j];
+    }
     for (int j0 = 0; j0 < n; j0 += 64) {                // ~B/E of the span's 256 edges: usually one trip
       const int j = j0 + lane_id();
       int key = -1;
@@ -1015,7 +1021,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      int* __restrict__ out_eid, bf16_t* __restrict__ out_w,
                                                      bf16_t* __restrict__ out_q, int* src_cursor, int* __restrict__ t_unsorted,
                                                      float eta_f, float ome_f, int cap_b, const int* __restrict__ kept_map,
-                                                     const bf16_t* __restrict__ node_prob, const uint2* __restrict__ seed_coef) {
+                                                     const bf16_t* __restrict__ node_prob, const uint2* __restrict__ seed_coef,
+                                                     const KeptRec* __restrict__ kept_rec, const int* __restrict__ span_cnt) {
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
@@ -1023,13 +1030,19 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
   KeptRec* buf = sh_kept[threadIdx.x >> 6];
   int bad = 0;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int n = span_collect(chunk, E, S, seg_ptr, col_base, span_seg, indices, kept_map, local_id, new_id, buf);
+    const int span = chunk * ITEMS + (threadIdx.x >> 6);
+    int n;
+    const KeptRec* list = buf;
+    if (kept_rec) {                                     // pass 1 left this span's kept edges, compacted and in order
+      n = (span * SPAN < E) ? span_cnt[span] : 0;
+      list = kept_rec + (size_t)span * SPAN;
+    } else n = span_collect(chunk, E, S, seg_ptr, col_base, span_seg, indices, kept_map, local_id, new_id, buf);
     int tot;
     const int run = chunk_off[chunk] + chunk_wave_offset(n, sh4, &tot);
     for (int j = lane_id(); j < n; j += 64) {
       const int idx = run + j;
       if (idx >= cap_b) break;
-      const KeptRec r = buf[j];
+      const KeptRec r = list[j];
       const int k = r.k;
       bf16_t q;
       if (BANDIT) {
@@ -1267,19 +1280,21 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   const uint2* seed_coef = (ws->n_bins > 0 && mode == BLISS_MODE_BANDIT) ? (const uint2*)(acc_w + 6 * (size_t)cap_s) : nullptr;
   if (frontier_bound < 1) frontier_bound = 1;
   const int gc = grid_for(frontier_bound, CHUNK);
+  // optional spill of pass 1's compacted kept-edge lists (one slot of 256 records per 256 frontier positions)
+  KeptRec* kept_rec = (ws->kept_rec && ws->span_cnt && frontier_bound <= ws->kept_rec_positions) ? (KeptRec*)ws->kept_rec : nullptr;
   int* src_cnt = ws->src_cnt;
   const bool want_t = src_cnt && out->t_indptr && out->t_edge && out->t_scratch;
   if (want_t && cap_s > TSORT_MAX_S) return BLISS_EINVAL;                    // caller falls back to bliss_block_transpose
   int* sc = want_t ? src_cnt : nullptr;
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt));
   else
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt));
   PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<want_t ? 3 : 2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b, src_cnt, out->t_indptr, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt));
   else
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt));
   if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
     const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
     PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map));

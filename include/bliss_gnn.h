@@ -88,6 +88,9 @@ typedef struct {
   uint64_t* touched_key;    /* [cap_c] (first position << 32 | source id) of every non-seed frontier source */
   uint64_t* touched_sum;    /* [cap_c] its exact sum */
   int32_t* span_seg;        /* [frontier_bound / 256 + 2] seed column in which every 256th frontier position lies */
+  void* kept_rec;           /* [kept_rec_positions * 16 bytes] optional: bliss_build_block's first pass leaves its per-span kept-edge */
+  int32_t* span_cnt;        /* [kept_rec_positions / 256 + 4]   lists here so that the second pass need not walk the frontier again; */
+  int64_t kept_rec_positions; /* used when frontier_bound <= kept_rec_positions (a multiple of 1024), else ignored (NULL = never) */
   int32_t* kept_map;        /* [num_nodes] block-local id of a kept node, -1 everywhere on entry and on exit of
                                bliss_build_block; NULL = look kept sources up through local_id + new_id (two gathers) */
 } bliss_layer_ws_t;
