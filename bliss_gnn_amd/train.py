@@ -239,7 +239,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
         self.mfgs = [None, None]
         self.side = torch.cuda.Stream()
-        self._smp_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._fwd_done, self._bwd_done = torch.cuda.Event(), torch.cuda.Event()
         self.losses = None
         self.last_counts2 = None
 
@@ -330,8 +330,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         gc.collect()
         torch.cuda.synchronize()
         # Six graphs, not one: a HIP graph with the sampler and the backward pass as parallel branches is executed with both
-        # branches on one hardware queue (ROCm 7.2), i.e. not overlapped.  Replaying the sampler graphs and the model graphs
-        # from two real streams, ordered by events, gives the overlap.
+        # branches on one hardware queue (ROCm 7.2), i.e. not overlapped.  Replaying the backward graphs from a second real
+        # stream, ordered by events, gives the overlap (see _replay).
         self._load(loader)
         main, side = torch.cuda.current_stream(), self.side
         pool = torch.cuda.graph_pool_handle()
@@ -350,21 +350,22 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._finish_pair()
 
     def _replay(self, first_chain=False):
+        # The critical chain  F -> X -> S -> F ...  stays on ONE stream (no cross-stream hand-off latency on it); only the
+        # backward pass, which has slack, is forked to the second stream and joined before the next forward.
         main, side = torch.cuda.current_stream(), self.side
         eng = self.sampler._engine
-        side.wait_stream(main)
         for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
             eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
+            main.wait_event(self._bwd_done)              # parameters after the previous step's Adam
+            self.g_fwd[cur].replay()                     # F + X
+            self._fwd_done.record(main)
             with torch.cuda.stream(side):
-                self.g_fwd[cur].replay()                 # F + X
-            main.wait_stream(side)                       # the sampler needs the EXP3 weights X just wrote
-            self.g_smp[nxt].replay()                     # S, beside ...
-            self._smp_done[nxt].record(main)             # (the generator's commit below is not something F waits for)
+                side.wait_event(self._fwd_done)
+                self.g_bwd[cur].replay()                 # B, beside ...
+                self._bwd_done.record(side)
+            self.g_smp[nxt].replay()                     # ... S (needs the EXP3 weights X just wrote: same stream)
             eng.static_rng_end(nxt)
-            with torch.cuda.stream(side):
-                self.g_bwd[cur].replay()                 # ... B
-                side.wait_event(self._smp_done[nxt])     # the next forward needs the blocks S built
-        main.wait_stream(side)
+        main.wait_event(self._bwd_done)
 
     def __call__(self, loader):
         """Two steps: trains the batch sampled by the previous call and the next batch of ``loader``; samples two."""
