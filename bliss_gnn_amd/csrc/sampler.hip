@@ -104,27 +104,41 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
     if (gridDim.x > 1) return;
   }
   long long run = 0;
-  for (int base = 0; base < S; base += blockDim.x) {
-    int k = base + threadIdx.x, deg = 0;
-    if (k < S) {
-      int s = seeds[k];
-      if (s < 0 || s >= num_nodes) { bad |= BLISS_ERR_CAP_CAND; }
-      else {
-        deg = (int)(indptr[s + 1] - indptr[s]);
-        local_id[s] = k;
+  constexpr int G = 4;                                  // four 1024-seed rounds have their pointer chases in flight together
+  for (int base0 = 0; base0 < S; base0 += G * (int)blockDim.x) {
+    int degs[G];
+    long long cols[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int k = base0 + i * (int)blockDim.x + threadIdx.x;
+      degs[i] = 0; cols[i] = 0;
+      if (k < S) {
+        const int s = seeds[k];
+        if (s < 0 || s >= num_nodes) { bad |= BLISS_ERR_CAP_CAND; }
+        else {
+          cols[i] = indptr[s];
+          degs[i] = (int)(indptr[s + 1] - cols[i]);
+          local_id[s] = k;
+        }
       }
     }
-    int tot, ex = block_excl_scan(deg, sh, &tot);
-    if (k < S) {
-      const long long start = run + ex;
-      seg_ptr[k] = (int)start;
-      // what every frontier pass needs to find its edges without a search and without chasing seeds -> indptr:
-      col_base[k] = deg > 0 ? (long long)indptr[seeds[k]] - start : 0;            // CSC position = col_base[k] + frontier position
-      if (start + deg <= 0x7fffffffll)
-        for (long long sp = (start + SPAN - 1) / SPAN; sp * SPAN < start + deg; ++sp) span_seg[sp] = k;   // segment of position sp * 256
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int k = base0 + i * (int)blockDim.x + threadIdx.x;
+      if (base0 + i * (int)blockDim.x >= S) break;      // block-uniform
+      const int deg = degs[i];
+      int tot, ex = block_excl_scan(deg, sh, &tot);
+      if (k < S) {
+        const long long start = run + ex;
+        seg_ptr[k] = (int)start;
+        // what every frontier pass needs to find its edges without a search and without chasing seeds -> indptr:
+        col_base[k] = deg > 0 ? cols[i] - start : 0;    // CSC position = col_base[k] + frontier position
+        if (start + deg <= 0x7fffffffll)
+          for (long long sp = (start + SPAN - 1) / SPAN; sp * SPAN < start + deg; ++sp) span_seg[sp] = k;   // segment of position sp * 256
+      }
+      run += tot;
+      if (run > 0x7fffffffll) bad |= BLISS_ERR_CAP_FRONTIER;
     }
-    run += tot;
-    if (run > 0x7fffffffll) bad |= BLISS_ERR_CAP_FRONTIER;
   }
   int any_bad = __syncthreads_or(bad);
   if (threadIdx.x == 0) {
