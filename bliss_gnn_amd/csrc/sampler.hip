@@ -4,12 +4,18 @@
 // Replaces, per layer, the ~40 DGL/ATen launches and >= 8 host syncs of
 //   bandit_sampler.py:101-138 (exp3_probabilities), :47-82 + :381-406 (compute_prob),
 //   :408-425 (select_neighbors), :269-339 (generate_block)      and the ladies_sampler.py twins
-// with 12 sync-free launches that never materialise the frontier: every pass re-reads the
-// seeds' CSC columns (coalesced, 4 B index + 2 B weight per edge) and keeps only per-seed,
-// per-candidate and per-kept-edge state.  Sizes (E, C, K, B) live on the device in LayerCounts.
+// with 15 sync-free launches that never materialise the frontier: the passes re-read the seeds' CSC columns
+// (coalesced, 4 B index + 2 B weight per edge) and keep only per-seed, per-candidate and per-kept-edge state.
+// Sizes (E, C, K, B) live on the device in LayerCounts.
 //
-// Node maps are dense |V|-sized arrays (local_id, first_pos, acc_p2) -- on a 288 GB part a dense
-// map beats a hash table: one L2-resident gather per edge, no probing, reset by touched entry.
+//   k_seg_scan -> [k_col_sums] -> k_bin_scatter -> k_bin_reduce -> k_bitmap_tiles -> k_cand_number     bliss_frontier_prob
+//   k_poisson_scale -> k_select_fused                                                                  bliss_poisson_select
+//   k_block_pass1 -> k_block_scans -> k_block_pass2 -> k_tr_sort_lists (+ map cleanup)                 bliss_build_block
+// (k_frontier_pass1/2/3 + k_cand_finalize: the same candidate stage with memory-side atomics, for graphs whose node
+// slots do not fit the LDS bins.)
+//
+// Node maps are dense |V|-sized arrays (local_id, kept_map; first_pos / acc_p2 for the atomic path) -- on a 288 GB
+// part a dense map beats a hash table: one L2-resident gather per edge, no probing, reset by touched entry.
 //
 // Ordering contract: candidates = seeds in given order, then every other frontier
 // source by FIRST APPEARANCE in the dst-major frontier; kept nodes and block edges keep that
