@@ -71,19 +71,33 @@ def exp3_all_ranks(sampler, mfgs, g):
 
 def exp3_all_ranks_static(sampler, mfgs, g):
     """The same exchange for capacity-padded blocks with the true edge counts on the device: fixed-size messages, no
-    host round trip -- the whole step, collectives included, can be recorded into one HIP graph."""
+    host round trip -- the whole step, collectives included, can be recorded into one HIP graph.
+
+    ONE all-gather per step: every rank packs the positions, factors and true counts of all its blocks into one int32
+    buffer (the update kernel writes the factors straight into it); the exchange is latency-bound (a few MB over xGMI), so
+    one collective instead of two per layer is what counts."""
     world = dist.get_world_size()
-    factors = [torch.empty(int(m.src.numel()), dtype=torch.bfloat16, device=g.device) for m in mfgs]
-    sampler.exp3(mfgs, g, apply=False, factors=factors)
-    for idx, mfg in enumerate(mfgs):
-        cap = int(mfg.src.numel())
-        ibuf = torch.empty(cap + 8, dtype=torch.int32, device=g.device)          # positions + the true count
-        ibuf[:cap] = mfg.pos
-        ibuf[cap:cap + 1] = mfg._counts_dev[4:5]                                  # LayerCounts::B
-        igath = [torch.empty_like(ibuf) for _ in range(world)]
-        fgath = [torch.empty_like(factors[idx]) for _ in range(world)]
-        dist.all_gather(igath, ibuf)
-        dist.all_gather(fgath, factors[idx])
-        for ib, fb in zip(igath, fgath):                                          # rank order on every rank
-            sampler.apply_updates(idx, ib[:cap], fb, g, n_dev=ib[cap:cap + 1])
-        sampler.normalize(idx, g)
+    L = len(mfgs)
+    caps = [int(m.src.numel()) for m in mfgs]
+    offs = [sum(caps[:i]) for i in range(L)]
+    tot = sum(caps)
+    n_fac = (tot + 1) // 2                                   # bf16 factors, two per int32 word
+    n = tot + n_fac + L
+    n_pad = (n + 3) // 4 * 4
+    buf = torch.empty(n_pad, dtype=torch.int32, device=g.device)
+    fac_all = buf[tot:tot + n_fac].view(torch.bfloat16)      # [2 * n_fac] bf16 view of the same storage
+    factors = [fac_all[offs[i]:offs[i] + caps[i]] for i in range(L)]
+    sampler.exp3(mfgs, g, apply=False, factors=factors)      # rewards + factors, nothing applied yet
+    for i, mfg in enumerate(mfgs):
+        buf[offs[i]:offs[i] + caps[i]].copy_(mfg.pos)
+        buf[tot + n_fac + i:tot + n_fac + i + 1].copy_(mfg._counts_dev[4:5])      # LayerCounts::B
+    gath = torch.empty(world * n_pad, dtype=torch.int32, device=g.device)
+    dist.all_gather_into_tensor(gath, buf)
+    for i in range(L):
+        for r in range(world):                               # rank order on every rank: the rows stay bit-identical
+            base = r * n_pad
+            pos_r = gath[base + offs[i]:base + offs[i] + caps[i]]
+            fac_r = gath[base + tot:base + tot + n_fac].view(torch.bfloat16)[offs[i]:offs[i] + caps[i]]
+            cnt_r = gath[base + tot + n_fac + i:base + tot + n_fac + i + 1]
+            sampler.apply_updates(i, pos_r, fac_r, g, n_dev=cnt_r)
+        sampler.normalize(i, g)
