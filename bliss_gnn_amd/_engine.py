@@ -199,6 +199,8 @@ class LayerEngine:
                 bad |= e
             if bad & ~_CAP_ERRS:
                 raise RuntimeError(f"sampler kernel error 0x{bad:x}: {_lib.err_string(bad)}")
+            if bad & 1:
+                raise RuntimeError("frontier longer than the graph has edges (repeated seeds?) or >= 2^31 positions")
             if bad & 2 and not self.n_bins:
                 raise RuntimeError("candidate capacity exceeded / seed id out of range")
             if bad == 0:

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
                                                    unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
                                                    int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
                                                    int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
-                                                   int* __restrict__ span_seg) {
+                                                   int* __restrict__ span_seg, long long frontier_cap) {
   __shared__ int sh[17];
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
@@ -139,11 +139,12 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
         seg_ptr[k] = (int)start;
         // what every frontier pass needs to find its edges without a search and without chasing seeds -> indptr:
         col_base[k] = deg > 0 ? cols[i] - start : 0;    // CSC position = col_base[k] + frontier position
-        if (start + deg <= 0x7fffffffll)
+        // (a frontier longer than the graph has edges means repeated seeds: flagged, nothing is written past the tables)
+        if (start + deg <= frontier_cap)
           for (long long sp = (start + SPAN - 1) / SPAN; sp * SPAN < start + deg; ++sp) span_seg[sp] = k;   // segment of position sp * 256
       }
       run += tot;
-      if (run > 0x7fffffffll) bad |= BLISS_ERR_CAP_FRONTIER;
+      if (run > frontier_cap) bad |= BLISS_ERR_CAP_FRONTIER;
     }
   }
   int any_bad = __syncthreads_or(bad);
@@ -1204,12 +1205,13 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     while ((1 << log2_bins) < ws->n_bins) ++log2_bins;
     slots = (g->num_nodes + ws->n_bins - 1) >> log2_bins;
     if ((1 << log2_bins) != ws->n_bins || ws->n_bins > MAX_BINS || (size_t)slots * 12 > 64 * 1024 || ws->bin_cap <= 0 ||
-        !ws->bin_cursor || !ws->bin_rec || !ws->bitmap || !ws->word_prefix || !ws->touched_key || !ws->touched_sum)
+        g->num_edges > (long long)MAX_TILES * BTILE * 32 || !ws->bin_cursor || !ws->bin_rec || !ws->bitmap || !ws->word_prefix || !ws->touched_key || !ws->touched_sum)
       return BLISS_EINVAL;
   }
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
-                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg));
+                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
+                                                            (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll)));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums

@@ -1137,3 +1137,22 @@ def test_poisson_ladies_static_and_pipelined(cuda):
     assert torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a, b)
+
+
+def test_repeated_seeds_are_rejected_not_overrun(cuda):
+    """Seeds must be unique (dgl's DataLoader hands out unique ids).  A frontier longer than the graph has edges -- only
+    possible with repeated seeds -- is flagged by k_seg_scan before any table sized by |E| is written past its end."""
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(200, 2000, seed=3)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    g.edata["w"] = bg.normalized_edata(g)
+    hub = int(torch.argmax(ip[1:] - ip[:-1]))
+    deg = int(ip[hub + 1] - ip[hub])
+    reps = (2200 // deg) + 2
+    sampler = bg.PoissonBanditLadiesSampler([20, 10], eta=0.1)
+    with pytest.raises(RuntimeError, match="repeated seeds"):
+        sampler.sample_blocks(g, torch.full((reps,), hub, dtype=torch.int32, device=cuda))
+    # and the sampler still works afterwards
+    inp, _, blocks = sampler.sample_blocks(g, torch.arange(8, dtype=torch.int32, device=cuda))
+    assert blocks[-1].num_dst_nodes() == 8
