@@ -48,6 +48,13 @@ class LayerWs(C.Structure):
                 ("kept_map", C.c_void_p)]
 
 
+class Exp3Block(C.Structure):
+    _fields_ = [("w_pos", C.c_void_p), ("row_sum", C.c_void_p), ("scratch", C.c_void_p), ("norm_out", C.c_void_p),
+                ("blk_indptr", C.c_void_p), ("blk_src", C.c_void_p), ("blk_dst", C.c_void_p), ("blk_pos", C.c_void_p),
+                ("q_ij", C.c_void_p), ("node_prob", C.c_void_p), ("embed_norm", C.c_void_p), ("alpha_or_null", C.c_void_p),
+                ("dst_nid", C.c_void_p), ("n_edges_dev", C.c_void_p), ("rewards_out", C.c_void_p), ("edges_bound", C.c_int32)]
+
+
 class BlockOut(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("pos", C.c_void_p),
                 ("eid", C.c_void_p), ("edge_weights", C.c_void_p), ("q_ij", C.c_void_p), ("t_indptr", C.c_void_p),
@@ -76,6 +83,7 @@ SIGNATURES = {
     "bliss_gat_chunk_edges": [],
     "bliss_graph_prepare": [_P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
+    "bliss_exp3_step": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],

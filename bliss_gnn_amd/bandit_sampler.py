@@ -176,6 +176,9 @@ class BanditLadiesSampler(BlockSampler):
         st = _stream()
         edge_w_pos = g.edata_by_position(self.edge_weight)
         cg = self._engine.c_graph
+        fused = apply and factors is None and len(mfgs) <= 8         # all blocks in two launches (bliss_exp3_step)
+        keep = []                                                    # (tensors the launch reads must outlive the loop)
+        recs = (_lib.Exp3Block * len(mfgs))() if fused else None
         for idx, mfg in enumerate(mfgs):
             B = mfg.num_edges()
             alpha = None
@@ -190,6 +193,16 @@ class BanditLadiesSampler(BlockSampler):
             en = mfg.srcdata["embed_norm"]
             if en.dtype != torch.bfloat16:
                 en = en.bfloat16()
+            en = en.contiguous()
+            if fused:
+                keep.append((alpha, en))
+                recs[idx] = _lib.Exp3Block(self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
+                                           self._norms[idx:].data_ptr(), mfg.indptr.data_ptr(), mfg.src.data_ptr(), mfg.dst.data_ptr(),
+                                           mfg.pos.data_ptr(), mfg.edata["q_ij"].data_ptr(), mfg.srcdata[self.node_prob].data_ptr(),
+                                           en.data_ptr(), 0 if alpha is None else alpha.data_ptr(), mfg.dstdata[NID].data_ptr(),
+                                           n_edges_ptr, rewards.data_ptr(), B)
+                mfg.edata["rewards"] = rewards                          # :193
+                continue
             _lib.check(_lib.lib.bliss_exp3_update(
                 C.byref(cg), edge_w_pos.data_ptr(), self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr(),
                 mfg.indptr.data_ptr(), mfg.src.data_ptr(), mfg.dst.data_ptr(), mfg.pos.data_ptr(),
@@ -203,6 +216,9 @@ class BanditLadiesSampler(BlockSampler):
             _lib.check(_lib.lib.bliss_exp3_normalize(self._w_pos[idx].data_ptr(), g.num_edges(),
                                                      self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
                                                      self._norms[idx:].data_ptr(), st), "bliss_exp3_normalize")
+        if fused and len(mfgs):
+            _lib.check(_lib.lib.bliss_exp3_step(C.byref(cg), edge_w_pos.data_ptr(), recs, len(mfgs), self._delta_f,
+                                                self._err.data_ptr(), st), "bliss_exp3_step")
 
     def apply_updates(self, idx, pos, factor, g, n_dev=None):
         """w[pos] *= factor on layer ``idx`` (positions unique within one call), bandit_sampler.py:248.  ``n_dev``: optional

@@ -85,20 +85,21 @@ __device__ __forceinline__ float nan_to_num_posinf0(float x) {   // torch.nan_to
   return x;
 }
 
-// one thread per block edge
-__global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restrict__ g_indptr, const bf16_t* __restrict__ edge_w,
-                                                       bf16_t* w_row, int64_t* row_sum, const int* __restrict__ blk_indptr,
-                                                       const int* __restrict__ blk_src, const int* __restrict__ blk_dst,
-                                                       const int* __restrict__ blk_pos, const bf16_t* __restrict__ q_ij,
-                                                       const bf16_t* __restrict__ node_prob, const bf16_t* __restrict__ embed_norm,
-                                                       const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
-                                                       const int* __restrict__ n_edges_dev, float delta_f,
-                                                       bf16_t* __restrict__ rewards_out, bf16_t* __restrict__ factor_out,
-                                                       int apply, int* err) {
+// one thread per block edge; wg / nwg: this workgroup's index and count among those working on THIS block (a launch may
+// cover several blocks, see k_exp3_update_multi)
+__device__ __forceinline__ void exp3_update_body(const int64_t* __restrict__ g_indptr, const bf16_t* __restrict__ edge_w,
+                                                 bf16_t* w_row, int64_t* row_sum, const int* __restrict__ blk_indptr,
+                                                 const int* __restrict__ blk_src, const int* __restrict__ blk_dst,
+                                                 const int* __restrict__ blk_pos, const bf16_t* __restrict__ q_ij,
+                                                 const bf16_t* __restrict__ node_prob, const bf16_t* __restrict__ embed_norm,
+                                                 const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
+                                                 const int* __restrict__ n_edges_dev, float delta_f,
+                                                 bf16_t* __restrict__ rewards_out, bf16_t* __restrict__ factor_out,
+                                                 int apply, int* err, int wg, int nwg) {
   const int B = *n_edges_dev;
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
-  for (int base = blockIdx.x * E3_TPB + (threadIdx.x & ~63); base < B; base += gridDim.x * E3_TPB) {
+  for (int base = wg * E3_TPB + (threadIdx.x & ~63); base < B; base += nwg * E3_TPB) {
     const int e = base + lane_id();
     if (e < B) {
       const int i = blk_dst[e], j = blk_src[e], pos = blk_pos[e];
@@ -132,6 +133,36 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restric
   }
   flush_digits(dg, row_sum);
   if (bad) atomicOr(err, bad);
+}
+
+__global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restrict__ g_indptr, const bf16_t* __restrict__ edge_w,
+                                                       bf16_t* w_row, int64_t* row_sum, const int* __restrict__ blk_indptr,
+                                                       const int* __restrict__ blk_src, const int* __restrict__ blk_dst,
+                                                       const int* __restrict__ blk_pos, const bf16_t* __restrict__ q_ij,
+                                                       const bf16_t* __restrict__ node_prob, const bf16_t* __restrict__ embed_norm,
+                                                       const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
+                                                       const int* __restrict__ n_edges_dev, float delta_f,
+                                                       bf16_t* __restrict__ rewards_out, bf16_t* __restrict__ factor_out,
+                                                       int apply, int* err) {
+  exp3_update_body(g_indptr, edge_w, w_row, row_sum, blk_indptr, blk_src, blk_dst, blk_pos, q_ij, node_prob, embed_norm, alpha_in,
+                   dst_nid, n_edges_dev, delta_f, rewards_out, factor_out, apply, err, blockIdx.x, gridDim.x);
+}
+
+// all blocks of a step in ONE launch (each launch costs >= 4 us inside a graph; the blocks are independent: every
+// layer has its own weight row)
+struct Exp3Multi {
+  bliss_exp3_block_t blk[BLISS_EXP3_MAX_BLOCKS];
+  int grid_begin[BLISS_EXP3_MAX_BLOCKS + 1];
+  int n;
+};
+__global__ void __launch_bounds__(E3_TPB) k_exp3_update_multi(const int64_t* __restrict__ g_indptr, const bf16_t* __restrict__ edge_w,
+                                                             const Exp3Multi m, float delta_f, int* err) {
+  int b = 0;
+  while (b + 1 < m.n && (int)blockIdx.x >= m.grid_begin[b + 1]) ++b;
+  const bliss_exp3_block_t& k = m.blk[b];
+  exp3_update_body(g_indptr, edge_w, (bf16_t*)k.w_pos, k.row_sum, k.blk_indptr, k.blk_src, k.blk_dst, k.blk_pos, (const bf16_t*)k.q_ij,
+                   (const bf16_t*)k.node_prob, (const bf16_t*)k.embed_norm, (const bf16_t*)k.alpha_or_null, k.dst_nid, k.n_edges_dev,
+                   delta_f, (bf16_t*)k.rewards_out, nullptr, 1, err, (int)blockIdx.x - m.grid_begin[b], m.grid_begin[b + 1] - m.grid_begin[b]);
 }
 
 __global__ void __launch_bounds__(E3_TPB) k_exp3_apply(bf16_t* w_row, int64_t* row_sum, const int* __restrict__ pos,
@@ -173,13 +204,13 @@ __global__ void k_zero_i64(int64_t* p, int n) { if ((int)threadIdx.x < n) p[thre
 // skip << 16 | err << 20 (for the host), [1] ticket, [2 ..] replicas of the renormalised row's exact sum.  Every workgroup
 // derives the norm from the (read-only) exact row sum; if it is 1.0 nothing is touched.  Otherwise the last workgroup to
 // finish installs the new exact sum -- the others have all read row_sum long before (they read it first thing).
-__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
+__device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out, int wg, int nwg) {
   __shared__ int sh_norm, sh_last;
   if (threadIdx.x == 0) {
     int bad = 0;
     const bf16_t nb = limbs_to_bf16(row_sum, &bad);
     sh_norm = (int)nb | (bad << 20);
-    if (blockIdx.x == 0) {
+    if (wg == 0) {
       scratch[0] = (int64_t)nb | ((int64_t)(nb == 0x3f80) << 16) | ((int64_t)bad << 20);
       if (norm_out) *norm_out = nb;
     }
@@ -190,7 +221,7 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
   const float denom = rbf(fmaxf(bf2f(nb), 1e-12f));  // F.normalize: norm.clamp_min(eps)
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
-  for (int64_t i = (int64_t)blockIdx.x * E3_TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * E3_TPB) {
+  for (int64_t i = (int64_t)wg * E3_TPB + threadIdx.x; i < n; i += (int64_t)nwg * E3_TPB) {
     bf16_t v = f2bf(bf2f(w[i]) / denom);           // :249 input / denom
     w[i] = v;
     int64_t a[3];
@@ -204,7 +235,7 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
   // hand-off needs.  (__threadfence() here cost a full L2 write-back per workgroup: 470 us per pass on a 15 M-edge row.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) sh_last = (atomicAdd((unsigned long long*)(scratch + 1), 1ull) == (unsigned long long)gridDim.x - 1);
+  if (threadIdx.x == 0) sh_last = (atomicAdd((unsigned long long*)(scratch + 1), 1ull) == (unsigned long long)nwg - 1);
   __syncthreads();
   if (sh_last) {
     for (int k = threadIdx.x; k < 3 * ROWSUM_SLOTS; k += E3_TPB) {
@@ -213,6 +244,16 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
     }
     if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(scratch + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
+  normalize_row_body(w, n, row_sum, scratch, norm_out, blockIdx.x, gridDim.x);
+}
+// the rows of all layers in one launch: gridDim.x / n_rows workgroups per row
+__global__ void __launch_bounds__(E3_TPB) k_normalize_rows(const Exp3Multi m, int64_t n, int per_row) {
+  const int r = blockIdx.x / per_row;
+  const bliss_exp3_block_t& k = m.blk[r];
+  normalize_row_body((bf16_t*)k.w_pos, n, k.row_sum, k.scratch, (bf16_t*)k.norm_out, (int)blockIdx.x - r * per_row, per_row);
 }
 
 // w_pos[p] = bf16(1 / bf16(indeg(dst(p))))          bandit_sampler.py:20-27
@@ -248,6 +289,35 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
                                                           blk_src, blk_dst, blk_pos, (const bf16_t*)q_ij, (const bf16_t*)node_prob,
                                                           (const bf16_t*)embed_norm, (const bf16_t*)alpha_or_null, dst_nid,
                                                           n_edges_dev, delta_f, (bf16_t*)rewards_out, (bf16_t*)factor_out, apply, err));
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                    float delta_f, int32_t* err, void* stream) {
+  if (!g || !blocks || n_blocks <= 0 || n_blocks > BLISS_EXP3_MAX_BLOCKS || !err) return BLISS_EINVAL;
+  Exp3Multi m;
+  m.n = n_blocks;
+  int total = 0;
+  for (int i = 0; i < n_blocks; ++i) {
+    const bliss_exp3_block_t& k = blocks[i];
+    if (!k.w_pos || !k.row_sum || !k.scratch || !k.blk_indptr || !k.blk_src || !k.blk_dst || !k.blk_pos || !k.q_ij || !k.node_prob ||
+        !k.embed_norm || !k.dst_nid || !k.n_edges_dev || (!edge_w_pos && !k.alpha_or_null) || k.edges_bound < 0)
+      return BLISS_EINVAL;
+    m.blk[i] = k;
+    m.grid_begin[i] = total;
+    int gb = (k.edges_bound + E3_TPB - 1) / E3_TPB;
+    if (gb < 1) gb = 1;
+    if (gb > 2048) gb = 2048;
+    total += gb;
+  }
+  m.grid_begin[n_blocks] = total;
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_EXP3_UPDATE, st, k_exp3_update_multi<<<total, E3_TPB, 0, st>>>(g->indptr, (const bf16_t*)edge_w_pos, m, delta_f, err));
+  int64_t per_row = (g->num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
+  const int64_t cap = 1024 / n_blocks > 0 ? 1024 / n_blocks : 1;      // usually every workgroup returns at once (norm == 1.0)
+  if (per_row > cap) per_row = cap;
+  if (per_row < 1) per_row = 1;
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows<<<(int)(per_row * n_blocks), E3_TPB, 0, st>>>(m, g->num_edges, (int)per_row));
   return (int)hipGetLastError();
 }
 

@@ -227,6 +227,21 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
                       int32_t edges_bound, float delta_f, void* rewards_out, void* factor_out, int apply,
                       int32_t* err, void* stream);
 
+/* sampler.exp3(mfgs, g) (bandit_sampler.py:251-267) for ALL blocks of a step in two launches: one bliss_exp3_update
+ * (apply = 1) over every block and one bliss_exp3_normalize over every layer's row.  Fields as the arguments of those
+ * two calls; every block has its own w_pos row, row_sum and scratch. */
+#define BLISS_EXP3_MAX_BLOCKS 8
+typedef struct {
+  void* w_pos; int64_t* row_sum; int64_t* scratch; void* norm_out;
+  const int32_t *blk_indptr, *blk_src, *blk_dst, *blk_pos;
+  const void *q_ij, *node_prob, *embed_norm, *alpha_or_null;
+  const int32_t* dst_nid; const int32_t* n_edges_dev;
+  void* rewards_out;
+  int32_t edges_bound;
+} bliss_exp3_block_t;
+int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                    float delta_f, int32_t* err, void* stream);
+
 /* The scatter half of update_exp3_weights (bandit_sampler.py:248) for factors computed elsewhere -- used
  * when several ranks keep replicas of the bandit state: w_pos[pos[e]] *= factor[e] for e < *n_dev, and
  * row_sum follows.  pos must be unique within one call; calls apply in stream order. */
