@@ -80,6 +80,8 @@ SIGNATURES = {
     "bliss_spmm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, C.c_int, _P, _I64, C.c_int, _P, _P],
     "bliss_block_transpose": [_P, _P, _I32, _I32, _I32, _P, _P, _P, _I64, _P],
     "bliss_spmm_chunk_edges": [_I32],
+    "bliss_sage_epilogue_fwd": [_P, _I64, _P, _I64, _I32, _I32, _F, C.c_uint32, _P, _P, _I64, _P, _P],
+    "bliss_sage_epilogue_bwd": [_P, _I64, _P, _I64, _I32, _I32, _F, _P, _I64, _P],
     "bliss_gat_chunk_edges": [],
     "bliss_graph_prepare": [_P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],

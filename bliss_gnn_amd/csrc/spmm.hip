@@ -200,6 +200,97 @@ __global__ void __launch_bounds__(SP_TPB) k_embed_norm(const bf16_t* __restrict_
   if (lane == 0) out[row] = f2bf(sqrtf(s));
 }
 
+// ---- SAGE hidden-layer epilogue in one pass ----------------------------------------------------------------------
+// model.py:321-333 + :318-320 of the next layer:   rst = fc_self(h_dst) + h_neigh;  h = dropout(relu(rst));  ||h_j||
+// The reference runs four element-wise kernels for this; here one wave walks a row once: bf16 add (fp32, one rounding),
+// ReLU, dropout (keep with probability 1-p, scale 1/(1-p), one rounding) and the fp32 sum of squares of what it stores
+// (the same accumulation order as k_embed_norm).  The dropout bits come from a counter-based hash of (seed, launch
+// counter, element index): the same Bernoulli(1-p) law as torch's fused_dropout, a different (device-resident,
+// graph-replayable) random stream.  ctr[0] = launch counter, ctr[1] = ticket: the last workgroup to finish bumps the
+// counter, so every workgroup of a launch has read the same value.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t ctr, uint32_t idx) {
+  uint32_t x = idx * 0x9e3779b1u + seed;
+  x ^= ctr * 0x85ebca77u + 0x165667b1u;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;    // lowbias32 finaliser
+  x += ctr; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+  return x;
+}
+
+template <bool VEC4>
+__global__ void __launch_bounds__(SP_TPB) k_sage_epilogue(const bf16_t* __restrict__ a, int64_t a_stride, const bf16_t* __restrict__ b,
+                                                         int64_t b_stride, int n_rows, int dim, uint32_t drop_thresh, float scale,
+                                                         uint32_t seed, unsigned long long* ctr, bf16_t* __restrict__ out,
+                                                         int64_t out_stride, bf16_t* __restrict__ norm_out) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
+  const uint32_t c = drop_thresh ? (uint32_t)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if (row < n_rows) {
+    const bf16_t *pa = a + row * a_stride, *pb = b + row * b_stride;
+    bf16_t* po = out + row * out_stride;
+    float s = 0.f;
+    constexpr int W = VEC4 ? 4 : 1;
+    for (int col = lane * W; col < dim; col += 64 * W) {
+      float v[W];
+      if (VEC4) {
+        const f4 x = load4(pa + col), y = load4(pb + col);
+        v[0] = x.x + y.x; v[1 % W] = x.y + y.y; v[2 % W] = x.z + y.z; v[3 % W] = x.w + y.w;
+      } else v[0] = bf2f(pa[col]) + bf2f(pb[col]);
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        float t = rbf(v[i]);                                  // the add's bf16 result
+        t = t > 0.f ? t : 0.f;                                // relu
+        if (drop_thresh) {
+          const bool keep = drop_hash(seed, c, (uint32_t)(row * dim + col + i)) >= drop_thresh;
+          t = keep ? rbf(t * scale) : 0.f;
+        }
+        v[i] = t;
+        s += t * t;
+      }
+      if (VEC4) {
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1 % W]) << 16);
+        o.y = (uint32_t)f2bf(v[2 % W]) | ((uint32_t)f2bf(v[3 % W]) << 16);
+        *reinterpret_cast<uint2*>(po + col) = o;
+      } else po[col] = f2bf(v[0]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0 && norm_out) norm_out[row] = f2bf(sqrtf(s));
+  }
+  if (drop_thresh) {                                          // launch counter: bumped once, by the last workgroup
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long t = atomicAdd(ctr + 1, 1ull);
+      if (t == (unsigned long long)gridDim.x - 1) {
+        __hip_atomic_store(ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(ctr, 1ull);
+      }
+    }
+  }
+}
+
+// d(a) = d(b) = dout * scale where the stored output is positive (kept and past the ReLU), else 0
+template <bool VEC4>
+__global__ void __launch_bounds__(SP_TPB) k_sage_epilogue_bwd(const bf16_t* __restrict__ dout, int64_t d_stride, const bf16_t* __restrict__ out,
+                                                             int64_t out_stride, int n_rows, int dim, float scale,
+                                                             bf16_t* __restrict__ din, int64_t din_stride) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * (SP_TPB / 64) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  constexpr int W = VEC4 ? 4 : 1;
+  for (int col = lane * W; col < dim; col += 64 * W) {
+    if (VEC4) {
+      const f4 g = load4(dout + row * d_stride + col), o = load4(out + row * out_stride + col);
+      f4 r;
+      r.x = o.x > 0.f ? g.x * scale : 0.f; r.y = o.y > 0.f ? g.y * scale : 0.f;
+      r.z = o.z > 0.f ? g.z * scale : 0.f; r.w = o.w > 0.f ? g.w * scale : 0.f;
+      store4<false>(din, row * din_stride + col, r);
+    } else {
+      const float g = bf2f(dout[row * d_stride + col]);
+      din[row * din_stride + col] = f2bf(bf2f(out[row * out_stride + col]) > 0.f ? g * scale : 0.f);
+    }
+  }
+}
+
 template <bool BWD>
 int launch_spmm(const int* row_ptr, const int* t_edge, const int* src, const int* dst, const int* blk_indptr, const void* w,
                 const void* h, int64_t h_stride, int n_rows, const int* nnz_dev, int nnz, int dim, int mean, void* out,
@@ -249,6 +340,39 @@ int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t
   if (!t_indptr || !indptr || !gout || !gh || nnz < 0 || (nnz > 0 && (!t_edge || !src || !dst))) return BLISS_EINVAL;
   return launch_spmm<true>(t_indptr, t_edge, src, dst, indptr, w, gout, gout_stride, n_src, nnz_dev, nnz, dim, mean, gh, gh_stride,
                            out_fp32, partials, (hipStream_t)stream);
+}
+
+int bliss_sage_epilogue_fwd(const void* a, int64_t a_stride, const void* b, int64_t b_stride, int32_t n_rows, int32_t dim,
+                            float p_drop, uint32_t seed, uint64_t* ctr, void* out, int64_t out_stride, void* norm_out, void* stream) {
+  if (!a || !b || !out || n_rows < 0 || dim <= 0 || p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !ctr)) return BLISS_EINVAL;
+  if (n_rows == 0) return 0;
+  const bool v4 = dim % 4 == 0 && a_stride % 4 == 0 && b_stride % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)a) % 8 == 0 &&
+                  ((uintptr_t)b) % 8 == 0 && ((uintptr_t)out) % 8 == 0;
+  const uint32_t thresh = p_drop > 0.f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64);
+  if (v4) k_sage_epilogue<true><<<grid, SP_TPB, 0, st>>>((const bf16_t*)a, a_stride, (const bf16_t*)b, b_stride, n_rows, dim, thresh, scale, seed,
+                                                        (unsigned long long*)ctr, (bf16_t*)out, out_stride, (bf16_t*)norm_out);
+  else k_sage_epilogue<false><<<grid, SP_TPB, 0, st>>>((const bf16_t*)a, a_stride, (const bf16_t*)b, b_stride, n_rows, dim, thresh, scale, seed,
+                                                      (unsigned long long*)ctr, (bf16_t*)out, out_stride, (bf16_t*)norm_out);
+  return (int)hipGetLastError();
+}
+
+int bliss_sage_epilogue_bwd(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, int32_t n_rows, int32_t dim,
+                            float p_drop, void* din, int64_t din_stride, void* stream) {
+  if (!dout || !out || !din || n_rows < 0 || dim <= 0 || p_drop < 0.f || p_drop >= 1.f) return BLISS_EINVAL;
+  if (n_rows == 0) return 0;
+  const bool v4 = dim % 4 == 0 && dout_stride % 4 == 0 && out_stride % 4 == 0 && din_stride % 4 == 0 && ((uintptr_t)dout) % 8 == 0 &&
+                  ((uintptr_t)out) % 8 == 0 && ((uintptr_t)din) % 8 == 0;
+  const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64);
+  if (v4) k_sage_epilogue_bwd<true><<<grid, SP_TPB, 0, st>>>((const bf16_t*)dout, dout_stride, (const bf16_t*)out, out_stride, n_rows, dim, scale,
+                                                            (bf16_t*)din, din_stride);
+  else k_sage_epilogue_bwd<false><<<grid, SP_TPB, 0, st>>>((const bf16_t*)dout, dout_stride, (const bf16_t*)out, out_stride, n_rows, dim, scale,
+                                                          (bf16_t*)din, din_stride);
+  return (int)hipGetLastError();
 }
 
 int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_stride, void* out, void* stream) {

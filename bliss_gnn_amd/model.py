@@ -7,7 +7,7 @@ runs the SAGEConv layers with the sampler's edge weights (model.py:321-329).
 import torch
 import torch.nn as nn
 
-from .nn import SAGEConv, embed_norm
+from .nn import SAGEConv, embed_norm, sage_epilogue
 
 
 class SAGE(nn.Module):
@@ -27,11 +27,37 @@ class SAGE(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.activation = activation
 
+    def _fusable(self, h):
+        act = self.activation
+        relu = act in (torch.relu, torch.nn.functional.relu) or isinstance(act, nn.ReLU)
+        return relu and h.is_cuda and h.dtype == torch.bfloat16 and isinstance(self.dropout, nn.Dropout)
+
+    def _dropout_state(self, l, device):
+        """Launch counter of the fused epilogue's dropout stream for layer l (device uint64[2]) and its seed."""
+        if not hasattr(self, "_drop_ctr"):
+            self._drop_ctr = {}
+        key = (l, str(device))
+        if key not in self._drop_ctr:
+            self._drop_ctr[key] = torch.zeros(2, dtype=torch.int64, device=device)
+        return self._drop_ctr[key], (torch.cuda.initial_seed() ^ (0x9E3779B1 * (l + 1))) & 0xFFFFFFFF
+
     def forward(self, blocks, x):
-        h = x
+        h, norm = x, None
         for l, (layer, block) in enumerate(zip(self.layers, blocks)):
-            block.srcdata["embed_norm"] = embed_norm(h)                       # model.py:318-320
-            h = layer(block, h, edge_weight=(block.edata["edge_weights"] if "edge_weights" in block.edata else None))
+            block.srcdata["embed_norm"] = embed_norm(h) if norm is None else norm          # model.py:318-320
+            norm = None
+            ew = block.edata["edge_weights"] if "edge_weights" in block.edata else None
+            if l < len(self.layers) - 1 and self._fusable(h):
+                # rst = fc_self + h_neigh, activation, dropout (:321-333) and the next layer's row norms in ONE kernel
+                parts = layer(block, h, edge_weight=ew, parts=True)
+                if isinstance(parts, tuple):
+                    p = self.dropout.p if self.training else 0.0
+                    ctr, seed = self._dropout_state(l, h.device) if p > 0 else (None, 0)
+                    h, norm = sage_epilogue(parts[0], parts[1], p, ctr, seed)
+                    continue
+                h = parts
+            else:
+                h = layer(block, h, edge_weight=ew)
             if l < len(self.layers) - 1:
                 h = self.activation(h)
                 h = self.dropout(h)

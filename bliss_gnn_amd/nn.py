@@ -79,6 +79,41 @@ def weighted_aggregate(block, h, edge_weight=None, mean=True, out_fp32=False):
     return _WeightedAggregate.apply(h, block, edge_weight, mean, out_fp32)
 
 
+class _SageEpilogue(torch.autograd.Function):
+    """out = dropout_p(relu(a + b)), norm = ||out||_2 per row in one kernel (csrc/spmm.hip: k_sage_epilogue)."""
+
+    @staticmethod
+    def forward(ctx, a, b, p, ctr, seed):
+        a, b = a.contiguous(), b.contiguous()
+        n, d = a.shape
+        out = torch.empty_like(a)
+        norm = torch.empty(n, dtype=torch.bfloat16, device=a.device)
+        _lib.check(_lib.lib.bliss_sage_epilogue_fwd(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), n, d, float(p), int(seed),
+                                                    0 if ctr is None else ctr.data_ptr(), out.data_ptr(), out.stride(0),
+                                                    norm.data_ptr(), _stream()), "bliss_sage_epilogue_fwd")
+        ctx.save_for_backward(out)
+        ctx.p = float(p)
+        ctx.mark_non_differentiable(norm)
+        return out, norm
+
+    @staticmethod
+    def backward(ctx, dout, _dnorm):
+        (out,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        if dout.dtype != torch.bfloat16:
+            dout = dout.bfloat16()
+        din = torch.empty_like(out)
+        _lib.check(_lib.lib.bliss_sage_epilogue_bwd(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), out.shape[0],
+                                                    out.shape[1], ctx.p, din.data_ptr(), din.stride(0), _stream()),
+                   "bliss_sage_epilogue_bwd")
+        return din, din, None, None, None
+
+
+def sage_epilogue(self_out, neigh, p, ctr, seed):
+    """The tail of a hidden SAGE layer (model.py:321-333) and the row norms the next layer stores (:318-320)."""
+    return _SageEpilogue.apply(self_out, neigh, p, ctr, seed)
+
+
 class SAGEConv(nn.Module):
     """dglnn.SAGEConv(in_feats, out_feats, 'mean') as used at model.py:303-308, 321-329."""
 
@@ -99,7 +134,8 @@ class SAGEConv(nn.Module):
         nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
 
-    def forward(self, graph, feat, edge_weight=None):
+    def forward(self, graph, feat, edge_weight=None, parts=False):
+        """``parts=True`` returns (fc_self(h_dst), h_neigh) un-added, for a caller that fuses the sum with what follows."""
         feat_src = self.feat_drop(feat)
         feat_dst = feat_src[: graph.num_dst_nodes()]
         lin_before_mp = self._in_src_feats > self._out_feats
@@ -107,6 +143,8 @@ class SAGEConv(nn.Module):
             h_neigh = weighted_aggregate(graph, self.fc_neigh(feat_src), edge_weight, mean=True)
         else:
             h_neigh = self.fc_neigh(weighted_aggregate(graph, feat_src, edge_weight, mean=True))
+        if parts and self.activation is None and self.norm is None:
+            return self.fc_self(feat_dst), h_neigh
         rst = self.fc_self(feat_dst) + h_neigh
         if self.activation is not None:
             rst = self.activation(rst)

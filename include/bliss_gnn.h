@@ -193,6 +193,16 @@ int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t
                    const int32_t* nnz_dev, int32_t nnz, int32_t dim, int mean, void* gh, int64_t gh_stride, int out_fp32,
                    float* partials, void* stream);
 
+/* The element-wise tail of a hidden SAGE layer in one pass (model.py:321-333 and :318-320 of the next layer):
+ * out = dropout_p(relu(a + b)) row by row, norm_out[row] = ||out[row,:]||_2 (bf16, may be NULL).  a, b, out: bf16
+ * [n_rows, dim].  p_drop = 0 (evaluation) makes it deterministic.  ctr: device uint64[2], zero-initialised once: the
+ * dropout stream's launch counter (bumped by every call with p_drop > 0) -- counter-based bits, not torch's generator.
+ * _bwd: din = dout / (1 - p) where out > 0, else 0 (the gradient w.r.t. both a and b). */
+int bliss_sage_epilogue_fwd(const void* a, int64_t a_stride, const void* b, int64_t b_stride, int32_t n_rows, int32_t dim,
+                            float p_drop, uint32_t seed, uint64_t* ctr, void* out, int64_t out_stride, void* norm_out, void* stream);
+int bliss_sage_epilogue_bwd(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, int32_t n_rows, int32_t dim,
+                            float p_drop, void* din, int64_t din_stride, void* stream);
+
 /* The by-source index the backward needs: t_edge [cap_b] = edge indices grouped by source, ascending
  * inside a source; t_indptr [n_src_cap + 1].  The edge count is *nnz_dev if given (arrays padded to
  * cap_b; how static-shape / HIP-graph callers work), else nnz.  temp: bliss_block_transpose_temp_bytes. */

@@ -1156,3 +1156,39 @@ def test_repeated_seeds_are_rejected_not_overrun(cuda):
     # and the sampler still works afterwards
     inp, _, blocks = sampler.sample_blocks(g, torch.arange(8, dtype=torch.int32, device=cuda))
     assert blocks[-1].num_dst_nodes() == 8
+
+
+def test_sage_epilogue_kernel(cuda):
+    """k_sage_epilogue: with p = 0 it is bit-identical to the separate add / relu / row-norm kernels; with p > 0 it drops
+    ~p of the positive entries, scales the rest by 1/(1-p), uses fresh bits every launch, and its backward is the mask."""
+    from bliss_gnn_amd.nn import sage_epilogue, embed_norm
+    gen = torch.Generator().manual_seed(4)
+    a = torch.randn(777, 256, generator=gen).bfloat16().to(cuda)
+    b = torch.randn(777, 256, generator=gen).bfloat16().to(cuda)
+    out, norm = sage_epilogue(a, b, 0.0, None, 0)
+    ref = torch.relu(a + b)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(norm.view(torch.int16), embed_norm(ref).view(torch.int16))
+    a2 = a[:, :41].contiguous(); b2 = b[:, :41].contiguous()                  # scalar path (dim % 4 != 0)
+    out2, norm2 = sage_epilogue(a2, b2, 0.0, None, 0)
+    assert torch.equal(out2.view(torch.int16), torch.relu(a2 + b2).view(torch.int16))
+    assert torch.equal(norm2.view(torch.int16), embed_norm(torch.relu(a2 + b2)).view(torch.int16))
+    # dropout
+    ctr = torch.zeros(2, dtype=torch.int64, device=cuda)
+    p = 0.25
+    ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    o1, n1 = sage_epilogue(ar, br, p, ctr, 123)
+    o2, _ = sage_epilogue(a, b, p, ctr, 123)
+    assert int(ctr[0]) == 2 and int(ctr[1]) == 0
+    pos = ref > 0
+    kept1 = (o1 > 0) & pos
+    frac = kept1.sum().item() / pos.sum().item()
+    assert abs(frac - (1 - p)) < 0.01
+    assert not torch.equal(o1, o2)                                           # a new mask every launch
+    scaled = (ref.float() / (1 - p)).bfloat16()
+    assert torch.equal(o1[kept1].view(torch.int16), scaled[kept1].view(torch.int16)) and bool((o1[~kept1] == 0).all())
+    assert torch.equal(n1.view(torch.int16), embed_norm(o1.detach()).view(torch.int16))
+    g = torch.randn(777, 256, generator=gen).bfloat16().to(cuda)
+    o1.backward(g)
+    want = torch.where(o1 > 0, (g.float() / (1 - p)).bfloat16(), torch.zeros_like(g))
+    assert torch.equal(ar.grad.view(torch.int16), want.view(torch.int16)) and torch.equal(br.grad, ar.grad)
