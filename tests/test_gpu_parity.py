@@ -1192,3 +1192,77 @@ def test_sage_epilogue_kernel(cuda):
     o1.backward(g)
     want = torch.where(o1 > 0, (g.float() / (1 - p)).bfloat16(), torch.zeros_like(g))
     assert torch.equal(ar.grad.view(torch.int16), want.view(torch.int16)) and torch.equal(br.grad, ar.grad)
+
+
+def test_full_size_properties_reddit_like(cuda, monkeypatch):
+    """BASELINE config 3 at full size (|V| = 232,965, |E| ~ 114 M, batch 256, fanouts 4096/2048/1024), where the oracle is
+    too slow: size-independent properties of two consecutive steps --
+      * the two independent candidate pipelines (LDS bins vs memory-side atomics) give identical blocks and weights,
+      * every block is a CSR by destination in frontier order whose edges exist in the graph (pos -> indices, column of
+        the seed), with sources numbered consistently (seeds first) and P = 1 for seeds,
+      * the incrementally maintained exact row sums equal a from-scratch exact sum of the weight rows after the update,
+      * torch's CPU generator advanced by exactly sum(C) draws."""
+    from bliss_gnn_amd import _lib
+    from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc
+    bg = _bg()
+    cfg = CONFIGS["reddit"]
+    ip, ix, ei = chung_lu_csc(cfg["num_nodes"], cfg["num_edges"], seed=0, device=cuda)
+    gen = torch.Generator().manual_seed(1)
+    batches = [torch.randperm(cfg["num_nodes"], generator=gen)[:cfg["batch"]].to(torch.int32).to(cuda) for _ in range(2)]
+    results = []
+    for bins in ("1", "0"):
+        monkeypatch.setenv("BLISS_BINS", bins)
+        g = bg.Graph(ip, ix, ei)
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler(cfg["fanouts"], eta=0.1)
+        torch.manual_seed(77)
+        steps = []
+        for seeds in batches:
+            before = torch.get_rng_state()
+            inp, _, blocks = sampler.sample_blocks(g, seeds)
+            drawn = sum(b._counts.C for b in blocks)
+            torch.set_rng_state(before); torch.rand(drawn)                     # the same number of 32-bit draws on the host
+            expect_state = torch.get_rng_state()
+            torch.set_rng_state(before)
+            inp2, _, blocks = sampler.sample_blocks(g, seeds)                    # (re-run: the sampler has no hidden state besides the weights)
+            assert torch.equal(inp, inp2) and torch.equal(torch.get_rng_state(), expect_state)
+            gen2 = torch.Generator().manual_seed(5)
+            for b in blocks:
+                b.srcdata["embed_norm"] = (torch.rand(b.num_src_nodes(), generator=gen2) * 30).bfloat16().to(cuda)
+            sampler.exp3(blocks, g)
+            sampler.check_errors()
+            steps.append(blocks)
+        results.append((steps, sampler))
+        if bins == "1":
+            assert sampler._engine.n_bins > 0
+            for blocks in steps:
+                seeds_l = None
+                for b in reversed(blocks):                                       # sampling order: output-most block first
+                    S, K, B = b.num_dst_nodes(), b.num_src_nodes(), b.num_edges()
+                    nid = b.srcdata[bg.NID].long()
+                    assert B == int(b.indptr[-1]) and bool((b.indptr[1:] >= b.indptr[:-1]).all())
+                    assert bool((b.dst[1:] >= b.dst[:-1]).all()) and int(b.src.max()) < K
+                    assert torch.equal(b.dst.long(), torch.repeat_interleave(torch.arange(S, device=cuda), (b.indptr[1:] - b.indptr[:-1]).long()))
+                    pos = b.pos.long()
+                    assert torch.equal(g.indices[pos].long(), nid[b.src.long()])                    # the edge exists, source id right
+                    col = nid[b.dst.long()]
+                    assert bool(((pos >= g.indptr[col]) & (pos < g.indptr[col + 1])).all())          # in the seed's CSC column
+                    assert bool((pos[1:] > pos[:-1])[b.dst[1:] == b.dst[:-1]].all())                 # frontier order inside a column
+                    assert nid.unique().numel() == K                                                # sources numbered once
+                    if seeds_l is not None:
+                        assert torch.equal(nid[:S], seeds_l)                                        # this layer's seeds = previous kept nodes
+                    assert bool((b.srcdata["node_prob"][:S].view(torch.int16) == 0x3F80).all())     # P = 1 for seeds
+                    seeds_l = nid
+            for l in range(3):                                                   # exact incremental row sum == from-scratch exact sum
+                fresh = torch.zeros(96, dtype=torch.int64, device=cuda)
+                _lib.check(_lib.lib.bliss_row_sum(sampler._w_pos[l].data_ptr(), g.num_edges(), fresh.data_ptr(), 0), "row_sum")
+                tot = lambda r: sum(int(r[3 * s]) + (int(r[3 * s + 1]) << 32) + (int(r[3 * s + 2]) << 64) for s in range(32))
+                assert tot(sampler._row_sum[l].cpu()) == tot(fresh.cpu())
+    (sa, sam_a), (sb, sam_b) = results
+    for blocks_a, blocks_b in zip(sa, sb):
+        for a, b in zip(blocks_a, blocks_b):
+            assert (a._counts.E, a._counts.C, a._counts.K, a._counts.B, a._counts.c) == (b._counts.E, b._counts.C, b._counts.K, b._counts.B, b._counts.c)
+            assert torch.equal(a.src, b.src) and torch.equal(a.pos, b.pos)
+            assert torch.equal(a.edata["edge_weights"].view(torch.int16), b.edata["edge_weights"].view(torch.int16))
+            assert torch.equal(a.edata["rewards"].view(torch.int16), b.edata["rewards"].view(torch.int16))
+    assert torch.equal(sam_a._w_pos.view(torch.int16), sam_b._w_pos.view(torch.int16))
