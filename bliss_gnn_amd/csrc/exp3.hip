@@ -221,12 +221,31 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
   const float denom = rbf(fmaxf(bf2f(nb), 1e-12f));  // F.normalize: norm.clamp_min(eps)
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
-  for (int64_t i = (int64_t)wg * E3_TPB + threadIdx.x; i < n; i += (int64_t)nwg * E3_TPB) {
-    bf16_t v = f2bf(bf2f(w[i]) / denom);           // :249 input / denom
-    w[i] = v;
+  auto one = [&](bf16_t x) {
+    const bf16_t v = f2bf(bf2f(x) / denom);        // :249 input / denom
     int64_t a[3];
     row_digits(v, a, &bad);
     dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
+    return v;
+  };
+  // When the pass does run it is a pure stream over the row (2 x 2 bytes per edge, 0.46 GB on the Reddit-like graph):
+  // 16-byte accesses, several in flight per thread; a scalar head / tail brings the row to 16-byte alignment.
+  const int64_t head = min(n, (int64_t)(((16 - ((uintptr_t)w & 15)) & 15) >> 1));
+  const int64_t nvec = (n - head) / 8;
+  const int64_t gtid = (int64_t)wg * E3_TPB + threadIdx.x, gsz = (int64_t)nwg * E3_TPB;
+  if (gtid < head) w[gtid] = one(w[gtid]);
+  for (int64_t i = head + nvec * 8 + gtid; i < n; i += gsz) w[i] = one(w[i]);
+  uint4* wv = reinterpret_cast<uint4*>(w + head);
+#pragma unroll 4
+  for (int64_t i = gtid; i < nvec; i += gsz) {
+    uint4 x = wv[i];
+    uint32_t* q = reinterpret_cast<uint32_t*>(&x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bf16_t lo = one((bf16_t)(q[k] & 0xffffu)), hi = one((bf16_t)(q[k] >> 16));
+      q[k] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+    wv[i] = x;
   }
   flush_digits(dg, scratch + 2);
   if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
@@ -314,8 +333,9 @@ int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_
   hipStream_t st = (hipStream_t)stream;
   PROF_LAUNCH(BK_EXP3_UPDATE, st, k_exp3_update_multi<<<total, E3_TPB, 0, st>>>(g->indptr, (const bf16_t*)edge_w_pos, m, delta_f, err));
   int64_t per_row = (g->num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
-  const int64_t cap = 1024 / n_blocks > 0 ? 1024 / n_blocks : 1;      // usually every workgroup returns at once (norm == 1.0)
-  if (per_row > cap) per_row = cap;
+  // usually every workgroup returns at once (norm == 1.0), but a row that does need the pass streams 4 bytes per edge and
+  // wants the whole chip: 1024 workgroups per row
+  if (per_row > 1024) per_row = 1024;
   if (per_row < 1) per_row = 1;
   PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows<<<(int)(per_row * n_blocks), E3_TPB, 0, st>>>(m, g->num_edges, (int)per_row));
   return (int)hipGetLastError();
