@@ -95,6 +95,23 @@ class TrainStep:
         return loss
 
 
+def _enable_gemm_tuning():
+    """Let PyTorch's TunableOp measure the rocBLAS / hipBLASLt solutions of every GEMM shape it meets from now on.  Returns
+    False (and leaves the library defaults in place) if this PyTorch build cannot."""
+    try:
+        tn = torch.cuda.tunable
+        tn.enable(True)
+        tn.tuning_enable(True)
+        tn.set_max_tuning_duration(30)
+        tn.set_max_tuning_iterations(20)
+        tn.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bliss_tunableop_%d.csv" % os.getpid()))
+        return True
+    except Exception as e:                                   # noqa: BLE001 -- tuning is an optimisation, never a requirement
+        import warnings
+        warnings.warn("GEMM tuning unavailable (%r); using the library defaults" % (e,))
+        return False
+
+
 class GraphedTrainStep:
     """The same step as TrainStep, recorded ONCE into a HIP graph and replayed: sampler kernels, feature gather,
     SAGE forward / backward, Adam and the EXP3 update with no host work in between.
@@ -168,13 +185,7 @@ class GraphedTrainStep:
         the warm-up (the shapes are static, so each is tuned once); the tall-skinny weight-gradient GEMMs otherwise get
         a default tile that fills only a fraction of the 256 CUs."""
         eng = self.sampler._engine
-        if tune_gemm:
-            tn = torch.cuda.tunable
-            tn.enable(True)
-            tn.tuning_enable(True)
-            tn.set_max_tuning_duration(30)
-            tn.set_max_tuning_iterations(20)
-            tn.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bliss_tunableop_%d.csv" % os.getpid()))
+        tune_gemm = tune_gemm and _enable_gemm_tuning()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -307,13 +318,7 @@ class PipelinedTrainStep(GraphedTrainStep):
 
     def capture(self, loader, warmup=2, tune_gemm=False):
         eng = self.sampler._engine
-        if tune_gemm:
-            tn = torch.cuda.tunable
-            tn.enable(True)
-            tn.tuning_enable(True)
-            tn.set_max_tuning_duration(30)
-            tn.set_max_tuning_iterations(20)
-            tn.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bliss_tunableop_%d.csv" % os.getpid()))
+        tune_gemm = tune_gemm and _enable_gemm_tuning()
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):
