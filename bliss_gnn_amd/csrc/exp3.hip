@@ -221,11 +221,22 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
   const float denom = rbf(fmaxf(bf2f(nb), 1e-12f));  // F.normalize: norm.clamp_min(eps)
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
+  // exact sum of the new values, cheaply: value * 2^64 = m << shift with an 8-bit m; shifts below 32 go to accA (units of
+  // 2^-64), shifts 32..55 to accB (units of 2^-32) -- a thread adds < 2^20 terms of < 2^40 to each, no overflow -- and only
+  // the rare large values take the general three-digit path
+  uint64_t accA = 0, accB = 0;
   auto one = [&](bf16_t x) {
     const bf16_t v = f2bf(bf2f(x) / denom);        // :249 input / denom
-    int64_t a[3];
-    row_digits(v, a, &bad);
-    dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
+    uint32_t e = (v >> 7) & 0xff, m = v & 0x7f;
+    if (e == 0) e = 1; else m |= 0x80;
+    const int shift = (int)e - 70;                 // e - 134 + 64
+    if ((v & 0x8000u) == 0 && e != 255 && shift >= 0 && shift < 56) {
+      if (shift < 32) accA += (uint64_t)m << shift; else accB += (uint64_t)m << (shift - 32);
+    } else {
+      int64_t a[3];
+      row_digits(v, a, &bad);
+      dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
+    }
     return v;
   };
   // When the pass does run it is a pure stream over the row (2 x 2 bytes per edge, 0.46 GB on the Reddit-like graph):
@@ -247,6 +258,8 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
     }
     wv[i] = x;
   }
+  dg[0] += (int64_t)(accA & 0xffffffffull); dg[1] += (int64_t)(accA >> 32);
+  dg[1] += (int64_t)(accB & 0xffffffffull); dg[2] += (int64_t)(accB >> 32);
   flush_digits(dg, scratch + 2);
   if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
   // The last workgroup installs the new exact sum.  Everything it needs from the others went through memory-side
