@@ -10,8 +10,8 @@ Buffers are sized by per-layer capacities; if a capacity is exceeded the kernels
 and the whole call is repeated with larger buffers from the same generator snapshot (steady state:
 never).  PyTorch is used for device memory and the current stream only.
 """
+import contextlib
 import ctypes as C
-
 import os
 
 import numpy as np
@@ -65,15 +65,16 @@ class LayerEngine:
         self.V, self.Eg = V, g.num_edges()
         if self.Eg >= 2 ** 31:
             raise RuntimeError("int32 edge positions: graphs with >= 2^31 edges are not supported")
-        self.local_id = torch.full((V,), -1, dtype=torch.int32, device=dev)
+        # Scratch shared by the layers exists ``scratch_sets`` times, layer n (sampling order) uses set n % scratch_sets: the
+        # block passes of layer n touch none of what the candidate pipeline of layer n + 1 touches, so a caller may run them
+        # beside each other on two streams (train.PipelinedTrainStep does, with one set per layer).
+        self.scratch_sets = 2
+        self._sets = {}
         self.first_pos = torch.full((V,), -1, dtype=torch.int32, device=dev)      # 0xFFFFFFFF
         self.acc_p2 = torch.zeros(V, dtype=torch.int64, device=dev)
-        self.kept_map = torch.full((V,), -1, dtype=torch.int32, device=dev)
-        self.span_seg = torch.zeros(self.Eg // 256 + 2, dtype=torch.int32, device=dev)
-        self._kept_rec = self._span_cnt = None
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
-        self.c_maps = _lib.NodeMaps(self.local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr())
-        self.chunk_cnt = torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(16, dtype=torch.int32, device=dev)              # cross-stream hand-offs (bliss_flag_wait)
+        self.flag_err = torch.zeros(1, dtype=torch.int32, device=dev)
         # binned candidate pipeline (csrc/sampler.hip): LDS-resident per-source reductions when |V| / n_bins slots fit in
         # 64 KiB; otherwise (or with BLISS_BINS=0) the memory-side atomic passes.  Scratch shared by all layers.
         self.n_bins = 0
@@ -94,6 +95,19 @@ class LayerEngine:
         self.ws = None
         self.counts_host = None
         self.retries = 0
+
+    def _set(self, n):
+        """The shared-scratch set of layer n: dense node maps (-1 = clean), span table, chunk counters, spill buffers."""
+        i = n % self.scratch_sets
+        if i not in self._sets:
+            dev, V = self.g.device, self.V
+            local_id = torch.full((V,), -1, dtype=torch.int32, device=dev)
+            self._sets[i] = dict(local_id=local_id, kept_map=torch.full((V,), -1, dtype=torch.int32, device=dev),
+                                 span_seg=torch.zeros(self.Eg // 256 + 2, dtype=torch.int32, device=dev),
+                                 chunk_cnt=torch.empty(max(self.Eg, V) // _CHUNK + 2, dtype=torch.int32, device=dev),
+                                 kept_rec=None, span_cnt=None,
+                                 c_maps=_lib.NodeMaps(local_id.data_ptr(), self.first_pos.data_ptr(), self.acc_p2.data_ptr()))
+        return self._sets[i]
 
     # ------------------------------------------------------------------ capacities
     def _init_caps(self, S0, fanouts_sampling_order):
@@ -238,7 +252,7 @@ class LayerEngine:
                 cur_seeds, n_seeds, n_seeds_dev = state
                 c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts)
                 w_pos = w_rows[n]
-                _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
+                _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self._set(n)["c_maps"]), w_pos.data_ptr(),
                                                         cur_seeds.data_ptr(), n_seeds, n_seeds_dev, self.caps[n]["S"], mode,
                                                         eta_f, ome_f, self.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
                 self.counts_host.copy_(counts, non_blocking=True)
@@ -249,7 +263,7 @@ class LayerEngine:
                 chosen_dev = chosen.to(torch.int32).to(dev)
                 _lib.check(_lib.lib.bliss_multinomial_select(C.byref(c_ws), chosen_dev.data_ptr(), int(chosen_dev.numel()), st),
                            "bliss_multinomial_select")
-                _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
+                _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self._set(n)["c_maps"]), w_pos.data_ptr(),
                                                       cur_seeds.data_ptr(), self.caps[n]["S"], mode, eta_f, ome_f, self.Eg,
                                                       C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
                 layers.append(lay)
@@ -303,18 +317,20 @@ class LayerEngine:
         b_q = hbuf[_up8(cb):_up8(cb) + cb]
         node_prob = hbuf[2 * _up8(cb):2 * _up8(cb) + ck]
         cnt_ptr = counts.data_ptr() + 40 * n
-        c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), self.chunk_cnt.data_ptr(),
+        sset = self._set(n)                       # which set of shared scratch this layer uses
+        c_ws = _lib.LayerWs(cnt_ptr, ws.seg_ptr.data_ptr(), ws.seed_acc.data_ptr(), sset["chunk_cnt"].data_ptr(),
                             ws.cand_nid.data_ptr(), ws.p.data_ptr(), ws.P.data_ptr(), ws.new_id.data_ptr(),
                             kept_nid.data_ptr(), node_prob.data_ptr(), self.hist.data_ptr(),
                             ws.src_cnt.data_ptr() if build_t else 0, cap["C"], ck)
-        c_ws.kept_map, c_ws.span_seg = self.kept_map.data_ptr(), self.span_seg.data_ptr()
+        c_ws.kept_map, c_ws.span_seg = sset["kept_map"].data_ptr(), sset["span_seg"].data_ptr()
         e_bound = max(c.get("E", self.Eg) for c in self.caps)        # one buffer for all layers (descriptors of earlier layers stay valid)
         if e_bound <= (1 << 24):        # spill buffer for the block passes: 16 B per frontier position, only for bounded frontiers
             pos = -(-e_bound // 1024) * 1024
-            if self._kept_rec is None or self._kept_rec.numel() < pos * 2:
-                self._kept_rec = torch.empty(pos * 2, dtype=torch.int64, device=dev)
-                self._span_cnt = torch.zeros(pos // 256 + 4, dtype=torch.int32, device=dev)
-            c_ws.kept_rec, c_ws.span_cnt, c_ws.kept_rec_positions = self._kept_rec.data_ptr(), self._span_cnt.data_ptr(), self._kept_rec.numel() // 2
+            if sset["kept_rec"] is None or sset["kept_rec"].numel() < pos * 2:
+                sset["kept_rec"] = torch.empty(pos * 2, dtype=torch.int64, device=dev)
+                sset["span_cnt"] = torch.zeros(pos // 256 + 4, dtype=torch.int32, device=dev)
+            kr, sc = sset["kept_rec"], sset["span_cnt"]
+            c_ws.kept_rec, c_ws.span_cnt, c_ws.kept_rec_positions = kr.data_ptr(), sc.data_ptr(), kr.numel() // 2
         if self.n_bins:
             b = self._bin_buffers()
             c_ws.n_bins, c_ws.bin_cap = self.n_bins, b["cap"]
@@ -364,15 +380,36 @@ class LayerEngine:
         self.mt_back.copy_(self.mt_dev, non_blocking=True)
         self._slot_counts_host[slot].copy_(self._slot_counts[slot], non_blocking=True)
 
-    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False):
+    def static_rng_chain(self, slot, counts_host):
+        """static_rng_end(slot) + static_rng_begin(chain_rng=True) without touching the current stream: the hand-over runs on
+        the generator's own stream (bliss_rng_stream_chain), ordered after what the current stream holds now (the sampler of
+        ``slot``); the counts records of ``slot`` arrive in ``counts_host`` (a pinned int32 tensor or a view of one).  Call
+        static_rng_ready() before enqueueing the next sampler.  The generator state is not handed back to the host: finish a
+        chain with static_rng_end."""
+        cd = self._slot_counts[slot]
+        assert counts_host.is_pinned() and counts_host.numel() >= cd.numel() and counts_host.dtype == torch.int32
+        _lib.check(_lib.lib.bliss_rng_stream_chain(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_out.data_ptr(),
+                                                   self.rng_raw.data_ptr(), self.rng_cap, cd.data_ptr(), cd.numel(),
+                                                   counts_host.data_ptr(), _stream()), "bliss_rng_stream_chain")
+
+    def static_rng_ready(self):
+        _lib.check(_lib.lib.bliss_rng_stream_ready(_stream()), "bliss_rng_stream_ready")
+
+    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False, part=None):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
         blocks (sampling order); sizes, errors and the generator state are read back by finish().
 
         ``slot``: which persistent set of output buffers to fill.  ``chain_rng``: continue from the generator state the
-        previous enqueue left on the device instead of the host-staged one (several batches sampled per host round trip)."""
+        previous enqueue left on the device instead of the host-staged one (several batches sampled per host round trip).
+        ``part``: None = the whole call.  "main" = everything except the blocks of all but the last-sampled layer, and layer
+        n raises ``flags[n]`` when it starts; "early_blocks" = only those blocks, each behind a bliss_flag_wait on
+        ``flags[n + 1]`` -- to be enqueued on ANOTHER stream, with ``scratch_sets`` >= the number of layers (block n then shares
+        no scratch with any later layer) and external_rng.  The caller orders the next "main" after both parts."""
+        if part is not None and (self.scratch_sets < len(fanouts) or not external_rng):
+            raise ValueError("split enqueue needs one scratch set per layer and an external generator")
         L = len(fanouts)
         out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng,
-                            external_rng=external_rng)
+                            external_rng=external_rng, part=part)
         counts_dev, layers = out
         if slot not in self._slot_counts_host:
             self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
@@ -411,7 +448,8 @@ class LayerEngine:
                                f"({_lib.err_string(bad)}); the step's results are invalid -- raise the margins")
         return cnts
 
-    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False, external_rng=False):
+    def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False, external_rng=False,
+                 part=None):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
         if snapshot is not None and not chain_rng and not external_rng:
@@ -437,28 +475,36 @@ class LayerEngine:
             cs, ws = cap["S"], self.ws[n]
             c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts, slot)
             w_pos = w_rows[n]
-            _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
-                                                    cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
-                                                    cap.get("E", self.Eg), C.byref(c_ws), st), "bliss_frontier_prob")
-            if use_rng:
-                off_ptr = self.rng_ctl.data_ptr() + 4 * (8 + n)
-                _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), self.rng_out.data_ptr(),
-                                                         off_ptr, self.rng_ctl.data_ptr(), int(n == L - 1), self.rng_cap,
-                                                         cap["C"], st), "bliss_poisson_select")
-            else:
-                u = uniforms[n].to(dev, torch.float32).reshape(-1)
-                m = min(u.numel(), cap["C"])
-                ws.uniforms[:m].copy_(u[:m])
-                _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
-                                                         0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
-            _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self.c_maps), w_pos.data_ptr(),
-                                                  cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, cap.get("E", self.Eg), C.byref(c_ws),
-                                                  C.byref(c_out), st), "bliss_build_block")
+            last = n == L - 1
+            if part == "main":                  # layer n raises flag n when it starts (= everything before it has completed)
+                c_ws.entry_flag = self.flags.data_ptr() + 4 * n
+            if part in (None, "main"):          # candidates, probabilities, draw: all the next layer needs (its seeds = kept_nid)
+                _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self._set(n)["c_maps"]), w_pos.data_ptr(),
+                                                        cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
+                                                        cap.get("E", self.Eg), C.byref(c_ws), st), "bliss_frontier_prob")
+                if use_rng:
+                    off_ptr = self.rng_ctl.data_ptr() + 4 * (8 + n)
+                    _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), self.rng_out.data_ptr(),
+                                                             off_ptr, self.rng_ctl.data_ptr(), int(n == L - 1), self.rng_cap,
+                                                             cap["C"], st), "bliss_poisson_select")
+                else:
+                    u = uniforms[n].to(dev, torch.float32).reshape(-1)
+                    m = min(u.numel(), cap["C"])
+                    ws.uniforms[:m].copy_(u[:m])
+                    _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
+                                                             0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
+            # the block of this layer: nothing the next layer's candidate pipeline reads or writes (own scratch set)
+            if part is None or (part == "main" and last) or (part == "early_blocks" and not last):
+                if part == "early_blocks":      # on another stream: wait until layer n + 1 has started, i.e. layer n's draw is done
+                    _lib.check(_lib.lib.bliss_flag_wait(self.flags.data_ptr() + 4 * (n + 1), self.flag_err.data_ptr(), st), "bliss_flag_wait")
+                _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self._set(n)["c_maps"]), w_pos.data_ptr(),
+                                                      cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, cap.get("E", self.Eg), C.byref(c_ws),
+                                                      C.byref(c_out), st), "bliss_build_block")
             layers.append(lay)
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
         if use_rng and not external_rng:      # join; mt_dev = generator state after exactly sum(C) draws
             _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
-                                                     self.rng_cap, counts.data_ptr() + 20, st), "bliss_rng_stream_end")
+                                                     self.rng_cap, counts.data_ptr() + 20, _stream()), "bliss_rng_stream_end")
         return counts, layers
 
     def _finish(self, out, cnts):

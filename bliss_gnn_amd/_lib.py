@@ -21,6 +21,7 @@ ERR_BITS = {
     32: "exact sum left its fixed-point range",
     64: "seed capacity exceeded",
     128: "random stream ran short / generator made no progress",
+    256: "a cross-stream flag never came (bliss_flag_wait timed out)",
 }
 
 
@@ -45,7 +46,7 @@ class LayerWs(C.Structure):
                 ("n_bins", C.c_int32), ("bin_cap", C.c_int64), ("bin_cursor", C.c_void_p), ("bin_rec", C.c_void_p),
                 ("bitmap", C.c_void_p), ("word_prefix", C.c_void_p), ("touched_key", C.c_void_p), ("touched_sum", C.c_void_p),
                 ("span_seg", C.c_void_p), ("kept_rec", C.c_void_p), ("span_cnt", C.c_void_p), ("kept_rec_positions", C.c_int64),
-                ("kept_map", C.c_void_p)]
+                ("kept_map", C.c_void_p), ("entry_flag", C.c_void_p)]
 
 
 class Exp3Block(C.Structure):
@@ -70,6 +71,9 @@ SIGNATURES = {
     "bliss_rng_stream_begin": [_P, _P, _P, _P, _I32, _P],
     "bliss_rng_stream_wait": [_P, _P, _P, C.c_int, _I32, _P],
     "bliss_rng_stream_end": [_P, _P, _P, _I32, _P, _P],
+    "bliss_rng_stream_chain": [_P, _P, _P, _P, _I32, _P, _I32, _P, _P],
+    "bliss_rng_stream_ready": [_P],
+    "bliss_flag_wait": [_P, _P, _P],
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
     "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],

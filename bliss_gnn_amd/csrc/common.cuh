@@ -30,6 +30,7 @@
 #define BLISS_ERR_FIXED_RANGE 32   // an exact sum left its fixed-point range
 #define BLISS_ERR_CAP_SEEDS   64   // more seeds than the per-layer seed capacity
 #define BLISS_ERR_RNG_STREAM 128   // the random stream ran short (capacity) or the generator did not make progress
+#define BLISS_ERR_FLAG_TIMEOUT 256 // bliss_flag_wait gave up: the producer's flag never came
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits
 

@@ -230,11 +230,60 @@ __global__ void __launch_bounds__(256) k_mt19937_commit(uint32_t* state, const i
   if (tid == 0) { state[MT_N] = (uint32_t)(MT_N + 1 - t); state[MT_N + 1] = (uint32_t)t; }
 }
 
+// k_mt19937_commit for the generator that just finished + hand-back of the finished call's counts record + k_rng_ctl_init
+// for the next generator, in ONE launch on the generator's own stream (bliss_rng_stream_chain): a free-running loop keeps
+// all of this off the stream its sampler and model run on.  counts_host is pinned host memory (device-visible).
+__global__ void __launch_bounds__(256) k_mt19937_chain(uint32_t* state, int* ctl, const uint32_t* __restrict__ raw, int cap_total,
+                                                       int* counts_dev, int n_count_words, int* counts_host) {
+  const int tid = threadIdx.x;
+  if (tid == 0 && ctl[3]) atomicOr(counts_dev + 5, BLISS_ERR_RNG_STREAM);     // LayerCounts::err of the first layer
+  int n = ctl[2];
+  if (n > cap_total) n = cap_total;
+  const int left = (int)state[MT_N], next = (int)state[MT_N + 1];
+  int avail = left - 1;
+  if (avail < 0) avail = 0;
+  if (avail > MT_N) avail = MT_N;
+  __syncthreads();                                      // everyone has read the old fields
+  int new_left, new_next;
+  if (n <= avail) {
+    new_left = left - n; new_next = next + n;
+  } else {
+    const int jp = n - avail - 1;                       // last consumed index among the regenerated numbers
+    const int b = 1 + jp / MT_N, t = jp % MT_N + 1;
+    for (int i = tid; i < MT_N; i += 256) state[i] = raw[b * MT_N + i];
+    new_left = MT_N + 1 - t; new_next = t;
+  }
+  for (int i = tid; i < n_count_words; i += 256)
+    counts_host[i] = __hip_atomic_load(counts_dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    state[MT_N] = (uint32_t)new_left; state[MT_N + 1] = (uint32_t)new_next;
+    int a = new_left - 1;
+    if (a < 0) a = 0;
+    if (a > MT_N) a = MT_N;
+    ctl[0] = 0; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = MT_N - a;
+  }
+}
+
+constexpr int N_EV = 48;
 hipStream_t g_side = nullptr;
-hipEvent_t g_ev[16];
+hipEvent_t g_ev[N_EV];
 int g_ev_next = 0;
 bool g_init = false;
 hipEvent_t g_join = nullptr;
+hipEvent_t g_ready = nullptr;     // control block of the generator started last by bliss_rng_stream_chain is initialised
+
+int rng_init() {
+  if (g_init) return 0;
+  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return BLISS_EINVAL;
+  for (int i = 0; i < N_EV; ++i) if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return BLISS_EINVAL;
+  g_init = true;
+  return 0;
+}
+hipEvent_t next_event() {
+  hipEvent_t e = g_ev[g_ev_next];
+  g_ev_next = (g_ev_next + 1) % N_EV;
+  return e;
+}
 
 }  // namespace
 
@@ -250,14 +299,10 @@ int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offs
 int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, void* stream) {
   if (!state || !ctl || !out || !raw || cap_total <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (!g_init) {
-    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return BLISS_EINVAL;
-    for (int i = 0; i < 16; ++i) if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return BLISS_EINVAL;
-    g_init = true;
-  }
-  hipEvent_t fork = g_ev[g_ev_next], jn = g_ev[g_ev_next + 1];
-  g_ev_next = (g_ev_next + 2) % 16;
+  if (rng_init()) return BLISS_EINVAL;
+  hipEvent_t fork = next_event(), jn = next_event();
   hipError_t e;
+  g_ready = nullptr;
   k_rng_ctl_init<<<1, 64, 0, st>>>(ctl, (const uint32_t*)state);
   if ((e = hipEventRecord(fork, st)) != hipSuccess) return (int)e;
   if ((e = hipStreamWaitEvent(g_side, fork, 0)) != hipSuccess) return (int)e;
@@ -265,6 +310,31 @@ int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t
   if ((e = hipEventRecord(jn, g_side)) != hipSuccess) return (int)e;
   g_join = jn;
   return (int)hipGetLastError();
+}
+
+int bliss_rng_stream_chain(void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, int32_t* counts_dev,
+                           int32_t n_count_words, int32_t* counts_host, void* stream) {
+  if (!state || !ctl || !out || !raw || cap_total <= 0 || !counts_dev || !counts_host || n_count_words < 6 || !g_join) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t done = next_event(), ready = next_event(), jn = next_event();
+  hipError_t e;
+  // the generator's stream is in order: the previous generator has finished when the kernel below starts
+  if ((e = hipEventRecord(done, st)) != hipSuccess) return (int)e;                   // the sampler that consumed it has finished
+  if ((e = hipStreamWaitEvent(g_side, done, 0)) != hipSuccess) return (int)e;
+  k_mt19937_chain<<<1, 256, 0, g_side>>>((uint32_t*)state, ctl, raw, cap_total, counts_dev, n_count_words, counts_host);
+  if ((e = hipEventRecord(ready, g_side)) != hipSuccess) return (int)e;
+  g_ready = ready;
+  PROF_LAUNCH(BK_MT19937, g_side, k_mt19937_stream<<<1, 256, 0, g_side>>>((const uint32_t*)state, ctl, out, raw, cap_total));
+  if ((e = hipEventRecord(jn, g_side)) != hipSuccess) return (int)e;
+  g_join = jn;
+  return (int)hipGetLastError();
+}
+
+int bliss_rng_stream_ready(void* stream) {
+  if (!g_ready) return 0;
+  hipError_t e = hipStreamWaitEvent((hipStream_t)stream, g_ready, 0);
+  g_ready = nullptr;
+  return (int)e;
 }
 
 int bliss_rng_stream_wait(int32_t* ctl, const void* counts, int32_t* layer_off, int is_last, int32_t cap_total, void* stream) {

@@ -95,8 +95,11 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
                                                    unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
                                                    int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
                                                    int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
-                                                   int* __restrict__ span_seg, long long frontier_cap) {
+                                                   int* __restrict__ span_seg, long long frontier_cap, int* entry_flag) {
   __shared__ int sh[17];
+  // This kernel runs <=> everything enqueued before this layer has completed (stream / graph order): tell a consumer on
+  // another stream (bliss_flag_wait) without an event, i.e. without cutting a captured graph in two.
+  if (entry_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(entry_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
@@ -1178,9 +1181,28 @@ inline int grid_for(int64_t n, int per_block, int max_blocks = 8192) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// one wave: wait until a producer on another stream has raised *flag (k_seg_scan's entry_flag), then lower it again.
+// Bounded: a flag that never comes (~1 s) sets *err and lets the stream continue, so the grid always drains.
+__global__ void __launch_bounds__(64) k_flag_wait(int* flag, int* err) {
+  if (threadIdx.x != 0) return;
+  long long spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1ll << 22)) { if (err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 extern "C" {
 
 int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
+
+int bliss_flag_wait(int32_t* flag, int32_t* err_word, void* stream) {
+  if (!flag) return BLISS_EINVAL;
+  k_flag_wait<<<1, 64, 0, (hipStream_t)stream>>>(flag, err_word);
+  return (int)hipGetLastError();
+}
 
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,
                         int32_t n_seeds, const int32_t* n_seeds_dev, int32_t cap_s, int mode, float eta_f,
@@ -1211,7 +1233,7 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
                                                             binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
-                                                            (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll)));
+                                                            (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll), ws->entry_flag));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums

@@ -10,6 +10,7 @@ replays, in order, exactly what they do to the sampler and the model each step
     loss = loss_fn(model(mfgs, x), y);  loss.backward();  optimiser.step()     :141-142 + Lightning
     sampler.exp3(mfgs, g)                                                      BatchSizeCallback :469-471
 """
+import contextlib
 import os
 
 import torch
@@ -232,15 +233,26 @@ class GraphedTrainStep:
 
 class PipelinedTrainStep(GraphedTrainStep):
     """Two train steps per call, software-pipelined: while the backward pass and Adam of batch ``a`` run on one stream,
-    the sampler already builds the blocks of batch ``b`` on the other (and vice versa); every piece is a replayed HIP graph.
+    the sampler already builds the blocks of batch ``b`` on another (and vice versa); every piece is a replayed HIP graph.
 
         F(a) X(a) [ S(b) || B(a) ]  F(b) X(b) [ S(a') || B(b) ]          F forward+loss, X exp3 update, B backward+Adam, S sample
 
     The sampler is a long chain of small latency- and atomic-bound kernels that leaves most of the chip idle; the
     dense backward fills that idle capacity.  Nothing is reordered that depends on anything else: S(b) needs the EXP3
-    weights after X(a) (it waits for it) and not the parameters; X reads only what the forward left on the blocks
+    weights after X(a) (it comes after it) and not the parameters; X reads only what the forward left on the blocks
     (embed_norm, q_ij), so running it before B changes no value -- every step computes exactly what the sequential
     loop computes, bit for bit, and torch's CPU generator is consumed in the same order (S(b) then S(a')).
+
+    How the pieces are ordered (``use_flags``, the default): every graph launch costs ~20 us on the stream it is launched
+    on, and an event between two kernels cuts a graph in two.  So the critical chain F X S of one step is ONE graph on the
+    main stream, and the work beside it is handed off through device flags instead of events (bliss_flag_wait): the
+    backward graph (second stream) starts with a wait for the flag the sampler's first kernel raises (= X has finished);
+    the blocks of all but the last-sampled layer are a third graph on a third stream, each behind a wait for the flag the
+    NEXT layer's first kernel raises (= this layer's draw has finished) -- block n shares no scratch with the later layers
+    (one scratch set per layer in the engine), so the critical path loses those block passes.  Inside ONE graph parallel
+    branches would share a hardware queue on ROCm 7.2, hence three graphs on three real streams.  ``capture`` checks that
+    the flags arrive (streams that happen to share a hardware queue would make a waiting kernel block its producer) and
+    otherwise falls back to event ordering: F+X, S and B as separate graphs (BLISS_PIPELINE_FLAGS=0 forces that).
 
     One call = two optimiser steps on two batches; the batch sampled last is trained by the next call (``drain``
     trains the final one)."""
@@ -249,13 +261,16 @@ class PipelinedTrainStep(GraphedTrainStep):
         super().__init__(g, sampler, model, batch_size, lr, multilabel, distributed)
         self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
         self.mfgs = [None, None]
-        self.side = torch.cuda.Stream()
-        self._fwd_done, self._bwd_done = torch.cuda.Event(), torch.cuda.Event()
+        self.side = torch.cuda.Stream()          # backward pass + Adam
+        self.third = torch.cuda.Stream()         # blocks of all but the last-sampled layer (flag mode)
+        self._fwd_done, self._bwd_done, self._blk_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.use_flags = os.environ.get("BLISS_PIPELINE_FLAGS", "1") != "0"
         self.losses = None
         self.last_counts2 = None
 
-    def _sample(self, slot, chain, external_rng=False):
-        return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng)[2]
+    def _sample(self, slot, chain, external_rng=False, part=None):
+        return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng,
+                                                 part=part)[2]
 
     def _forward(self, mfgs):
         pred = self.model(mfgs, mfgs[0].srcdata["features"])
@@ -278,8 +293,9 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.opt.step()
 
     def _pair(self):
-        # The sampler stays on the capture's origin stream (its random-number generator forks from there); the model runs
-        # on the second stream, forward AND backward (autograd replays a node on the stream of its forward).
+        # Eager version (warm-up, kernel-by-kernel timing).  The sampler stays on the origin stream (its random-number
+        # generator forks from there); the model runs on the second stream, forward AND backward (autograd replays a node on
+        # the stream of its forward).
         main, side = torch.cuda.current_stream(), self.side
         side.wait_stream(main)
         losses = []
@@ -303,13 +319,15 @@ class PipelinedTrainStep(GraphedTrainStep):
         torch.cuda.current_stream().synchronize()
         self.sampler.finish_static(0, commit=True)
 
-    def _finish_pair(self):
+    def _finish_pair(self, check_flags=True):
         torch.cuda.current_stream().synchronize()
         c1 = self.sampler.finish_static(1, commit=False)
         c0 = self.sampler.finish_static(0, commit=True)
         self.last_counts2 = [c1, c0]                     # the two batches sampled by this replay, in sampling order
         self.last_counts = c0
         self.num_steps += 2
+        if check_flags and self.graph and self.use_flags and int(self.sampler._engine.flag_err.item()):
+            raise RuntimeError("a cross-stream flag never arrived (bliss_flag_wait timed out): the pipelined results are invalid")
 
     def _load(self, loader):
         self.seeds2[1].copy_(next(loader))               # S(b) runs first, then S(a')
@@ -317,7 +335,10 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.sampler._engine.stage_rng_from_torch()
 
     def capture(self, loader, warmup=2, tune_gemm=False):
-        eng = self.sampler._engine
+        eng = self.sampler._bind(self.g)
+        L = len(self.sampler.nodes_per_layer)
+        if self.use_flags:
+            eng.scratch_sets = max(eng.scratch_sets, L)      # block n then shares no scratch with any later layer
         tune_gemm = tune_gemm and _enable_gemm_tuning()
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
@@ -334,43 +355,99 @@ class PipelinedTrainStep(GraphedTrainStep):
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        # Six graphs, not one: a HIP graph with the sampler and the backward pass as parallel branches is executed with both
-        # branches on one hardware queue (ROCm 7.2), i.e. not overlapped.  Replaying the backward graphs from a second real
-        # stream, ordered by events, gives the overlap (see _replay).
+        self._capture_graphs(loader)
+        if self.use_flags and int(eng.flag_err.item()):
+            import warnings
+            warnings.warn("PipelinedTrainStep: a cross-stream flag timed out (streams sharing a hardware queue?); "
+                          "falling back to event-ordered graphs")
+            eng.flag_err.zero_()
+            eng.flags.zero_()
+            self.use_flags = False
+            self._capture_graphs(loader)
+
+    def _capture_graphs(self, loader):
+        # Several graphs, not one: a HIP graph with the sampler and the backward pass as parallel branches is executed with
+        # both branches on one hardware queue (ROCm 7.2), i.e. not overlapped.  Replaying them from different real streams
+        # gives the overlap (see _half).
+        eng = self.sampler._engine
+        L = len(self.sampler.nodes_per_layer)
         self._load(loader)
-        main, side = torch.cuda.current_stream(), self.side
+        side = self.side
         pool = torch.cuda.graph_pool_handle()
-        self.g_fwd, self.g_bwd, self.g_smp, held = [None, None], [None, None], [None, None], [None, None]
+        self.graph = None
+        self.g_main, self.g_fwd, self.g_bwd, self.g_smp, self.g_blk = ([None, None] for _ in range(5))
+        held = [None, None]
         for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
-            self.g_fwd[cur], self.g_bwd[cur], self.g_smp[nxt] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side):
-                held[cur] = self._forward(self.mfgs[cur])
-            with torch.cuda.graph(self.g_smp[nxt]):       # without its generator: that one is launched ahead of time
-                self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True)
-            with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
-                self._backward(held[cur])
+            # (the sampler is recorded without its generator: that one is launched ahead of time, see _replay / run)
+            self.g_bwd[cur] = torch.cuda.CUDAGraph()
+            if self.use_flags:
+                self.g_main[cur] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_main[cur], pool=pool, stream=side):
+                    held[cur] = self._forward(self.mfgs[cur])                                   # F + X
+                    self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True, part="main")   # S without the early blocks
+                if L > 1:
+                    self.g_blk[nxt] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_blk[nxt]):
+                        self._sample(nxt, chain, external_rng=True, part="early_blocks")
+                with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
+                    # B may start once S has (flag 0 is raised by the sampler's first kernel: F and X have completed)
+                    _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr(), eng.flag_err.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream), "bliss_flag_wait")
+                    self._backward(held[cur])
+            else:
+                self.g_fwd[cur], self.g_smp[nxt] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side):
+                    held[cur] = self._forward(self.mfgs[cur])
+                with torch.cuda.graph(self.g_smp[nxt]):
+                    self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True)
+                with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
+                    self._backward(held[cur])
         self.losses = tuple(h.detach() for h in held)
         self.graph = True
         self._replay()                                   # the captures themselves executed nothing
-        self._finish_pair()
+        self._finish_pair(check_flags=False)             # (capture() looks at the flags itself)
 
-    def _replay(self, first_chain=False):
-        # The critical chain  F -> X -> S -> F ...  stays on ONE stream (no cross-stream hand-off latency on it); only the
-        # backward pass, which has slack, is forked to the second stream and joined before the next forward.
+    def _half(self, cur, nxt, on_side=None):
+        """Enqueue F(cur) X(cur) [ S(nxt) || B(cur) ].  The generator of S(nxt) has been started by the caller.
+        ``on_side``: extra work for the backward pass's stream, after B."""
         main, side = torch.cuda.current_stream(), self.side
-        eng = self.sampler._engine
-        for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
-            eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
-            main.wait_event(self._bwd_done)              # parameters after the previous step's Adam
+        main.wait_event(self._bwd_done)                  # parameters after the previous step's Adam
+        if self.use_flags:
+            main.wait_event(self._blk_done)              # all blocks of the batch about to be trained
+            self.g_main[cur].replay()                    # F + X + S: one graph on the critical stream
+            with torch.cuda.stream(side):
+                self.g_bwd[cur].replay()                 # B: waits for the flag S raises when it starts
+                if on_side is not None:
+                    on_side()
+                self._bwd_done.record(side)
+            if self.g_blk[nxt] is not None:
+                with torch.cuda.stream(self.third):
+                    self.g_blk[nxt].replay()             # early blocks of S: each waits for the flag of the next layer
+                    self._blk_done.record(self.third)
+        else:
             self.g_fwd[cur].replay()                     # F + X
             self._fwd_done.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(self._fwd_done)
                 self.g_bwd[cur].replay()                 # B, beside ...
+                if on_side is not None:
+                    on_side()
                 self._bwd_done.record(side)
             self.g_smp[nxt].replay()                     # ... S (needs the EXP3 weights X just wrote: same stream)
-            eng.static_rng_end(nxt)
+
+    def _join(self):
+        main = torch.cuda.current_stream()
         main.wait_event(self._bwd_done)
+        if self.use_flags:
+            main.wait_event(self._blk_done)
+
+    def _replay(self, first_chain=False):
+        eng = self.sampler._engine
+        for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
+            eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
+            self._half(cur, nxt)
+            eng.static_rng_end(nxt)
+        self._join()
 
     def __call__(self, loader):
         """Two steps: trains the batch sampled by the previous call and the next batch of ``loader``; samples two."""
@@ -402,20 +479,43 @@ class PipelinedTrainStep(GraphedTrainStep):
                 sizes.append([dict(S=c.S, E=c.E, C=c.C, K=c.K, B=c.B) for c in reversed(cs)])
 
         eng.stage_rng_from_torch()
-        for k in range(n_pairs):
-            if len(pending) == ring:
-                collect(pending.pop(0))
-            self.seeds2[1].copy_(next(loader))           # stream order: after the previous pair's samplers have read them
-            self.seeds2[0].copy_(next(loader))
-            self._replay(first_chain=k > 0)
-            r = self._ring[k % ring]
-            r[:L * 10].copy_(eng._slot_counts[1], non_blocking=True)
-            r[L * 10:].copy_(eng._slot_counts[0], non_blocking=True)
-            self._ring_ev[k % ring].record()
-            pending.append(k % ring)
-        for i in pending:
-            collect(i)
+        # Free-running loop: nothing but graph replays and event records goes onto the main stream.  The generator hand-over
+        # between two samplers (state commit, counts to the host, control block of the next generator) is one kernel on the
+        # generator's stream (static_rng_chain); the seed ids of later batches are copied on the backward pass's stream.
+        main = torch.cuda.current_stream()
         if n_pairs:
+            self.seeds2[1].copy_(next(loader))           # S(b) runs first, then S(a')
+            self.seeds2[0].copy_(next(loader))
+        for k in range(n_pairs):
+            while pending and pending[0] <= k - ring:    # this pair reuses that pair's record
+                collect(pending.pop(0) % ring)
+            last = k == n_pairs - 1
+            r = self._ring[k % ring]
+            for cur, nxt in ((0, 1), (1, 0)):
+                if k == 0 and cur == 0:
+                    eng.static_rng_begin(False)          # from the host-staged state
+                elif cur == 0:                           # ends S(a') of the previous pair; its sizes complete that pair's record
+                    eng.static_rng_chain(0, self._ring[(k - 1) % ring][L * 10:])
+                else:
+                    eng.static_rng_chain(1, r[:L * 10])
+                eng.static_rng_ready()
+                if cur == 0 and k > 0:                   # main is now ordered after the hand-over that wrote the record
+                    self._ring_ev[(k - 1) % ring].record(main)
+                    pending.append(k - 1)
+                # the sampler that read slot ``cur``'s seed ids finished before this half's forward pass: load the next batch
+                refill = (cur == 0 and k > 0) or (cur == 1 and not last)
+                self._half(cur, nxt, on_side=(lambda c=cur: self.seeds2[c].copy_(next(loader))) if refill else None)
+            if last:
+                eng.static_rng_end(0)
+                r[L * 10:].copy_(eng._slot_counts[0], non_blocking=True)
+                self._join()
+                self._ring_ev[k % ring].record(main)
+                pending.append(k)
+        for i in pending:
+            collect(i % ring)
+        if n_pairs:
+            # what finish_static(1) reads: the last pair's first sampler handed its sizes to the ring
+            eng._slot_counts_host[1].copy_(self._ring[(n_pairs - 1) % ring][:L * 10])
             self._finish_pair()
         if bad:
             raise RuntimeError(f"static-shape step exceeded its capacities or hit a kernel error 0x{bad:x} "

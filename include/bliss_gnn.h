@@ -93,6 +93,8 @@ typedef struct {
   int64_t kept_rec_positions; /* used when frontier_bound <= kept_rec_positions (a multiple of 1024), else ignored (NULL = never) */
   int32_t* kept_map;        /* [num_nodes] block-local id of a kept node, -1 everywhere on entry and on exit of
                                bliss_build_block; NULL = look kept sources up through local_id + new_id (two gathers) */
+  int32_t* entry_flag;      /* optional: set to 1 by the first kernel of bliss_frontier_prob, i.e. once everything enqueued before
+                               this layer has completed -- the hand-off bliss_flag_wait consumes on another stream */
 } bliss_layer_ws_t;
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
@@ -111,6 +113,13 @@ typedef struct {
 } bliss_block_out_t;
 
 int bliss_layer_counts_bytes(void);
+
+/* Cross-stream ordering without an event (no reference counterpart).  An event between two kernels of one stream cuts a
+ * captured HIP graph in two, and every graph launch costs ~20 us on the stream it is launched on; a flag does not.
+ * Enqueues a one-wave kernel on `stream` that waits until *flag != 0 (raised through bliss_layer_ws_t.entry_flag), then
+ * resets it to 0.  One producer and one consumer per flag and round.  The wait is bounded (~1 s): on a timeout bit 256
+ * is OR-ed into *err_word (optional) and the stream continues. */
+int bliss_flag_wait(int32_t* flag, int32_t* err_word, void* stream);
 
 /* exp3_probabilities + BanditLadiesSampler.compute_prob      bandit_sampler.py:101-138, :47-82
  * LadiesSampler.compute_prob                                 ladies_sampler.py:34-52
@@ -166,6 +175,16 @@ int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t
 int bliss_rng_stream_wait(int32_t* ctl, const void* counts, int32_t* layer_off, int is_last, int32_t cap_total, void* stream);
 int bliss_rng_stream_end(void* state, const int32_t* ctl, const uint32_t* raw, int32_t cap_total, int32_t* err_word,
                          void* stream);
+/* For a loop that samples batch after batch without a host round trip (no reference counterpart: the reference syncs
+ * at every draw): `end` of the generator started last and `begin` of the next one in ONE kernel on the generator's own
+ * stream, ordered after everything enqueued on `stream` so far (the sampler that consumed the numbers).  That kernel also
+ * copies the finished call's counts records (counts_dev, n_count_words int32, LayerCounts::err of the first record
+ * receives bit 128 as in `end`) to counts_host, which must be pinned, device-visible host memory.  Nothing is enqueued on
+ * `stream` except an event record.  `ready`: make `stream` wait until the control block of the generator started by the
+ * last `chain` is initialised -- call it before enqueueing the sampler that consumes that generator. */
+int bliss_rng_stream_chain(void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, int32_t* counts_dev,
+                           int32_t n_count_words, int32_t* counts_host, void* stream);
+int bliss_rng_stream_ready(void* stream);
 
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);

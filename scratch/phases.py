@@ -32,7 +32,7 @@ for it in range(N):
         with torch.cuda.stream(side):
             a = E(); a.record(side); step.g_fwd[cur].replay(); b = E(); b.record(side)
         main.wait_stream(side)
-        c = E(); c.record(main); step.g_smp[nxt].replay(); eng.static_rng_end(nxt); d = E(); d.record(main)
+        c = E(); c.record(main); step._replay_sampler(nxt); eng.static_rng_end(nxt); d = E(); d.record(main)
         with torch.cuda.stream(side):
             e = E(); e.record(side); step.g_bwd[cur].replay(); f = E(); f.record(side); side.wait_stream(main)
         ev[h] = (a, b, c, d, e, f)

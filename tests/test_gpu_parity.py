@@ -916,7 +916,7 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
     labels = torch.randint(0, 5, (8000,), generator=torch.Generator().manual_seed(3))
     fan, bs = [400, 200, 100], 64
     ids = torch.arange(8000, dtype=torch.int32, device=cuda)
-    outs = []
+    outs, seq_sizes = [], []
     for cls in (GraphedTrainStep, PipelinedTrainStep):
         g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
         g.edata["w"] = bg.normalized_edata(g)
@@ -933,6 +933,7 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             for _ in range(8):                                   # 11 trained batches in total
                 step(next(loader))
                 losses.append(float(step.loss))
+                seq_sizes.append(step.sizes())
             sampler.sample_blocks(g, next(loader))               # the pipelined loop has sampled one batch ahead
         else:
             step.capture(loader, warmup=1)                       # prime + 1 warm pair + captured pair = 4 trained, 5 sampled
@@ -940,6 +941,8 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             losses += [float(la), float(lb)]                     # 6 trained, 7 sampled
             sizes = step.run(loader, 2)                          # two more pairs without a host round trip in between
             assert len(sizes) == 4 and all(s[0]["E"] > 0 for s in sizes)
+            # batches 8..11: their sizes came back through the pinned ring (written by the generator hand-over kernel)
+            assert sizes == seq_sizes[-4:]
             losses += [None, None] + [float(x) for x in step.losses]     # 10 trained, 11 sampled
             losses.append(float(step.drain()))                   # 11 trained
             sampler.sample_blocks(g, next(loader))               # keep the two generators aligned: 12 sampled on both sides
