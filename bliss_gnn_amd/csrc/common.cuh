@@ -105,6 +105,20 @@ __device__ __forceinline__ int wave_total_i32(int v) {
   v += dpp_mov0<0x142, 0xa>(v); v += dpp_mov0<0x143, 0xc>(v);
   return __builtin_amdgcn_readlane(v, 63);
 }
+// wave maximum of non-negative values (lanes without a DPP source contribute 0)
+__device__ __forceinline__ int wave_max_u31(int v) {
+  v = max(v, dpp_mov0<0x111, 0xf>(v)); v = max(v, dpp_mov0<0x112, 0xf>(v)); v = max(v, dpp_mov0<0x114, 0xf>(v));
+  v = max(v, dpp_mov0<0x118, 0xf>(v)); v = max(v, dpp_mov0<0x142, 0xa>(v)); v = max(v, dpp_mov0<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// Block-floating exact sums (sum_j w_ij of a seed column, bandit_sampler.py:129): the EXP3 weights of a row span many
+// orders of magnitude once the bandit has concentrated it, so a column's terms are scaled by 2^s, s = 126 - (largest
+// biased exponent in the column), before they are added as Q.FRAC_DST integers: the sum is exact relative to the column's
+// largest term (terms more than ~2^-33 below it truncate), wherever the column sits in bf16's range.  s = 0 for a column
+// holding a weight >= 0.5; the oracle does the same (numerics.exact_segment_sum_rel).
+__device__ __forceinline__ int bf_exp_field(bf16_t b) { const int e = (b >> 7) & 0xff; return e == 0 ? 1 : e; }
+__device__ __forceinline__ int rel_frac(int frac, int emax) { const int s = 126 - emax; return frac + (s > 0 ? s : 0); }
+
 __device__ __forceinline__ long long wave_total_i64(long long v) {
   v += dpp_mov0_i64<0x111, 0xf>(v); v += dpp_mov0_i64<0x112, 0xf>(v); v += dpp_mov0_i64<0x114, 0xf>(v);
   v += dpp_mov0_i64<0x118, 0xf>(v); v += dpp_mov0_i64<0x142, 0xa>(v); v += dpp_mov0_i64<0x143, 0xc>(v);

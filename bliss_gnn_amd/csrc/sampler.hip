@@ -381,6 +381,18 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 #define BINRED_TPB 512
 
 template <int NT>
+__device__ __forceinline__ int block_max_u31(int v, long long* sh) {
+  v = wave_max_u31(v);
+  __syncthreads();                                    // sh free again
+  if (lane_id() == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t = max(t, (int)sh[w]);
+  return t;
+}
+
+template <int NT>
 __device__ __forceinline__ long long block_sum_i64(long long v, long long* sh) {
   v = wave_total_i64(v);
   __syncthreads();                                    // sh free again
@@ -424,14 +436,19 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_R];
     long long part = 0;
+    int emax = 1;
 #pragma unroll
     for (int r = 0; r < COL_R; ++r) {
       const int i = lane + r * 64;
       wr[r] = 0;
-      if (i < n) { wr[r] = w[p0 + i]; part += bf_to_fixed(wr[r], FRAC_DST, &bad); }          // :129 copy_e_sum over exp3 weights
+      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
     }
+    const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r)
+      if (lane + r * 64 < n) part += bf_to_fixed(wr[r], wfrac, &bad);                         // :129 copy_e_sum over exp3 weights
     const long long ws_fixed = wave_total_i64(part);
-    const bf16_t wsum = fixed_to_bf(ws_fixed, FRAC_DST, &bad);
+    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
     const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll
@@ -450,16 +467,23 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_RB];
     long long part = 0;
+    int emax = 1;
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r) {
       const int i = tid + r * COL_TPB;
       wr[r] = 0;
-      if (i < n) { wr[r] = w[p0 + i]; part += bf_to_fixed(wr[r], FRAC_DST, &bad); }
+      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], FRAC_DST, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(w[p0 + i]));
+    const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL_TPB>(emax, sh));
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r)
+      if (tid + r * COL_TPB < n) part += bf_to_fixed(wr[r], wfrac, &bad);
+#pragma unroll 8
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], wfrac, &bad);
     const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
-    const bf16_t wsum = fixed_to_bf(ws_fixed, FRAC_DST, &bad);
+    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
     const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll

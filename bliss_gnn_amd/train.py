@@ -264,6 +264,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.side = torch.cuda.Stream()          # backward pass + Adam
         self.third = torch.cuda.Stream()         # blocks of all but the last-sampled layer (flag mode)
         self._fwd_done, self._bwd_done, self._blk_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self._seed_ev = torch.cuda.Event()
         self.use_flags = os.environ.get("BLISS_PIPELINE_FLAGS", "1") != "0"
         self.losses = None
         self.last_counts2 = None
@@ -503,8 +504,17 @@ class PipelinedTrainStep(GraphedTrainStep):
                     self._ring_ev[(k - 1) % ring].record(main)
                     pending.append(k - 1)
                 # the sampler that read slot ``cur``'s seed ids finished before this half's forward pass: load the next batch
-                refill = (cur == 0 and k > 0) or (cur == 1 and not last)
-                self._half(cur, nxt, on_side=(lambda c=cur: self.seeds2[c].copy_(next(loader))) if refill else None)
+                # there, behind the backward pass.  The loader itself works on the main stream (a new epoch shuffles there).
+                on_side = None
+                if (cur == 0 and k > 0) or (cur == 1 and not last):
+                    batch = next(loader)
+                    self._seed_ev.record(main)
+                    batch.record_stream(self.side)
+
+                    def on_side(c=cur, b=batch):
+                        self.side.wait_event(self._seed_ev)
+                        self.seeds2[c].copy_(b)
+                self._half(cur, nxt, on_side=on_side)
             if last:
                 eng.static_rng_end(0)
                 r[L * 10:].copy_(eng._slot_counts[0], non_blocking=True)

@@ -127,7 +127,7 @@ def exp3_edge_prob(g: CSC, fr: Frontier, w_row: torch.Tensor, eta: float):
     """bandit_sampler.py:127-137.  ``w_row`` = exp3_weights[layer], bf16, by edge id."""
     S = fr.n_seeds
     w_e = w_row[fr.eid]                                           # :127
-    w_sum, _ = nx.exact_segment_sum(w_e, fr.dst_l, S, nx.FRAC_DST)  # :129 copy_e_sum
+    w_sum, _ = nx.exact_segment_sum_rel(w_e, fr.dst_l, S, nx.FRAC_DST)  # :129 copy_e_sum
     w_div = w_e / w_sum[fr.dst_l]                                 # :131 e_div_v
     n_i = (fr.seg_ptr[1:] - fr.seg_ptr[:-1]).to(torch.int32)      # :133 g.in_degrees(seeds)
     a = (eta / n_i).bfloat16()                                    # :137 (self.eta / n_i).bfloat16()

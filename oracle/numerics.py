@@ -45,8 +45,8 @@ def bits_to_bf16(bits: torch.Tensor) -> torch.Tensor:
     return b.view(torch.bfloat16)
 
 
-def bf16_to_fixed(x: torch.Tensor, frac: int) -> torch.Tensor:
-    """Exact (truncating below 2**-frac) bf16 -> signed int64 fixed point.
+def bf16_to_fixed(x: torch.Tensor, frac) -> torch.Tensor:
+    """Exact (truncating below 2**-frac) bf16 -> signed int64 fixed point (``frac``: int, or an int64 tensor per element).
 
     Non-finite inputs are not representable: they raise, and the HIP side sets
     its error flag for them (tests cover both)."""
@@ -67,8 +67,8 @@ def bf16_to_fixed(x: torch.Tensor, frac: int) -> torch.Tensor:
     return torch.where(sign == 1, -mag, mag)
 
 
-def fixed_to_bf16(n: torch.Tensor, frac: int) -> torch.Tensor:
-    """Signed int64 fixed point -> bf16, round-to-nearest-even, exact."""
+def fixed_to_bf16(n: torch.Tensor, frac) -> torch.Tensor:
+    """Signed int64 fixed point -> bf16, round-to-nearest-even, exact (``frac``: int, or an int64 tensor per element)."""
     n = n.to(torch.int64)
     sign = (n < 0).to(torch.int64)
     mag = n.abs()
@@ -107,6 +107,25 @@ def exact_segment_sum(values: torch.Tensor, seg: torch.Tensor, nseg: int, frac: 
     acc = torch.zeros(nseg, dtype=torch.int64)
     acc.index_add_(0, seg.to(torch.int64), fx)
     return fixed_to_bf16(acc, frac), acc
+
+
+def exact_segment_sum_rel(values: torch.Tensor, seg: torch.Tensor, nseg: int, frac: int) -> torch.Tensor:
+    """exact_segment_sum in block-floating form, for sums whose terms may sit anywhere in bf16's range (the EXP3 weights
+    of a seed column, bandit_sampler.py:129, once the bandit has concentrated a row): every segment's terms are scaled
+    by 2**s, s = max(0, 126 - largest biased exponent in the segment), before the exact integer addition, so the sum is
+    exact relative to the segment's largest term.  Identical to exact_segment_sum wherever that one truncates nothing.
+    (csrc/common.cuh: rel_frac; csrc/sampler.hip: k_col_sums.)"""
+    bits = bf16_bits(values)
+    exp = (bits >> 7) & 0xFF
+    exp = torch.where(exp == 0, torch.ones_like(exp), exp)
+    seg = seg.to(torch.int64)
+    emax = torch.ones(nseg, dtype=torch.int64)
+    emax.scatter_reduce_(0, seg, exp, reduce="amax", include_self=True)
+    fr = frac + (126 - emax).clamp(min=0)
+    fx = bf16_to_fixed(values, fr[seg])
+    acc = torch.zeros(nseg, dtype=torch.int64)
+    acc.index_add_(0, seg, fx)
+    return fixed_to_bf16(acc, fr), acc
 
 
 # ----------------------------------------------------------------------------

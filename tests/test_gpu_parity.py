@@ -957,6 +957,56 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
         assert torch.equal(pa, pb)
 
 
+def test_concentrated_weight_rows_match_oracle(cuda):
+    """EXP3 rows after the bandit has concentrated them: weights from ~0.3 down to 1e-30 in the same row, columns whose
+    weights are ALL tiny (their sum is far below 2^-40: the block-floating column sums of k_col_sums), two consecutive
+    steps incl. the update -- bit-exact against the oracle."""
+    from oracle import bliss_oracle as bo
+    bg = _bg()
+    gen = torch.Generator().manual_seed(5)
+    V, E0 = 3000, 40000
+    og = bo.prepare_graph(torch.randint(0, V, (E0,), generator=gen), torch.randint(0, V, (E0,), generator=gen), V)
+    g = bg.Graph(og.indptr.to(cuda), og.indices.to(cuda), og.eid.to(cuda))
+    g.edata["w"] = bg.normalized_edata(g)
+    edge_w = bo.normalized_edata(og)
+    E = og.num_edges
+    rows = []
+    for lo in (-100.0, -60.0):                       # exponents uniform in [lo, -2]: most of the row is far below 2^-40
+        w = torch.exp2(lo + (-2.0 - lo) * torch.rand(E, generator=gen))
+        dst = torch.repeat_interleave(torch.arange(V), og.indptr[1:] - og.indptr[:-1])
+        tiny_col = (torch.rand(V, generator=gen) < 0.3)[dst]                  # whole columns of tiny weights (by position)
+        w_pos = torch.where(tiny_col, w * 2.0 ** -20, w)
+        w_e = torch.empty(E)
+        w_e[og.eid.long()] = w_pos                   # by edge id, like the reference's attribute
+        rows.append(w_e)
+    o_w = torch.stack(rows).bfloat16()
+    fan, eta = [300, 150], 0.1
+    sampler = bg.PoissonBanditLadiesSampler(fan, eta=eta)
+    sampler._bind(g)
+    sampler.exp3_weights = o_w.to(cuda)
+    for step in range(2):
+        seeds = torch.randperm(V, generator=gen)[:48].to(torch.int32)
+        torch.manual_seed(step)
+        inp, _, blocks = sampler.sample_blocks(g, seeds.to(cuda))
+        torch.manual_seed(step)
+        o_inp, _, o_blocks = bo.sample_blocks_bandit(og, seeds, fan, o_w, eta)
+        assert torch.equal(inp.cpu().long(), o_inp)
+        embed = []
+        for b, ob in zip(blocks, o_blocks):
+            assert b._counts.E == ob.trace["E"] and b._counts.c == ob.trace["c"]
+            assert torch.equal(b._trace["p"].cpu().view(torch.int16), ob.trace["p"].view(torch.int16))
+            assert torch.equal(b.src.cpu().long(), ob.src) and torch.equal(b.dst.cpu().long(), ob.dst)
+            for mine, ref in ((b.edata["edge_weights"], ob.edge_weights), (b.edata["q_ij"], ob.q_ij), (b.srcdata["node_prob"], ob.node_prob)):
+                assert torch.equal(mine.cpu().view(torch.int16), ref.view(torch.int16))
+            en = (torch.rand(ob.n_src, generator=gen) * 40).bfloat16()
+            b.srcdata["embed_norm"] = en.to(cuda)
+            embed.append(en)
+        sampler.exp3(blocks, g)
+        sampler.check_errors()
+        o_w, _ = bo.exp3(og, o_blocks, o_w, edge_w, embed)
+        assert torch.equal(sampler.exp3_weights.cpu().view(torch.int16), o_w.view(torch.int16))
+
+
 def test_hub_columns_match_oracle(cuda):
     """Seed columns of 30 000, 5 000 and 1 500 in-edges (k_col_sums' one-workgroup path with and without the register
     cache overflowing, and its one-wave path for the rest; multi-batch scatter; hubs with thousands of appearances as

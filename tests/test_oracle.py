@@ -154,3 +154,24 @@ def test_prepare_graph_toy_and_generator_convention():
     n = ix.numel() - 500                                     # the generator's last V edge ids are its self loops
     g = bo.prepare_graph(src_by_eid[:n], dst_by_eid[:n], 500)
     assert torch.equal(g.indptr, ip) and torch.equal(g.indices, ix) and torch.equal(g.eid, ei)
+
+
+def test_block_floating_segment_sum():
+    """exact_segment_sum_rel: equal to exact_segment_sum where that one truncates nothing; exact (vs Python fractions)
+    for segments whose terms all lie far below 2**-40; zero only for all-zero segments."""
+    from fractions import Fraction
+    from oracle import numerics as nx
+    gen = torch.Generator().manual_seed(0)
+    seg = torch.randint(0, 50, (4000,), generator=gen)
+    big = (torch.rand(4000, generator=gen) * 0.01 + 1e-4).bfloat16()
+    a, _ = nx.exact_segment_sum(big, seg, 50, nx.FRAC_DST)
+    b, _ = nx.exact_segment_sum_rel(big, seg, 50, nx.FRAC_DST)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    tiny = torch.exp2(-90.0 + 12.0 * torch.rand(4000, generator=gen)).bfloat16()
+    r, _ = nx.exact_segment_sum_rel(tiny, seg, 50, nx.FRAC_DST)
+    z, _ = nx.exact_segment_sum(tiny, seg, 50, nx.FRAC_DST)
+    assert bool((z == 0).all()) and bool((r > 0).all())
+    for k in range(50):
+        exact = sum((Fraction(float(v)) for v in tiny[seg == k]), Fraction(0))
+        want = torch.tensor(float(exact), dtype=torch.float64).to(torch.bfloat16)     # one rounding of the exact value
+        assert float(r[k]) == float(want), k
