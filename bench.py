@@ -117,7 +117,9 @@ def main():
             step.calibrate(loader, steps=8)
             step.capture(loader, warmup=2, tune_gemm=args.tune_gemm)
             launch = ("one HIP graph per step" if args.no_pipeline else
-                      "HIP graphs on two streams (sampler | model); sampling of batch t+1 overlaps backward+Adam of batch t")
+                      ("one HIP graph per step on the critical stream (forward + exp3 + sampling of batch t+1); backward+Adam of batch t "
+                       "and the early layers' blocks on two more streams, handed off through device flags") if step.use_flags else
+                      "HIP graphs on two streams ordered by events (sampler | model); sampling of batch t+1 overlaps backward+Adam of batch t")
         except Exception as e:                       # e.g. a runtime that cannot capture collectives: launch kernel by kernel
             if world == 1:
                 raise
@@ -216,8 +218,10 @@ def main():
         per_launch = alg_dom / dom_timing["launches"]
         achieved = per_launch / (dom_timing["avg_us"] * 1e-6) / 1e9
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")     # separate rocprofv3 --pmc passes
-        if os.path.exists(pmc_file):
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # separate rocprofv3 --pmc passes
+        pmc_file = pmc_files[-1] if pmc_files else ""
+        if pmc_file:
             raw = json.load(open(pmc_file))
             # profiler symbol(s) of the timed kernel id: k_spmm_fwd / k_spmm_bwd are the BWD = false / true instantiations of k_spmm<>
             if dominant in ("k_spmm_fwd", "k_spmm_bwd"):
@@ -230,7 +234,7 @@ def main():
                 # launch-weighted mean over the instantiations
                 n = sum(r["launches"] for r in rows)
                 traffic = 1024.0 * sum(r["launches"] * (r["fetch_KiB_x2_corrected"] + r["write_KiB_per_launch"]) for r in rows) / max(n, 1)
-                traffic_src = "profiles/r01_g_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), bytes per launch"
+                traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes), bytes per launch" % os.path.basename(pmc_file)
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / roofline.HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": dom_timing["avg_us"], "launches": dom_timing["launches"],

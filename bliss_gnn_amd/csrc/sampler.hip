@@ -1218,9 +1218,19 @@ __global__ void __launch_bounds__(64) k_flag_wait(int* flag, int* err) {
   __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__global__ void k_flag_raise(int* flag) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 extern "C" {
 
 int bliss_layer_counts_bytes(void) { return (int)sizeof(LayerCounts); }
+
+int bliss_flag_raise(int32_t* flag, void* stream) {
+  if (!flag) return BLISS_EINVAL;
+  k_flag_raise<<<1, 64, 0, (hipStream_t)stream>>>(flag);
+  return (int)hipGetLastError();
+}
 
 int bliss_flag_wait(int32_t* flag, int32_t* err_word, void* stream) {
   if (!flag) return BLISS_EINVAL;

@@ -356,6 +356,11 @@ class PipelinedTrainStep(GraphedTrainStep):
         import gc
         gc.collect()
         torch.cuda.synchronize()
+        if self.use_flags and not self._flags_usable():
+            import warnings
+            warnings.warn("PipelinedTrainStep: streams do not run side by side here (shared hardware queue, or a profiler "
+                          "serialising kernels); ordering the graphs with events instead of device flags")
+            self.use_flags = False
         self._capture_graphs(loader)
         if self.use_flags and int(eng.flag_err.item()):
             import warnings
@@ -365,6 +370,28 @@ class PipelinedTrainStep(GraphedTrainStep):
             eng.flags.zero_()
             self.use_flags = False
             self._capture_graphs(loader)
+
+    def _flags_usable(self):
+        """Probe with harmless kernels: a wait enqueued on the backward / block stream FIRST, the raise on the main stream
+        afterwards.  That only completes without a timeout if the streams really run side by side -- not when two of them
+        share a hardware queue, and not under a profiler that serialises kernels (rocprofv3 --pmc).  A flag that times out
+        in the real loop would let a consumer run before its producer; better to know beforehand."""
+        eng = self.sampler._engine
+        main = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        eng.flag_err.zero_()
+        eng.flags.zero_()
+        torch.cuda.synchronize()
+        for i, st in ((14, self.side), (15, self.third)):
+            _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * i, eng.flag_err.data_ptr(), st.cuda_stream), "bliss_flag_wait")
+        for i in (14, 15):
+            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * i, main.cuda_stream), "bliss_flag_raise")
+        torch.cuda.synchronize()
+        ok = int(eng.flag_err.item()) == 0
+        eng.flag_err.zero_()
+        eng.flags.zero_()
+        torch.cuda.synchronize()
+        return ok
 
     def _capture_graphs(self, loader):
         # Several graphs, not one: a HIP graph with the sampler and the backward pass as parallel branches is executed with

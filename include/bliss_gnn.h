@@ -120,6 +120,11 @@ int bliss_layer_counts_bytes(void);
  * resets it to 0.  One producer and one consumer per flag and round.  The wait is bounded (~1 s): on a timeout bit 256
  * is OR-ed into *err_word (optional) and the stream continues. */
 int bliss_flag_wait(int32_t* flag, int32_t* err_word, void* stream);
+/* Raise *flag from `stream` (a one-thread kernel).  The hot path raises its flags from kernels it runs anyway
+ * (entry_flag); this entry point exists so that a caller can PROBE, with harmless kernels, whether a wait enqueued on one
+ * stream and a raise enqueued later on another really run side by side (they do not when the two streams share a
+ * hardware queue, or under a profiler that serialises kernels) before it relies on flags for ordering. */
+int bliss_flag_raise(int32_t* flag, void* stream);
 
 /* exp3_probabilities + BanditLadiesSampler.compute_prob      bandit_sampler.py:101-138, :47-82
  * LadiesSampler.compute_prob                                 ladies_sampler.py:34-52

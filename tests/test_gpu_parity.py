@@ -916,14 +916,19 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
     labels = torch.randint(0, 5, (8000,), generator=torch.Generator().manual_seed(3))
     fan, bs = [400, 200, 100], 64
     ids = torch.arange(8000, dtype=torch.int32, device=cuda)
+    import os
     outs, seq_sizes = [], []
-    for cls in (GraphedTrainStep, PipelinedTrainStep):
+    # the pipelined loop twice: ordered by device flags (one graph per step on the critical stream), and by events
+    for cls, flags in ((GraphedTrainStep, None), (PipelinedTrainStep, "1"), (PipelinedTrainStep, "0")):
+        if flags is not None:
+            os.environ["BLISS_PIPELINE_FLAGS"] = flags
         g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
         g.edata["w"] = bg.normalized_edata(g)
         sampler = bg.PoissonBanditLadiesSampler(fan, eta=0.1)
         torch.manual_seed(0)
         model = SAGE(64, 32, 5, 3, torch.relu, 0.0).to(cuda).bfloat16()
         step = cls(g, sampler, model, bs)
+        os.environ.pop("BLISS_PIPELINE_FLAGS", None)
         loader = BatchLoader(ids, bs, seed=5).forever()
         torch.manual_seed(9)
         step.calibrate(loader, steps=3)
@@ -937,6 +942,7 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             sampler.sample_blocks(g, next(loader))               # the pipelined loop has sampled one batch ahead
         else:
             step.capture(loader, warmup=1)                       # prime + 1 warm pair + captured pair = 4 trained, 5 sampled
+            assert flags == "1" or not step.use_flags            # ("1" may still fall back if capture()'s probe says so)
             la, lb = step(loader)
             losses += [float(la), float(lb)]                     # 6 trained, 7 sampled
             sizes = step.run(loader, 2)                          # two more pairs without a host round trip in between
@@ -949,12 +955,13 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
         sampler.check_errors()
         outs.append(dict(w=sampler.exp3_weights.cpu().view(torch.int16).clone(), rng=torch.get_rng_state(),
                          params=[p.detach().cpu().clone() for p in model.parameters()], losses=losses))
-    a, b = outs
-    assert torch.equal(a["rng"], b["rng"])
-    assert torch.equal(a["w"], b["w"])
-    assert a["losses"][-3:] == b["losses"][-3:] and a["losses"][-7:-5] == b["losses"][-7:-5]
-    for pa, pb in zip(a["params"], b["params"]):
-        assert torch.equal(pa, pb)
+    a = outs[0]
+    for b in outs[1:]:
+        assert torch.equal(a["rng"], b["rng"])
+        assert torch.equal(a["w"], b["w"])
+        assert a["losses"][-3:] == b["losses"][-3:] and a["losses"][-7:-5] == b["losses"][-7:-5]
+        for pa, pb in zip(a["params"], b["params"]):
+            assert torch.equal(pa, pb)
 
 
 def test_concentrated_weight_rows_match_oracle(cuda):
