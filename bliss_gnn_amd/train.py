@@ -338,6 +338,11 @@ class PipelinedTrainStep(GraphedTrainStep):
     def capture(self, loader, warmup=2, tune_gemm=False):
         eng = self.sampler._bind(self.g)
         L = len(self.sampler.nodes_per_layer)
+        if self.use_flags and not self._flags_usable():       # (before the warm-up: autograd remembers the streams it ran on)
+            import warnings
+            warnings.warn("PipelinedTrainStep: streams do not run side by side here (a profiler serialising kernels?); "
+                          "ordering the graphs with events instead of device flags")
+            self.use_flags = False
         if self.use_flags:
             eng.scratch_sets = max(eng.scratch_sets, L)      # block n then shares no scratch with any later layer
         tune_gemm = tune_gemm and _enable_gemm_tuning()
@@ -356,11 +361,6 @@ class PipelinedTrainStep(GraphedTrainStep):
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        if self.use_flags and not self._flags_usable():
-            import warnings
-            warnings.warn("PipelinedTrainStep: streams do not run side by side here (shared hardware queue, or a profiler "
-                          "serialising kernels); ordering the graphs with events instead of device flags")
-            self.use_flags = False
         self._capture_graphs(loader)
         if self.use_flags and int(eng.flag_err.item()):
             import warnings
@@ -371,27 +371,38 @@ class PipelinedTrainStep(GraphedTrainStep):
             self.use_flags = False
             self._capture_graphs(loader)
 
-    def _flags_usable(self):
-        """Probe with harmless kernels: a wait enqueued on the backward / block stream FIRST, the raise on the main stream
-        afterwards.  That only completes without a timeout if the streams really run side by side -- not when two of them
-        share a hardware queue, and not under a profiler that serialises kernels (rocprofv3 --pmc).  A flag that times out
-        in the real loop would let a consumer run before its producer; better to know beforehand."""
+    def _probe(self, st, flag_index):
+        """One wait on ``st`` enqueued FIRST, the raise on the main stream afterwards: completes without a timeout only if
+        the two streams really run side by side."""
         eng = self.sampler._engine
         main = torch.cuda.current_stream()
         torch.cuda.synchronize()
         eng.flag_err.zero_()
         eng.flags.zero_()
         torch.cuda.synchronize()
-        for i, st in ((14, self.side), (15, self.third)):
-            _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * i, eng.flag_err.data_ptr(), st.cuda_stream), "bliss_flag_wait")
-        for i in (14, 15):
-            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * i, main.cuda_stream), "bliss_flag_raise")
+        f = eng.flags.data_ptr() + 4 * flag_index
+        _lib.check(_lib.lib.bliss_flag_wait(f, eng.flag_err.data_ptr(), st.cuda_stream), "bliss_flag_wait")
+        _lib.check(_lib.lib.bliss_flag_raise(f, main.cuda_stream), "bliss_flag_raise")
         torch.cuda.synchronize()
         ok = int(eng.flag_err.item()) == 0
         eng.flag_err.zero_()
         eng.flags.zero_()
         torch.cuda.synchronize()
         return ok
+
+    def _flags_usable(self, tries=4):
+        """Probe with harmless kernels before relying on device flags for ordering: a flag that times out in the real loop
+        would let a consumer run before its producer.  HIP multiplexes streams onto a few hardware queues (4 by default);
+        a stream that shares the main stream's queue cannot wait for it, so such a stream is replaced by the next one of
+        PyTorch's pool and probed again.  Under a profiler that serialises kernels (rocprofv3 --pmc) no stream passes."""
+        for name in ("side", "third"):
+            for _ in range(tries):
+                if self._probe(getattr(self, name), 14):
+                    break
+                setattr(self, name, torch.cuda.Stream())
+            else:
+                return False
+        return True
 
     def _capture_graphs(self, loader):
         # Several graphs, not one: a HIP graph with the sampler and the backward pass as parallel branches is executed with
