@@ -75,6 +75,7 @@ SIGNATURES = {
     "bliss_rng_stream_ready": [_P],
     "bliss_flag_wait": [_P, _P, _P],
     "bliss_flag_raise": [_P, _P],
+    "bliss_gather_rows": [_P, _I64, _P, _I32, _I32, _P, _I64, _P, _P],
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
     "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],

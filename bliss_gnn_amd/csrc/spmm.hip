@@ -200,6 +200,46 @@ __global__ void __launch_bounds__(SP_TPB) k_embed_norm(const bf16_t* __restrict_
   if (lane == 0) out[row] = f2bf(sqrtf(s));
 }
 
+// ---- feature gather + row norms in one pass ---------------------------------------------------------------------------
+// blocks[0].srcdata['features'] = g.ndata['features'][input_nodes] (train_lightning.py:138) and the embed_norm of those rows
+// (model.py:318-320): a wave copies one row (W bf16 per lane and access) through its slice of LDS to `out`, then takes the
+// sum of squares from LDS in exactly k_embed_norm's order, so the norm has the bits k_embed_norm(out) would give.
+// HBM-bound: 2 * K * F bytes in, the same out (SURVEY 8d "feature gather").
+template <int W>
+__global__ void __launch_bounds__(SP_TPB) k_gather_rows_norm(const bf16_t* __restrict__ feat, int64_t f_stride, const int* __restrict__ ids,
+                                                            int n_rows, int dim, bf16_t* __restrict__ out, int64_t o_stride,
+                                                            bf16_t* __restrict__ norm_out, int norm_vec4) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t rows_sh[];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * (SP_TPB / 64) + wave;
+  if (row >= n_rows) return;                          // wave-uniform; no workgroup barrier below
+  const int dpad = (dim + 7) & ~7;
+  bf16_t* sh = rows_sh + (size_t)wave * dpad;
+  const bf16_t* p = feat + (int64_t)ids[row] * f_stride;
+  bf16_t* q = out + (int64_t)row * o_stride;
+  if (W == 4) {
+    for (int c = lane * 4; c < dim; c += 256) { const uint2 v = *reinterpret_cast<const uint2*>(p + c); *reinterpret_cast<uint2*>(q + c) = v; *reinterpret_cast<uint2*>(sh + c) = v; }
+  } else if (W == 2) {
+    for (int c = lane * 2; c < dim; c += 128) { const uint32_t v = *reinterpret_cast<const uint32_t*>(p + c); *reinterpret_cast<uint32_t*>(q + c) = v; *reinterpret_cast<uint32_t*>(sh + c) = v; }
+  } else {
+    for (int c = lane; c < dim; c += 64) { const bf16_t v = p[c]; q[c] = v; sh[c] = v; }
+  }
+  if (!norm_out) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                    // the wave's own LDS writes, in order, before its reads
+  float s = 0.f;
+  if (norm_vec4) {
+    for (int c = lane * 4; c < dim; c += 256) {
+      const float a = bf2f(sh[c]), b = bf2f(sh[c + 1]), cc = bf2f(sh[c + 2]), d = bf2f(sh[c + 3]);
+      s += a * a; s += b * b; s += cc * cc; s += d * d;
+    }
+  } else {
+    for (int c = lane; c < dim; c += 64) { const float a = bf2f(sh[c]); s += a * a; }
+  }
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if (lane == 0) norm_out[row] = f2bf(sqrtf(s));
+}
+
 // ---- SAGE hidden-layer epilogue in one pass ----------------------------------------------------------------------
 // model.py:321-333 + :318-320 of the next layer:   rst = fc_self(h_dst) + h_neigh;  h = dropout(relu(rst));  ||h_j||
 // The reference runs four element-wise kernels for this; here one wave walks a row once: bf16 add (fp32, one rounding),
@@ -372,6 +412,25 @@ int bliss_sage_epilogue_bwd(const void* dout, int64_t dout_stride, const void* o
                                                             (bf16_t*)din, din_stride);
   else k_sage_epilogue_bwd<false><<<grid, SP_TPB, 0, st>>>((const bf16_t*)dout, dout_stride, (const bf16_t*)out, out_stride, n_rows, dim, scale,
                                                           (bf16_t*)din, din_stride);
+  return (int)hipGetLastError();
+}
+
+int bliss_gather_rows(const void* feat, int64_t feat_stride, const int32_t* ids, int32_t n_rows, int32_t dim, void* out,
+                      int64_t out_stride, void* norm_out, void* stream) {
+  if (!feat || !ids || !out || dim <= 0 || feat_stride < dim || out_stride < dim) return BLISS_EINVAL;
+  if (n_rows <= 0) return 0;
+  const size_t lds = (size_t)(SP_TPB / 64) * ((dim + 7) & ~7) * sizeof(bf16_t);
+  if (lds > 48 * 1024) return BLISS_EINVAL;           // (caller gathers and norms separately)
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (n_rows + SP_TPB / 64 - 1) / (SP_TPB / 64);
+  const uintptr_t al = (uintptr_t)feat | (uintptr_t)out;
+  const int norm_vec4 = (dim % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)out) % 8 == 0);     // = bliss_embed_norm(out)
+  if (dim % 4 == 0 && feat_stride % 4 == 0 && out_stride % 4 == 0 && al % 8 == 0)
+    k_gather_rows_norm<4><<<grid, SP_TPB, lds, st>>>((const bf16_t*)feat, feat_stride, ids, n_rows, dim, (bf16_t*)out, out_stride, (bf16_t*)norm_out, norm_vec4);
+  else if (dim % 2 == 0 && feat_stride % 2 == 0 && out_stride % 2 == 0 && al % 4 == 0)
+    k_gather_rows_norm<2><<<grid, SP_TPB, lds, st>>>((const bf16_t*)feat, feat_stride, ids, n_rows, dim, (bf16_t*)out, out_stride, (bf16_t*)norm_out, norm_vec4);
+  else
+    k_gather_rows_norm<1><<<grid, SP_TPB, lds, st>>>((const bf16_t*)feat, feat_stride, ids, n_rows, dim, (bf16_t*)out, out_stride, (bf16_t*)norm_out, norm_vec4);
   return (int)hipGetLastError();
 }
 

@@ -100,13 +100,34 @@ class _LazyFrame(dict):
         super().__init__()
         self._parent = parent_frame
         self._index_fn = index_fn
+        self._row_norms = []            # (gathered tensor, its bf16 row norms) for rows gathered by the fused kernel
 
     def __missing__(self, key):
         if self._parent is not None and key in self._parent:
-            v = torch.index_select(self._parent[key], 0, self._index_fn())      # int32 ids are fine: no widening pass
+            src, idx = self._parent[key], self._index_fn()
+            if (src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1 and src.shape[1] <= 6144
+                    and idx.dtype == torch.int32 and idx.is_contiguous()):
+                # bf16 feature rows: one HBM-bound pass gathers them AND leaves their row norms (the embed_norm the model
+                # takes of blocks[0]'s input right afterwards, model.py:318-320)
+                from . import _lib
+                v = torch.empty(idx.numel(), src.shape[1], dtype=torch.bfloat16, device=src.device)
+                nrm = torch.empty(idx.numel(), dtype=torch.bfloat16, device=src.device)
+                _lib.check(_lib.lib.bliss_gather_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), idx.numel(), src.shape[1],
+                                                      v.data_ptr(), v.stride(0), nrm.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), "bliss_gather_rows")
+                self._row_norms.append((v, nrm))
+            else:
+                v = torch.index_select(src, 0, idx)                             # int32 ids are fine: no widening pass
             self[key] = v
             return v
         raise KeyError(key)
+
+    def row_norm_of(self, t):
+        """bf16 row norms of ``t`` if ``t`` is a tensor this frame gathered with the fused kernel, else None."""
+        for v, nrm in self._row_norms:
+            if v is t:
+                return nrm
+        return None
 
     def __contains__(self, key):
         return dict.__contains__(self, key) or (self._parent is not None and key in self._parent)

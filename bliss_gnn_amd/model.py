@@ -10,6 +10,13 @@ import torch.nn as nn
 from .nn import SAGEConv, embed_norm, sage_epilogue
 
 
+def _gathered_norm(blocks, x):
+    """The row norms of ``x`` if it is blocks[0]'s feature slice as gathered by the fused gather + norm kernel
+    (graph._LazyFrame), else None (the caller then runs embed_norm: same bits either way)."""
+    fn = getattr(blocks[0].srcdata, "row_norm_of", None) if len(blocks) else None
+    return fn(x) if fn is not None else None
+
+
 class SAGE(nn.Module):
     """model.py:292-383."""
 
@@ -42,7 +49,7 @@ class SAGE(nn.Module):
         return self._drop_ctr[key], (torch.cuda.initial_seed() ^ (0x9E3779B1 * (l + 1))) & 0xFFFFFFFF
 
     def forward(self, blocks, x):
-        h, norm = x, None
+        h, norm = x, _gathered_norm(blocks, x)
         for l, (layer, block) in enumerate(zip(self.layers, blocks)):
             block.srcdata["embed_norm"] = embed_norm(h) if norm is None else norm          # model.py:318-320
             norm = None
@@ -132,9 +139,9 @@ class GCN(nn.Module):
         self.activation = activation
 
     def forward(self, blocks, x):
-        h = x
+        h, norm = x, _gathered_norm(blocks, x)
         for l, (layer, block) in enumerate(zip(self.layers, blocks)):
-            block.srcdata["embed_norm"] = embed_norm(h)                       # model.py:425-427
+            block.srcdata["embed_norm"] = embed_norm(h) if (l > 0 or norm is None) else norm      # model.py:425-427
             h = layer(block, h, edge_weight=(block.edata["edge_weights"] if "edge_weights" in block.edata else None))
             if l < len(self.layers) - 1:
                 h = self.dropout(h)                                           # model.py:437-438
@@ -195,8 +202,9 @@ class GATv2(nn.Module):
 
     def forward(self, blocks, inputs):
         h = inputs.bfloat16()
+        norm = _gathered_norm(blocks, h)
         for l, block in enumerate(blocks):
-            block.srcdata["embed_norm"] = embed_norm(h)                                                        # :211-213
+            block.srcdata["embed_norm"] = embed_norm(h) if (l > 0 or norm is None) else norm                   # :211-213
             h, a = self.gatv2_layers[l](block, h, edge_weight=(block.edata["edge_weights"] if "edge_weights" in block.edata else None),
                                         get_attention=True)
             block.edata["a_ij"] = a.squeeze(-1).mean(dim=1)                                                    # :224-227

@@ -194,6 +194,14 @@ int bliss_rng_stream_ready(void* stream);
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);
 
+/* Feature gather      train_lightning.py:138 (blocks[0].srcdata['features'], DGL's lazy slice of g.ndata by ndata[NID]):
+ * out[r, :] = feat[ids[r], :] for r < n_rows, bf16 rows of `dim` elements (strides in elements).  norm_out (optional, bf16
+ * [n_rows]) receives the row norms of the gathered rows with exactly the bits bliss_embed_norm(out, ...) would produce --
+ * the embed_norm model.py:318-320 takes of the same rows right afterwards.  ids must be valid row numbers (padded rows of
+ * a static-shape block point at row 0).  BLISS_EINVAL if dim exceeds what one wave stages in LDS (6144 elements). */
+int bliss_gather_rows(const void* feat, int64_t feat_stride, const int32_t* ids, int32_t n_rows, int32_t dim, void* out,
+                      int64_t out_stride, void* norm_out, void* stream);
+
 /* th.norm(h, dim=1)   model.py:318-320: embed_norm[j] = ||h_j||_2, fp32 accumulation, bf16 out. */
 int bliss_embed_norm(const void* h, int32_t n_rows, int32_t dim, int64_t row_stride, void* out, void* stream);
 

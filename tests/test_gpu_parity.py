@@ -964,6 +964,42 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             assert torch.equal(pa, pb)
 
 
+def test_feature_gather_with_norms(cuda):
+    """bliss_gather_rows (blocks[0].srcdata['features'] + its embed_norm in one pass): rows identical to index_select, norms
+    bit-identical to embed_norm of the gathered rows, for the 8-, 4- and 2-byte copy paths; and through the Block frame."""
+    from bliss_gnn_amd import _lib
+    from bliss_gnn_amd.nn import embed_norm
+    bg = _bg()
+    gen = torch.Generator().manual_seed(4)
+    for V, dim, off in ((5000, 602, 0), (3000, 256, 0), (2000, 301, 0), (2000, 1433, 0), (1000, 64, 1)):
+        base = torch.randn(V * dim + 8, generator=gen).bfloat16().to(cuda)
+        feat = base[off:off + V * dim].view(V, dim)                      # off = 1: rows 2-byte aligned only
+        ids = torch.randint(0, V, (777,), generator=gen).to(torch.int32).to(cuda)
+        out = torch.empty(777, dim, dtype=torch.bfloat16, device=cuda)
+        nrm = torch.empty(777, dtype=torch.bfloat16, device=cuda)
+        _lib.check(_lib.lib.bliss_gather_rows(feat.data_ptr(), feat.stride(0), ids.data_ptr(), 777, dim, out.data_ptr(), out.stride(0),
+                                              nrm.data_ptr(), torch.cuda.current_stream().cuda_stream), "bliss_gather_rows")
+        want = torch.index_select(feat, 0, ids)
+        assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+        assert torch.equal(nrm.view(torch.int16), embed_norm(want).view(torch.int16))
+        ref = want.float().norm(dim=1)
+        assert torch.allclose(nrm.float(), ref, rtol=2 ** -8)          # one bf16 rounding of the fp32 norm
+    # through the frames: the model picks the cached norms up for blocks[0]
+    from bliss_gnn_amd.synth import chung_lu_csc
+    ip, ix, ei = chung_lu_csc(3000, 40000, seed=3)
+    feats = torch.randn(3000, 50, generator=gen).bfloat16().to(cuda)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats})
+    g.edata["w"] = bg.normalized_edata(g)
+    s = bg.PoissonBanditLadiesSampler([60, 30], eta=0.1)
+    torch.manual_seed(1)
+    inp, _, blocks = s.sample_blocks(g, torch.arange(16, dtype=torch.int32, device=cuda))
+    x = blocks[0].srcdata["features"]
+    assert torch.equal(x.view(torch.int16), feats[inp.long()].view(torch.int16))
+    n = blocks[0].srcdata.row_norm_of(x)
+    assert n is not None and torch.equal(n.view(torch.int16), embed_norm(x).view(torch.int16))
+    assert blocks[0].srcdata.row_norm_of(x.clone()) is None
+
+
 def test_concentrated_weight_rows_match_oracle(cuda):
     """EXP3 rows after the bandit has concentrated them: weights from ~0.3 down to 1e-30 in the same row, columns whose
     weights are ALL tiny (their sum is far below 2^-40: the block-floating column sums of k_col_sums), two consecutive
