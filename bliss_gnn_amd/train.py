@@ -452,17 +452,19 @@ class PipelinedTrainStep(GraphedTrainStep):
         main, side = torch.cuda.current_stream(), self.side
         main.wait_event(self._bwd_done)                  # parameters after the previous step's Adam
         if self.use_flags:
-            main.wait_event(self._blk_done)              # all blocks of the batch about to be trained
             self.g_main[cur].replay()                    # F + X + S: one graph on the critical stream
-            with torch.cuda.stream(side):
-                self.g_bwd[cur].replay()                 # B: waits for the flag S raises when it starts
-                if on_side is not None:
-                    on_side()
-                self._bwd_done.record(side)
             if self.g_blk[nxt] is not None:
                 with torch.cuda.stream(self.third):
                     self.g_blk[nxt].replay()             # early blocks of S: each waits for the flag of the next layer
                     self._blk_done.record(self.third)
+            with torch.cuda.stream(side):
+                self.g_bwd[cur].replay()                 # B: waits for the flag S raises when it starts
+                if on_side is not None:
+                    on_side()
+                # one wait on the critical stream instead of two: "B done" below also means "all blocks of S built"
+                if self.g_blk[nxt] is not None:
+                    side.wait_event(self._blk_done)
+                self._bwd_done.record(side)
         else:
             self.g_fwd[cur].replay()                     # F + X
             self._fwd_done.record(main)
@@ -475,10 +477,7 @@ class PipelinedTrainStep(GraphedTrainStep):
             self.g_smp[nxt].replay()                     # ... S (needs the EXP3 weights X just wrote: same stream)
 
     def _join(self):
-        main = torch.cuda.current_stream()
-        main.wait_event(self._bwd_done)
-        if self.use_flags:
-            main.wait_event(self._blk_done)
+        torch.cuda.current_stream().wait_event(self._bwd_done)     # (flag mode: implies the early blocks, see _half)
 
     def _replay(self, first_chain=False):
         eng = self.sampler._engine
