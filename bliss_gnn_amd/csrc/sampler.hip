@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
                                                    int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
                                                    int* __restrict__ span_seg, long long frontier_cap, int* entry_flag) {
   __shared__ int sh[17];
+  __shared__ int st_sh[1024];
   // This kernel runs <=> everything enqueued before this layer has completed (stream / graph order): tell a consumer on
   // another stream (bliss_flag_wait) without an event, i.e. without cutting a captured graph in two.
   if (entry_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(entry_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -137,14 +138,27 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
       if (base0 + i * (int)blockDim.x >= S) break;      // block-uniform
       const int deg = degs[i];
       int tot, ex = block_excl_scan(deg, sh, &tot);
+      const long long start = run + ex;
       if (k < S) {
-        const long long start = run + ex;
         seg_ptr[k] = (int)start;
         // what every frontier pass needs to find its edges without a search and without chasing seeds -> indptr:
         col_base[k] = deg > 0 ? cols[i] - start : 0;    // CSC position = col_base[k] + frontier position
-        // (a frontier longer than the graph has edges means repeated seeds: flagged, nothing is written past the tables)
-        if (start + deg <= frontier_cap)
-          for (long long sp = (start + SPAN - 1) / SPAN; sp * SPAN < start + deg; ++sp) span_seg[sp] = k;   // segment of position sp * 256
+      }
+      // span_seg[sp] = the seed column holding frontier position sp * 256.  Done by the whole workgroup over the round's
+      // spans (a search in the round's 1024 column starts), not by every thread over its own column: a hub column of 30 K
+      // edges has > 100 spans, and a round used to wait for the thread that owned it.
+      // (a frontier longer than the graph has edges means repeated seeds: flagged, nothing is written past the tables)
+      if (run + tot <= frontier_cap) {
+        st_sh[threadIdx.x] = (int)(k < S ? start : run + tot);
+        __syncthreads();
+        const long long sp_end = (run + tot + SPAN - 1) / SPAN;
+        for (long long sp = (run + SPAN - 1) / SPAN + threadIdx.x; sp < sp_end; sp += blockDim.x) {
+          const int p = (int)(sp * SPAN);
+          int t = 0;                                    // last column of the round that starts at or before p (st_sh[0] = run <= p)
+#pragma unroll
+          for (int step = 512; step >= 1; step >>= 1) if (st_sh[t + step] <= p) t += step;
+          span_seg[sp] = base0 + i * (int)blockDim.x + t;
+        }
       }
       run += tot;
       if (run > frontier_cap) bad |= BLISS_ERR_CAP_FRONTIER;
