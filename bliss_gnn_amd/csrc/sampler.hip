@@ -111,6 +111,8 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
     for (int i = t0; i < cap_s * 5; i += step) seed_acc[i] = 0ull;
     if (src_cnt) for (int i = t0; i <= cap_k; i += step) src_cnt[i] = 0;
     if (bin_cursor) for (int i = t0; i <= n_bins; i += step) bin_cursor[i] = 0;   // [n_bins] = touched count
+    // the seeds' local ids (scattered 4-byte stores): here, spread over several CUs, not in the one workgroup that scans
+    for (int k = t0; k < S; k += step) { const int s = seeds[k]; if (s >= 0 && s < num_nodes) local_id[s] = k; }
     if (gridDim.x > 1) return;
   }
   long long run = 0;
@@ -128,7 +130,6 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
         else {
           cols[i] = indptr[s];
           degs[i] = (int)(indptr[s + 1] - cols[i]);
-          local_id[s] = k;
         }
       }
     }
