@@ -232,6 +232,20 @@ class BanditLadiesSampler(BlockSampler):
                                              factor.data_ptr(), n_dev.data_ptr(), bound, self._err.data_ptr(), _stream()),
                    "bliss_exp3_apply")
 
+    def apply_updates_ranks(self, block_ids, gathered, rank_stride, n_ranks, pos_off, factor_off_bf16, count_off, bounds):
+        """apply_updates for the packed (position, factor, count) lists of ``n_ranks`` ranks and several blocks in ONE launch,
+        rank after rank (bliss_exp3_apply_ranks; ``gathered`` int32 = the all-gathered buffers, offsets per block inside one
+        rank's buffer).  Same bits as the corresponding apply_updates calls in rank order."""
+        m = _lib.Exp3RankLists()
+        for j, idx in enumerate(block_ids):
+            m.w_pos[j], m.row_sum[j] = self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr()
+            m.pos_off_words[j], m.factor_off_bf16[j], m.count_off_words[j], m.bound[j] = pos_off[j], factor_off_bf16[j], count_off[j], bounds[j]
+        m.n_blocks, m.n_ranks, m.rank_stride_words = len(block_ids), int(n_ranks), int(rank_stride)
+        if getattr(self, "_apply_bar", None) is None:
+            self._apply_bar = torch.zeros(2, dtype=torch.int32, device=gathered.device)
+        _lib.check(_lib.lib.bliss_exp3_apply_ranks(C.byref(m), gathered.data_ptr(), self._apply_bar.data_ptr(), self._err.data_ptr(),
+                                                   _stream()), "bliss_exp3_apply_ranks")
+
     def normalize(self, idx, g):
         """F.normalize(self.exp3_weights[idx], p=1, dim=0), bandit_sampler.py:249 (bit-exact, skipped on the
         device when the bf16 norm is 1.0)."""

@@ -186,6 +186,79 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_apply(bf16_t* w_row, int64_t* r
   if (bad) atomicOr(err, bad);
 }
 
+// ---- the update lists of ALL ranks and ALL blocks in one launch (replicas of the bandit state) ----
+// Lists are applied rank after rank (the bf16 products do not commute, and every replica must end with the same bits): a
+// grid barrier separates the ranks -- the launch gaps of n_ranks x n_blocks small kernels were the cost of the old path.
+// A position may occur in the lists of several ranks, written by workgroups on different XCDs (whose L2s are not coherent
+// for plain stores), and two neighbouring positions share a 32-bit word: every update is a compare-and-swap on that word
+// at agent scope (performed at the memory side), so no cache write-back is needed at the barrier.
+// Grid: <= APPLY_MAX_WGS co-resident workgroups.  bar[0] = arrivals (monotone within a launch), bar[1] = exit ticket;
+// the last workgroup to leave resets both.
+#define APPLY_MAX_WGS 256
+struct ApplyLists {
+  bf16_t* w_row[BLISS_EXP3_MAX_BLOCKS];
+  int64_t* row_sum[BLISS_EXP3_MAX_BLOCKS];
+  int pos_off[BLISS_EXP3_MAX_BLOCKS], fac_off[BLISS_EXP3_MAX_BLOCKS], cnt_off[BLISS_EXP3_MAX_BLOCKS], bound[BLISS_EXP3_MAX_BLOCKS];
+  int n_blocks, n_ranks;
+  long long rank_stride;          // int32 words between two ranks' packed buffers
+};
+
+__global__ void __launch_bounds__(E3_TPB) k_exp3_apply_ranks(ApplyLists m, const int* __restrict__ gathered, int* bar, int* err) {
+  int bad = 0;
+  int64_t dg[BLISS_EXP3_MAX_BLOCKS][3];
+#pragma unroll
+  for (int b = 0; b < BLISS_EXP3_MAX_BLOCKS; ++b) dg[b][0] = dg[b][1] = dg[b][2] = 0;
+  const int G = gridDim.x;
+  for (int r = 0; r < m.n_ranks; ++r) {
+    const int* base = gathered + (long long)r * m.rank_stride;
+#pragma unroll
+    for (int b = 0; b < BLISS_EXP3_MAX_BLOCKS; ++b) {
+      if (b >= m.n_blocks) break;
+      int n = base[m.cnt_off[b]];
+      if (n > m.bound[b]) n = m.bound[b];
+      const int* pos = base + m.pos_off[b];
+      const bf16_t* fac = reinterpret_cast<const bf16_t*>(base) + m.fac_off[b];
+      for (int e = blockIdx.x * E3_TPB + threadIdx.x; e < n; e += G * E3_TPB) {
+        const float f = bf2f(fac[e]);
+        const uintptr_t a = (uintptr_t)(m.w_row[b] + pos[e]);
+        unsigned* word = reinterpret_cast<unsigned*>(a & ~(uintptr_t)3);
+        const int sh = (a & 2) ? 16 : 0;
+        unsigned cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          const bf16_t w_old = (bf16_t)((cur >> sh) & 0xffffu);
+          const bf16_t w_new = f2bf(bf2f(w_old) * f);                                   // :248
+          if (w_new == w_old) break;
+          const unsigned want = (cur & ~(0xffffu << sh)) | ((unsigned)w_new << sh);
+          if (__hip_atomic_compare_exchange_strong(word, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            int64_t x[3], y[3];
+            row_digits(w_new, x, &bad);
+            row_digits(w_old, y, &bad);
+            dg[b][0] += x[0] - y[0]; dg[b][1] += x[1] - y[1]; dg[b][2] += x[2] - y[2];
+            break;
+          }
+        }
+      }
+    }
+    if (r + 1 < m.n_ranks) {                             // every update of rank r has been performed (the CAS returned)
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (r + 1) * G) __builtin_amdgcn_s_sleep(2);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BLISS_EXP3_MAX_BLOCKS; ++b)
+    if (b < m.n_blocks) flush_digits(dg[b], m.row_sum[b]);
+  if (bad) atomicOr(err, bad);
+  __syncthreads();
+  if (threadIdx.x == 0 && __hip_atomic_fetch_add(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+    __hip_atomic_store(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(bar + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ void __launch_bounds__(E3_TPB) k_row_sum(const bf16_t* __restrict__ w, int64_t n, int64_t* limbs, int* err) {
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
@@ -363,6 +436,26 @@ int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const vo
   if (grid > 2048) grid = 2048;
   hipStream_t st = (hipStream_t)stream;
   PROF_LAUNCH(BK_EXP3_APPLY, st, k_exp3_apply<<<grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, row_sum, pos, (const bf16_t*)factor, n_dev, err));
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_apply_ranks(const bliss_exp3_rank_lists_t* lists, const int32_t* gathered, int32_t* barrier, int32_t* err, void* stream) {
+  if (!lists || !gathered || !barrier || !err || lists->n_blocks < 1 || lists->n_blocks > BLISS_EXP3_MAX_BLOCKS || lists->n_ranks < 1 ||
+      lists->rank_stride_words <= 0)
+    return BLISS_EINVAL;
+  ApplyLists m;
+  int64_t most = 1;
+  for (int b = 0; b < lists->n_blocks; ++b) {
+    if (!lists->w_pos[b] || !lists->row_sum[b] || lists->bound[b] < 0) return BLISS_EINVAL;
+    m.w_row[b] = (bf16_t*)lists->w_pos[b]; m.row_sum[b] = lists->row_sum[b];
+    m.pos_off[b] = lists->pos_off_words[b]; m.fac_off[b] = lists->factor_off_bf16[b]; m.cnt_off[b] = lists->count_off_words[b];
+    m.bound[b] = lists->bound[b];
+    if (lists->bound[b] > most) most = lists->bound[b];
+  }
+  m.n_blocks = lists->n_blocks; m.n_ranks = lists->n_ranks; m.rank_stride = lists->rank_stride_words;
+  int grid = (int)((most + E3_TPB - 1) / E3_TPB);
+  if (grid > APPLY_MAX_WGS) grid = APPLY_MAX_WGS;      // all workgroups must be resident together (grid barrier)
+  k_exp3_apply_ranks<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(m, gathered, barrier, err);
   return (int)hipGetLastError();
 }
 

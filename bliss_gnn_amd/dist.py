@@ -11,7 +11,8 @@ step keep the replicas in lock-step:
   * EXP3: each rank computes the multiplicative factors of its own blocks without applying them
     (bliss_exp3_update(apply=0)); (position, factor) lists are all-gathered (padded to the longest,
     ~6 B per sampled edge) and EVERY rank applies ALL lists in rank order, then renormalises -- so
-    the bf16 weight rows stay bit-identical on every GPU.
+    the bf16 weight rows stay bit-identical on every GPU.  In the static-shape step the lists of all
+    ranks and blocks are applied by one launch (bliss_exp3_apply_ranks: grid barrier between ranks).
 
 The collective logic below is backend-agnostic and covered by world_size-2 gloo tests on CPU.
 """
@@ -31,14 +32,15 @@ def allreduce_gradients(model):
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     if not grads:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([g.reshape(-1) for g in grads])                  # one kernel
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(dist.get_world_size())
-    off = 0
+    views, off = [], 0
     for g in grads:
         n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+        views.append(flat[off:off + n].view_as(g))
         off += n
+    torch._foreach_copy_(grads, views)                                 # one multi-tensor launch instead of one copy per parameter
 
 
 def gather_updates(pos, factor):
@@ -88,16 +90,13 @@ def exp3_all_ranks_static(sampler, mfgs, g):
     fac_all = buf[tot:tot + n_fac].view(torch.bfloat16)      # [2 * n_fac] bf16 view of the same storage
     factors = [fac_all[offs[i]:offs[i] + caps[i]] for i in range(L)]
     sampler.exp3(mfgs, g, apply=False, factors=factors)      # rewards + factors, nothing applied yet
-    for i, mfg in enumerate(mfgs):
-        buf[offs[i]:offs[i] + caps[i]].copy_(mfg.pos)
-        buf[tot + n_fac + i:tot + n_fac + i + 1].copy_(mfg._counts_dev[4:5])      # LayerCounts::B
+    # positions and true counts (LayerCounts::B) of all blocks: one multi-tensor copy
+    torch._foreach_copy_([buf[offs[i]:offs[i] + caps[i]] for i in range(L)] + [buf[tot + n_fac + i:tot + n_fac + i + 1] for i in range(L)],
+                         [m.pos for m in mfgs] + [m._counts_dev[4:5] for m in mfgs])
     gath = torch.empty(world * n_pad, dtype=torch.int32, device=g.device)
     dist.all_gather_into_tensor(gath, buf)
+    # every rank's lists, rank after rank (rank order on every rank: the rows stay bit-identical), all blocks: ONE launch
+    sampler.apply_updates_ranks(list(range(L)), gath, n_pad, world, offs, [2 * tot + o for o in offs],
+                                [tot + n_fac + i for i in range(L)], caps)
     for i in range(L):
-        for r in range(world):                               # rank order on every rank: the rows stay bit-identical
-            base = r * n_pad
-            pos_r = gath[base + offs[i]:base + offs[i] + caps[i]]
-            fac_r = gath[base + tot:base + tot + n_fac].view(torch.bfloat16)[offs[i]:offs[i] + caps[i]]
-            cnt_r = gath[base + tot + n_fac + i:base + tot + n_fac + i + 1]
-            sampler.apply_updates(i, pos_r, fac_r, g, n_dev=cnt_r)
         sampler.normalize(i, g)

@@ -290,6 +290,23 @@ int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_
 int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const void* factor, const int32_t* n_dev,
                      int32_t n_bound, int32_t* err, void* stream);
 
+/* The same for the lists of ALL ranks and ALL blocks of a step in ONE launch (replicas).  `gathered`
+ * holds n_ranks packed buffers of rank_stride_words int32 words each (what an all-gather of every rank's buffer leaves);
+ * inside a rank's buffer block b has its positions at pos_off_words[b] (int32 [bound[b]]), its bf16 factors at element
+ * factor_off_bf16[b] of the buffer viewed as bf16, and its true list length at count_off_words[b].  Ranks are applied in
+ * rank order (grid barrier between them: the bf16 products do not commute), blocks of one rank side by side; a position may
+ * occur in several ranks' lists.  barrier: int32[2], zero on first use, left zero.  Bits identical to n_ranks x n_blocks
+ * bliss_exp3_apply calls in rank order. */
+typedef struct {
+  void* w_pos[BLISS_EXP3_MAX_BLOCKS];
+  int64_t* row_sum[BLISS_EXP3_MAX_BLOCKS];
+  int32_t pos_off_words[BLISS_EXP3_MAX_BLOCKS], factor_off_bf16[BLISS_EXP3_MAX_BLOCKS], count_off_words[BLISS_EXP3_MAX_BLOCKS],
+      bound[BLISS_EXP3_MAX_BLOCKS];
+  int32_t n_blocks, n_ranks;
+  int64_t rank_stride_words;
+} bliss_exp3_rank_lists_t;
+int bliss_exp3_apply_ranks(const bliss_exp3_rank_lists_t* lists, const int32_t* gathered, int32_t* barrier, int32_t* err, void* stream);
+
 /* F.normalize(row, p=1, dim=0), bandit_sampler.py:249, bit-exact: norm = bf16(exact sum).  The pass
  * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[BLISS_NORM_SCRATCH], zero-initialised
  * once by the caller and left zero ([0] afterwards holds norm bits | skip << 16 | err << 20). */

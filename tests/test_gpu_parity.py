@@ -964,6 +964,59 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             assert torch.equal(pa, pb)
 
 
+def test_apply_ranks_matches_sequential_applies(cuda):
+    """bliss_exp3_apply_ranks (the update lists of all ranks and blocks in one launch, grid barrier between ranks) leaves
+    the bits of the same lists applied one bliss_exp3_apply at a time in rank order: positions repeated across ranks,
+    neighbouring positions (two bf16 share a 32-bit word), an odd row length (second row starts mid-word), short counts."""
+    from oracle import bliss_oracle as bo
+    bg = _bg()
+    gen = torch.Generator().manual_seed(11)
+    V = 2000
+    og = bo.prepare_graph(torch.randint(0, V, (30001,), generator=gen), torch.randint(0, V, (30001,), generator=gen), V)
+    E = og.num_edges
+    g = bg.Graph(og.indptr.to(cuda), og.indices.to(cuda), og.eid.to(cuda))
+    w0 = (torch.rand(2, E, generator=gen) * 1e-3 + 1e-6).bfloat16()
+    R, bounds = 4, [20000, 9000]
+    offs, tot = [0, bounds[0]], sum(bounds)
+    n_fac = (tot + 1) // 2
+    n_pad = (tot + n_fac + 2 + 3) // 4 * 4
+    gath = torch.zeros(R * n_pad, dtype=torch.int32)
+    lists = []
+    for r in range(R):
+        base = gath[r * n_pad:(r + 1) * n_pad]
+        per = []
+        for b in range(2):
+            n = bounds[b] - 37 * (r + 1) - b                           # true length < capacity
+            hot = torch.randperm(min(E, 3 * bounds[b]), generator=gen)[:n].to(torch.int32)   # dense range: many repeats across ranks
+            fac = (torch.rand(n, generator=gen) * 2.2 + 0.5).bfloat16()
+            base[offs[b]:offs[b] + n] = hot
+            base[tot:tot + n_fac].view(torch.bfloat16)[offs[b]:offs[b] + n] = fac
+            base[tot + n_fac + b] = n
+            per.append((hot, fac))
+        lists.append(per)
+    outs = []
+    for fused in (False, True):
+        s = bg.PoissonBanditLadiesSampler([10, 10], eta=0.1)
+        s._bind(g)
+        s.exp3_weights = w0.to(cuda)                                      # by edge id; the lists index positions: same thing for both runs
+        if fused:
+            s.apply_updates_ranks([0, 1], gath.to(cuda), n_pad, R, offs, [2 * tot + o for o in offs], [tot + n_fac, tot + n_fac + 1], bounds)
+        else:
+            for r in range(R):
+                for b in range(2):
+                    pos, fac = lists[r][b]
+                    s.apply_updates(b, pos.to(cuda), fac.to(cuda), g)
+        torch.cuda.synchronize()
+        s.check_errors()
+        limbs = s._row_sum.cpu().view(2, -1, 3).sum(dim=1)               # replicas of three limbs -> one exact sum per row
+        sums = [int(l[0]) + (int(l[1]) << 32) + (int(l[2]) << 64) for l in limbs]
+        outs.append((s._w_pos.cpu().view(torch.int16).clone(), sums))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    assert not torch.equal(outs[0][0], bg.Graph.by_position(g, w0.to(cuda)).cpu().view(torch.int16))     # something was applied
+    assert int(s._apply_bar.abs().sum()) == 0                             # the barrier words are left zero
+
+
 def test_feature_gather_with_norms(cuda):
     """bliss_gather_rows (blocks[0].srcdata['features'] + its embed_norm in one pass): rows identical to index_select, norms
     bit-identical to embed_norm of the gathered rows, for the 8-, 4- and 2-byte copy paths; and through the Block frame."""
