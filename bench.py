@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises: see bliss_gnn_amd/__init__.py
 
 import torch
 import torch.distributed as dist
@@ -39,6 +40,9 @@ def parse():
     ap.add_argument("--tune-gemm", type=int, default=1, help="1: TunableOp picks the library GEMM solutions during warm-up")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the step's HIP graph")
     ap.add_argument("--no-pipeline", action="store_true", help="one step per graph, sampling not overlapped with the backward pass")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="single process: run the replica exchange path (gradient all-reduce, EXP3 all-gather + apply) on a world of "
+                         "one rank -- what the multi-GPU step costs per GPU before any communication time")
     return ap.parse_args()
 
 
@@ -57,6 +61,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    force_dist = args.force_dist and world == 1
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
@@ -113,7 +122,7 @@ def main():
         # graph; by default two consecutive steps per graph, with the next batch's sampling overlapped with the backward pass
         try:
             cls = GraphedTrainStep if args.no_pipeline else PipelinedTrainStep
-            step = cls(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"], distributed=world > 1)
+            step = cls(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"], distributed=world > 1 or force_dist)
             step.calibrate(loader, steps=8)
             step.capture(loader, warmup=2, tune_gemm=args.tune_gemm)
             launch = ("one HIP graph per step" if args.no_pipeline else
@@ -205,7 +214,8 @@ def main():
                                                                  "SAGE" if args.model == "sage" else "GATv2 (heads 4/4/1)", hidden, eta,
                                                                  "/".join(map(str, fan)), cfg["batch"],
                                                                  "" if args.sampler == "poisson-bandit" else " [sampler: poisson-ladies, no EXP3 update]"),
-                   "parallelism": "replicas x%d (grad all-reduce + exp3 all-gather over RCCL)" % world if world > 1 else "single GPU",
+                   "parallelism": ("replicas x%d (grad all-reduce + exp3 all-gather over RCCL)" % world if world > 1 else
+                                   "single GPU, replica exchange path on a world of one rank" if force_dist else "single GPU"),
                    "launch": launch,
                    "global_batch": cfg["batch"] * world},
         "sampled_edges_per_sec": n_edges / dt, "frontier_edges_per_sec": n_frontier / dt,
@@ -246,7 +256,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(g, feats, labels, train_nid, cfg, fan, eta, hidden, args.cpu_baseline_steps)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

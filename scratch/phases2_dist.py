@@ -1,0 +1,68 @@
+"""Phase boundaries of the pipelined loop in free-running mode (no sync between pairs): timing events on the main stream
+between the graph replays of PipelinedTrainStep._replay / _replay_sampler."""
+import sys, time, torch
+sys.path.insert(0, '.')
+import bliss_gnn_amd as bg
+from bliss_gnn_amd.model import SAGE
+from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc, node_data
+from bliss_gnn_amd.train import BatchLoader, PipelinedTrainStep
+dev = torch.device('cuda:0')
+cfg = CONFIGS['reddit']
+ip, ix, ei = chung_lu_csc(cfg["num_nodes"], cfg["num_edges"], seed=0, device=dev)
+feats, labels, train_nid = node_data(cfg["num_nodes"], cfg["feat"], cfg["classes"], cfg["n_train"], seed=1, device=dev)
+g = bg.Graph(ip, ix, ei, ndata={"features": feats, "labels": labels}); g.edata["w"] = bg.normalized_edata(g)
+sampler = bg.PoissonBanditLadiesSampler(cfg["fanouts"], eta=0.1)
+torch.manual_seed(1234)
+model = SAGE(cfg["feat"], 256, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()
+loader = BatchLoader(train_nid, cfg["batch"], seed=2).forever()
+import os, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29577")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+step = PipelinedTrainStep(g, sampler, model, cfg["batch"], distributed=True)
+step.calibrate(loader, steps=8); step.capture(loader, warmup=2, tune_gemm=True)
+step.run(loader, 50)
+torch.cuda.synchronize()
+marks = []
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True); e.record(torch.cuda.current_stream()); marks.append((name, e))
+
+
+class W:
+    def __init__(s, gr, a, b): s.gr, s.a, s.b = gr, a, b
+
+    def replay(s):
+        if s.a: mark(s.a)
+        s.gr.replay()
+        if s.b: mark(s.b)
+
+
+if step.use_flags:
+    step.g_main = [W(x, "F_start", "S_end") for x in step.g_main]
+else:
+    step.g_fwd = [W(x, "F_start", "X_end") for x in step.g_fwd]
+    step.g_smp = [W(x, None, "S_end") for x in step.g_smp]
+eng = sampler._engine
+orig_end = eng.static_rng_end
+
+
+def end(slot):
+    orig_end(slot); mark("tail_end")
+
+
+eng.static_rng_end = end
+N = 40
+step.run(loader, N)
+torch.cuda.synchronize()
+acc, cnt = {}, {}
+for (n0, e0), (n1, e1) in zip(marks, marks[1:]):
+    k = n0 + " -> " + n1
+    acc[k] = acc.get(k, 0.0) + e0.elapsed_time(e1) * 1e3; cnt[k] = cnt.get(k, 0) + 1
+tot = 0
+for k in acc:
+    print("%8.1f us  x%d  %s" % (acc[k] / cnt[k], cnt[k], k)); tot += acc[k] / cnt[k]
+print("sum", tot)
+print("use_flags", step.use_flags)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter(); step.run(loader, 100); torch.cuda.synchronize(); print("ms/step unmarked-ish", (time.perf_counter() - t0) * 1e3 / 200)
