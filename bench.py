@@ -20,7 +20,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises: see bliss_gnn_amd/__init__.py
 
 import torch
 import torch.distributed as dist
@@ -62,6 +61,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     force_dist = args.force_dist and world == 1
+    if world > 1 or force_dist:
+        from bliss_gnn_amd.dist import want_hw_queues
+        want_hw_queues()                                  # before the first GPU call of this process
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

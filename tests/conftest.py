@@ -1,8 +1,6 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises: see bliss_gnn_amd/__init__.py
-
 import numpy as np
 import pytest
 import torch
