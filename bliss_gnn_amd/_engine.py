@@ -354,7 +354,10 @@ class LayerEngine:
             # E only sizes launch grids (every kernel strides over the true count): a tight bound lets the hardware balance
             # the workgroups instead of a capped grid looping unevenly
             e = int(min(self.Eg, int(1.5 * max_sizes[n].get("E", self.Eg)) + 65536))
-            caps.append(dict(S=s, C=self.V, K=k, B=b, E=e))
+            # X: how many block edges a multi-GPU step EXCHANGES per block (update lists are sent capacity-sized; B's margin
+            # is for memory that costs nothing, X's for bytes that cross xGMI every step); a longer list is flagged
+            x = int(min(b, int(1.5 * max_sizes[n]["B"]) + 2048))
+            caps.append(dict(S=s, C=self.V, K=k, B=b, E=e, X=x))
             s = k
         self.caps, self.ws = caps, None
         self._ensure(S0, fanouts)
@@ -424,6 +427,7 @@ class LayerEngine:
             blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
             blk._counts, blk._counts_dev = None, cdev
             blk._nnz_ptr = counts_dev.data_ptr() + 40 * n + 16
+            blk._xcap = int(cap.get("X", cap["B"]))
             if t_indptr is not None:
                 blk._transposed = (t_indptr, t_edge)
             blk._trace = {}

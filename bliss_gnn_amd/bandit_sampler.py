@@ -166,12 +166,13 @@ class BanditLadiesSampler(BlockSampler):
         return self._engine.finish(slot, commit)
 
     # -- bandit update ----------------------------------------------------------------------
-    def exp3(self, mfgs, g, apply=True, factors=None):
+    def exp3(self, mfgs, g, apply=True, factors=None, bounds=None):
         """bandit_sampler.py:251-267: rewards + weight update + L1 renormalisation, per block.
 
         ``apply=False`` (multi-GPU replicas, bliss_gnn_amd/dist.py) only computes the rewards and, into
         ``factors[idx]`` (bf16 [B]), the multiplicative updates; ``apply_updates`` then applies every
-        rank's updates in rank order."""
+        rank's updates in rank order.  ``bounds[idx]``: process at most that many edges of block idx (the length of
+        ``factors[idx]``); a longer block is flagged (error bit 8)."""
         self._bind(g)
         st = _stream()
         edge_w_pos = g.edata_by_position(self.edge_weight)
@@ -208,7 +209,7 @@ class BanditLadiesSampler(BlockSampler):
                 mfg.indptr.data_ptr(), mfg.src.data_ptr(), mfg.dst.data_ptr(), mfg.pos.data_ptr(),
                 mfg.edata["q_ij"].data_ptr(), mfg.srcdata[self.node_prob].data_ptr(), en.contiguous().data_ptr(),
                 0 if alpha is None else alpha.data_ptr(), mfg.dstdata[NID].data_ptr(), mfg.num_dst_nodes(),
-                n_edges_ptr, B, self._delta_f, rewards.data_ptr(),
+                n_edges_ptr, B if bounds is None else min(B, int(bounds[idx])), self._delta_f, rewards.data_ptr(),
                 0 if factors is None else factors[idx].data_ptr(), int(apply), self._err.data_ptr(), st), "bliss_exp3_update")
             mfg.edata["rewards"] = rewards                              # :193
             if not apply:

@@ -95,9 +95,10 @@ __device__ __forceinline__ void exp3_update_body(const int64_t* __restrict__ g_i
                                                  const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
                                                  const int* __restrict__ n_edges_dev, float delta_f,
                                                  bf16_t* __restrict__ rewards_out, bf16_t* __restrict__ factor_out,
-                                                 int apply, int* err, int wg, int nwg) {
-  const int B = *n_edges_dev;
+                                                 int apply, int* err, int wg, int nwg, int bound) {
+  int B = *n_edges_dev;
   int bad = 0;
+  if (B > bound) { B = bound; bad |= BLISS_ERR_CAP_EDGES; }        // the caller's arrays end at `bound`
   int64_t dg[3] = {0, 0, 0};
   for (int base = wg * E3_TPB + (threadIdx.x & ~63); base < B; base += nwg * E3_TPB) {
     const int e = base + lane_id();
@@ -143,9 +144,9 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update(const int64_t* __restric
                                                        const bf16_t* __restrict__ alpha_in, const int* __restrict__ dst_nid,
                                                        const int* __restrict__ n_edges_dev, float delta_f,
                                                        bf16_t* __restrict__ rewards_out, bf16_t* __restrict__ factor_out,
-                                                       int apply, int* err) {
+                                                       int apply, int* err, int edges_bound) {
   exp3_update_body(g_indptr, edge_w, w_row, row_sum, blk_indptr, blk_src, blk_dst, blk_pos, q_ij, node_prob, embed_norm, alpha_in,
-                   dst_nid, n_edges_dev, delta_f, rewards_out, factor_out, apply, err, blockIdx.x, gridDim.x);
+                   dst_nid, n_edges_dev, delta_f, rewards_out, factor_out, apply, err, blockIdx.x, gridDim.x, edges_bound);
 }
 
 // all blocks of a step in ONE launch (each launch costs >= 4 us inside a graph; the blocks are independent: every
@@ -162,7 +163,8 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_update_multi(const int64_t* __r
   const bliss_exp3_block_t& k = m.blk[b];
   exp3_update_body(g_indptr, edge_w, (bf16_t*)k.w_pos, k.row_sum, k.blk_indptr, k.blk_src, k.blk_dst, k.blk_pos, (const bf16_t*)k.q_ij,
                    (const bf16_t*)k.node_prob, (const bf16_t*)k.embed_norm, (const bf16_t*)k.alpha_or_null, k.dst_nid, k.n_edges_dev,
-                   delta_f, (bf16_t*)k.rewards_out, nullptr, 1, err, (int)blockIdx.x - m.grid_begin[b], m.grid_begin[b + 1] - m.grid_begin[b]);
+                   delta_f, (bf16_t*)k.rewards_out, nullptr, 1, err, (int)blockIdx.x - m.grid_begin[b], m.grid_begin[b + 1] - m.grid_begin[b],
+                   k.edges_bound);
 }
 
 __global__ void __launch_bounds__(E3_TPB) k_exp3_apply(bf16_t* w_row, int64_t* row_sum, const int* __restrict__ pos,
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_apply_ranks(ApplyLists m, const
     for (int b = 0; b < BLISS_EXP3_MAX_BLOCKS; ++b) {
       if (b >= m.n_blocks) break;
       int n = base[m.cnt_off[b]];
-      if (n > m.bound[b]) n = m.bound[b];
+      if (n > m.bound[b]) { n = m.bound[b]; bad |= BLISS_ERR_CAP_EDGES; }     // that rank's list was cut short: flagged everywhere
       const int* pos = base + m.pos_off[b];
       const bf16_t* fac = reinterpret_cast<const bf16_t*>(base) + m.fac_off[b];
       for (int e = blockIdx.x * E3_TPB + threadIdx.x; e < n; e += G * E3_TPB) {
@@ -393,7 +395,7 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
   PROF_LAUNCH(BK_EXP3_UPDATE, st, k_exp3_update<<<grid, E3_TPB, 0, st>>>(g->indptr, (const bf16_t*)edge_w_pos, (bf16_t*)w_pos, row_sum, blk_indptr,
                                                           blk_src, blk_dst, blk_pos, (const bf16_t*)q_ij, (const bf16_t*)node_prob,
                                                           (const bf16_t*)embed_norm, (const bf16_t*)alpha_or_null, dst_nid,
-                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, (bf16_t*)factor_out, apply, err));
+                                                          n_edges_dev, delta_f, (bf16_t*)rewards_out, (bf16_t*)factor_out, apply, err, edges_bound));
   return (int)hipGetLastError();
 }
 

@@ -91,7 +91,9 @@ def exp3_all_ranks_static(sampler, mfgs, g):
     one collective instead of two per layer is what counts."""
     world = dist.get_world_size()
     L = len(mfgs)
-    caps = [int(m.src.numel()) for m in mfgs]
+    # per block: how many edges are exchanged (the engine's X capacity: tighter than the block's own capacity, these bytes
+    # cross xGMI every step; a block with more edges raises error bit 8 on every rank)
+    caps = [min(int(m.src.numel()), int(getattr(m, "_xcap", m.src.numel()))) for m in mfgs]
     offs = [sum(caps[:i]) for i in range(L)]
     tot = sum(caps)
     n_fac = (tot + 1) // 2                                   # bf16 factors, two per int32 word
@@ -100,10 +102,10 @@ def exp3_all_ranks_static(sampler, mfgs, g):
     buf = torch.empty(n_pad, dtype=torch.int32, device=g.device)
     fac_all = buf[tot:tot + n_fac].view(torch.bfloat16)      # [2 * n_fac] bf16 view of the same storage
     factors = [fac_all[offs[i]:offs[i] + caps[i]] for i in range(L)]
-    sampler.exp3(mfgs, g, apply=False, factors=factors)      # rewards + factors, nothing applied yet
+    sampler.exp3(mfgs, g, apply=False, factors=factors, bounds=caps)      # rewards + factors, nothing applied yet
     # positions and true counts (LayerCounts::B) of all blocks: one multi-tensor copy
     torch._foreach_copy_([buf[offs[i]:offs[i] + caps[i]] for i in range(L)] + [buf[tot + n_fac + i:tot + n_fac + i + 1] for i in range(L)],
-                         [m.pos for m in mfgs] + [m._counts_dev[4:5] for m in mfgs])
+                         [m.pos[:caps[i]] for i, m in enumerate(mfgs)] + [m._counts_dev[4:5] for m in mfgs])
     gath = torch.empty(world * n_pad, dtype=torch.int32, device=g.device)
     dist.all_gather_into_tensor(gath, buf)
     # every rank's lists, rank after rank (rank order on every rank: the rows stay bit-identical), all blocks: ONE launch
