@@ -395,6 +395,16 @@ class LayerEngine:
                                                    self.rng_raw.data_ptr(), self.rng_cap, cd.data_ptr(), cd.numel(),
                                                    counts_host.data_ptr(), _stream()), "bliss_rng_stream_chain")
 
+    def static_rng_record(self, event):
+        """Record ``event`` on the generator's stream, i.e. behind the hand-over kernel of the last static_rng_chain (which
+        wrote that call's counts_host) and the generator it started."""
+        if getattr(self, "_gen_stream", None) is None:
+            h = int(_lib.lib.bliss_rng_stream_handle())
+            if not h:
+                raise RuntimeError("bliss_rng_stream_handle failed")
+            self._gen_stream = torch.cuda.ExternalStream(h)
+        event.record(self._gen_stream)
+
     def static_rng_ready(self):
         _lib.check(_lib.lib.bliss_rng_stream_ready(_stream()), "bliss_rng_stream_ready")
 

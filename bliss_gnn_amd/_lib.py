@@ -119,7 +119,7 @@ SIGNATURES = {
 
 
 SPECIAL_SIGNATURES = ("bliss_prof_kernel_name", "bliss_block_transpose_temp_bytes", "bliss_graph_prepare_capacity",
-                      "bliss_graph_prepare_temp_bytes")   # non-int return types, set in _load()
+                      "bliss_graph_prepare_temp_bytes", "bliss_rng_stream_handle")   # non-int return types, set in _load()
 
 
 def _load():
@@ -137,6 +137,8 @@ def _load():
     for name in ("bliss_graph_prepare_capacity", "bliss_graph_prepare_temp_bytes"):
         getattr(lib, name).argtypes = [_I64, _I32, C.c_int]
         getattr(lib, name).restype = C.c_int64
+    lib.bliss_rng_stream_handle.argtypes = []
+    lib.bliss_rng_stream_handle.restype = C.c_int64
     lib.bliss_prof_kernel_name.argtypes = [C.c_int]
     lib.bliss_prof_kernel_name.restype = C.c_char_p
     assert lib.bliss_layer_counts_bytes() == C.sizeof(LayerCounts), "LayerCounts layout mismatch"

@@ -251,6 +251,16 @@ __device__ __forceinline__ int wave_segment(const int* __restrict__ seg_ptr, int
 // offset into the stream and account for the numbers it will consume.  ctl: [0] progress, [1] stop_at, [2] pos,
 // [3] error, [4] base.  Bounded spin: never hangs the GPU.
 __device__ __forceinline__ void rng_stream_acquire(int* ctl, int C, int* layer_off, int is_last, int cap_total) {
+  // ctl[5] = "this control block belongs to the generator of THIS call": set by whoever initialised it (k_rng_ctl_init on the
+  // consumer's own stream, or k_mt19937_chain on the generator's stream -- then nothing else orders that kernel before this
+  // one), cleared by the call's last layer.  Bounded like the wait below.
+  {
+    long long spins = 0;
+    while (__hip_atomic_load(ctl + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1ll << 22)) { atomicOr(ctl + 3, 2); break; }
+    }
+  }
   const int pos = ctl[2];
   int need = pos + C;
   if (need > cap_total) { need = cap_total; atomicOr(ctl + 3, 1); }
@@ -262,7 +272,10 @@ __device__ __forceinline__ void rng_stream_acquire(int* ctl, int C, int* layer_o
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   *layer_off = ctl[4] + pos;
   ctl[2] = need;
-  if (is_last) __hip_atomic_store(ctl + 1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (is_last) {
+    __hip_atomic_store(ctl + 1, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctl + 5, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Per-layer sizes kept on the device (the S/E/C/K/B symbols of SURVEY.md); layout = the ABI's.

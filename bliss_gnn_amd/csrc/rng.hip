@@ -205,6 +205,7 @@ __global__ void k_rng_ctl_init(int* ctl, const uint32_t* __restrict__ state) {
     if (avail < 0) avail = 0;
     if (avail > MT_N) avail = MT_N;
     ctl[0] = 0; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = MT_N - avail;
+    __hip_atomic_store(ctl + 5, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // see rng_stream_acquire
   }
 }
 
@@ -261,6 +262,8 @@ __global__ void __launch_bounds__(256) k_mt19937_chain(uint32_t* state, int* ctl
     if (a < 0) a = 0;
     if (a > MT_N) a = MT_N;
     ctl[0] = 0; ctl[1] = -1; ctl[2] = 0; ctl[3] = 0; ctl[4] = MT_N - a;
+    // the consumer (next sampler, another stream) starts reading the block once it sees this: no event needed in between
+    __hip_atomic_store(ctl + 5, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -328,6 +331,11 @@ int bliss_rng_stream_chain(void* state, int32_t* ctl, float* out, uint32_t* raw,
   if ((e = hipEventRecord(jn, g_side)) != hipSuccess) return (int)e;
   g_join = jn;
   return (int)hipGetLastError();
+}
+
+int64_t bliss_rng_stream_handle(void) {
+  if (rng_init()) return 0;
+  return (int64_t)(uintptr_t)g_side;
 }
 
 int bliss_rng_stream_ready(void* stream) {

@@ -536,9 +536,10 @@ class PipelinedTrainStep(GraphedTrainStep):
                     eng.static_rng_chain(0, self._ring[(k - 1) % ring][L * 10:])
                 else:
                     eng.static_rng_chain(1, r[:L * 10])
-                eng.static_rng_ready()
-                if cur == 0 and k > 0:                   # main is now ordered after the hand-over that wrote the record
-                    self._ring_ev[(k - 1) % ring].record(main)
+                # (no wait for the hand-over on the main stream: the sampler's first random-number wait checks that the control
+                # block is the new generator's -- the event round trip cost ~12 us between every two steps)
+                if cur == 0 and k > 0:                   # the previous pair's record is complete once that hand-over has run
+                    eng.static_rng_record(self._ring_ev[(k - 1) % ring])
                     pending.append(k - 1)
                 # the sampler that read slot ``cur``'s seed ids finished before this half's forward pass: load the next batch
                 # there, behind the backward pass.  The loader itself works on the main stream (a new epoch shuffles there).

@@ -171,7 +171,7 @@ int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offs
 /* The same generator as ONE streaming kernel per sample_blocks call, on a library-owned side stream, so that the
  * serial MT19937 recurrence overlaps the sampling kernels (eagerly and inside a captured HIP graph):
  *   begin: fork the generator from `stream`; it writes uniforms into out[cap_total + 1248] in stream order, keeps the raw
- *          state blocks in raw[624 * (cap_total / 624 + 3)] and publishes its progress in ctl (int32[8]);
+ *          state blocks in raw[624 * (cap_total / 624 + 3)] and publishes its progress in ctl (int32[8]; [5] = "initialised for the current call");
  *   wait:  (per layer, on `stream`) block `stream` until the next C numbers exist, C = the layer's counts record;
  *          *layer_off = where they start in `out`; is_last tells the generator where to stop;
  *   end:   join, then advance `state` by exactly the number of draws the layers consumed; a stream that ran
@@ -185,11 +185,15 @@ int bliss_rng_stream_end(void* state, const int32_t* ctl, const uint32_t* raw, i
  * stream, ordered after everything enqueued on `stream` so far (the sampler that consumed the numbers).  That kernel also
  * copies the finished call's counts records (counts_dev, n_count_words int32, LayerCounts::err of the first record
  * receives bit 128 as in `end`) to counts_host, which must be pinned, device-visible host memory.  Nothing is enqueued on
- * `stream` except an event record.  `ready`: make `stream` wait until the control block of the generator started by the
- * last `chain` is initialised -- call it before enqueueing the sampler that consumes that generator. */
+ * `stream` except an event record.  The sampler that consumes the new generator needs no ordering after this call: its
+ * first wait (bliss_poisson_select / bliss_rng_stream_wait) also waits for the control block to be the new one (ctl[5]).
+ * `ready` (optional, stricter): make `stream` itself wait until that control block is initialised. */
 int bliss_rng_stream_chain(void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, int32_t* counts_dev,
                            int32_t n_count_words, int32_t* counts_host, void* stream);
 int bliss_rng_stream_ready(void* stream);
+/* The library-owned generator stream as an integer (hipStream_t; created on first use), so that a caller can record an
+ * event behind the kernels `chain` enqueued there -- e.g. to know when counts_host has been written. */
+int64_t bliss_rng_stream_handle(void);
 
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);
