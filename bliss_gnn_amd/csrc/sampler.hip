@@ -720,7 +720,6 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
 }
 
 // ---------------------------------------------------------------- K_h: Poisson scale c  (bandit_sampler.py:391-401)
-#define PS_LIST 4096      // occupied histogram bins k_poisson_scale lists in LDS (24 KiB)
 __device__ __forceinline__ double block_sum_f64(double v, double* shd) {
   for (int d = 32; d >= 1; d >>= 1) {
     long long b = __double_as_longlong(v);
@@ -738,9 +737,6 @@ __device__ __forceinline__ double block_sum_f64(double v, double* shd) {
 __global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps, int* rng_ctl,
                                                         int* layer_off, int is_last, int rng_cap_total, int* __restrict__ sel_state) {
   __shared__ double shd[16];
-  __shared__ int ps_sh[17];
-  __shared__ unsigned short ps_bin[PS_LIST];
-  __shared__ int ps_cnt[PS_LIST];
   const int C = cnt->C;
   // ticket + one status word per 1024-candidate chunk for k_select_fused's look-back
   for (int i = threadIdx.x; i < (C + CHUNK - 1) / CHUNK + 2; i += 1024) sel_state[i] = 0;
@@ -757,43 +753,6 @@ __global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* 
   }
   if (C <= num) {                                     // :392-393 everything is kept
     if (threadIdx.x == 0) { cnt->c = 1.0; cnt->all_one = 1; cnt->iters = 0; }
-    return;
-  }
-  // Only a few hundred of the 32768 bit patterns occur: list the occupied bins once, then ONE wave runs the fixed-point
-  // iterations over that list with wave-level reductions (no workgroup barrier per iteration).  The fp64 sum of
-  // count * bf16 terms is exact, so the order of addition does not change a bit.  (Lists longer than PS_LIST: the
-  // workgroup-wide loop below.)
-  int mine = 0;
-#pragma unroll
-  for (int i = 0; i < HIST_BINS / 1024; ++i) mine += n[i] != 0;
-  int n_occ, at = block_excl_scan(mine, ps_sh, &n_occ);
-  if (n_occ <= PS_LIST) {
-#pragma unroll
-    for (int i = 0; i < HIST_BINS / 1024; ++i)
-      if (n[i]) { ps_bin[at] = (unsigned short)(i * 1024 + threadIdx.x); ps_cnt[at] = n[i]; ++at; }
-    __syncthreads();
-    if (threadIdx.x >= 64) return;                    // (thread 1023 has finished its wait for the random numbers above)
-    double c = 1.0;
-    int it = 0;
-    for (; it < 50; ++it) {                           // :396
-      const float c32 = (float)c;                     // torch multiplies a bf16 tensor by a Python float in fp32
-      double loc = 0;
-      for (int e = threadIdx.x; e < n_occ; e += 64) {
-        float v = rbf(bf2f((bf16_t)ps_bin[e]) * c32);
-        v = v < 1.0f ? v : (v != v ? v : 1.0f);       // torch.minimum propagates NaN
-        loc += (double)ps_cnt[e] * (double)v;         // count * bf16 value: exact in fp64
-      }
-      for (int d = 32; d >= 1; d >>= 1) {             // butterfly: every lane ends with the total
-        const long long b = __double_as_longlong(loc);
-        const int lo = __shfl_xor((int)(b & 0xffffffffll), d), hi = __shfl_xor((int)(b >> 32), d);
-        loc += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-      }
-      const double Ssum = loc;                        // :397
-      const double lo_ = Ssum < (double)num ? Ssum : (double)num, hi_ = Ssum < (double)num ? (double)num : Ssum;
-      if (lo_ / hi_ >= eps) { ++it; break; }          // :398
-      c *= (double)num / Ssum;                        // :401
-    }
-    if (threadIdx.x == 0) { cnt->c = c; cnt->all_one = 0; cnt->iters = it > 50 ? 50 : it; }
     return;
   }
   double c = 1.0;
