@@ -66,6 +66,12 @@ class Exp3RankLists(C.Structure):                      # bliss_exp3_rank_lists_t
                 ("n_blocks", C.c_int32), ("n_ranks", C.c_int32), ("rank_stride_words", C.c_int64)]
 
 
+class PackLists(C.Structure):                          # bliss_pack_lists_t
+    _fields_ = [("pos", C.c_void_p * EXP3_MAX_BLOCKS), ("n_dev", C.c_void_p * EXP3_MAX_BLOCKS),
+                ("pos_off_words", C.c_int32 * EXP3_MAX_BLOCKS), ("count_off_words", C.c_int32 * EXP3_MAX_BLOCKS),
+                ("bound", C.c_int32 * EXP3_MAX_BLOCKS), ("n_blocks", C.c_int32)]
+
+
 class BlockOut(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("pos", C.c_void_p),
                 ("eid", C.c_void_p), ("edge_weights", C.c_void_p), ("q_ij", C.c_void_p), ("t_indptr", C.c_void_p),
@@ -87,6 +93,7 @@ SIGNATURES = {
     "bliss_flag_raise": [_P, _P],
     "bliss_gather_rows": [_P, _I64, _P, _I32, _I32, _P, _I64, _P, _P],
     "bliss_exp3_apply_ranks": [C.POINTER(Exp3RankLists), _P, _P, _P, _P],
+    "bliss_pack_lists": [C.POINTER(PackLists), _P, _P],
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
     "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],

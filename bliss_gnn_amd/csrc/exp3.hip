@@ -261,6 +261,24 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_apply_ranks(ApplyLists m, const
   }
 }
 
+// positions + true counts of all blocks into the packed exchange buffer, ONE launch, only the entries that exist
+struct PackLists {
+  const int* pos[BLISS_EXP3_MAX_BLOCKS];
+  const int* n_dev[BLISS_EXP3_MAX_BLOCKS];
+  int pos_off[BLISS_EXP3_MAX_BLOCKS], cnt_off[BLISS_EXP3_MAX_BLOCKS], bound[BLISS_EXP3_MAX_BLOCKS];
+  int n_blocks;
+};
+__global__ void __launch_bounds__(E3_TPB) k_pack_lists(PackLists m, int* __restrict__ buf) {
+  for (int b = 0; b < m.n_blocks; ++b) {
+    const int n_true = *m.n_dev[b];
+    const int n = n_true < m.bound[b] ? n_true : m.bound[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) buf[m.cnt_off[b]] = n_true;      // uncapped: a list cut short is flagged by the apply
+    const int* __restrict__ src = m.pos[b];
+    int* __restrict__ dst = buf + m.pos_off[b];
+    for (int e = blockIdx.x * E3_TPB + threadIdx.x; e < n; e += gridDim.x * E3_TPB) dst[e] = src[e];
+  }
+}
+
 __global__ void __launch_bounds__(E3_TPB) k_row_sum(const bf16_t* __restrict__ w, int64_t n, int64_t* limbs, int* err) {
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
@@ -438,6 +456,24 @@ int bliss_exp3_apply(void* w_pos, int64_t* row_sum, const int32_t* pos, const vo
   if (grid > 2048) grid = 2048;
   hipStream_t st = (hipStream_t)stream;
   PROF_LAUNCH(BK_EXP3_APPLY, st, k_exp3_apply<<<grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, row_sum, pos, (const bf16_t*)factor, n_dev, err));
+  return (int)hipGetLastError();
+}
+
+int bliss_pack_lists(const bliss_pack_lists_t* lists, int32_t* buf, void* stream) {
+  if (!lists || !buf || lists->n_blocks < 1 || lists->n_blocks > BLISS_EXP3_MAX_BLOCKS) return BLISS_EINVAL;
+  PackLists m;
+  int64_t most = 1;
+  for (int b = 0; b < lists->n_blocks; ++b) {
+    if (!lists->pos[b] || !lists->n_dev[b] || lists->bound[b] < 0) return BLISS_EINVAL;
+    m.pos[b] = lists->pos[b]; m.n_dev[b] = lists->n_dev[b];
+    m.pos_off[b] = lists->pos_off_words[b]; m.cnt_off[b] = lists->count_off_words[b]; m.bound[b] = lists->bound[b];
+    if (lists->bound[b] > most) most = lists->bound[b];
+  }
+  m.n_blocks = lists->n_blocks;
+  int grid = (int)((most + E3_TPB * 4 - 1) / (E3_TPB * 4));
+  if (grid > 512) grid = 512;
+  if (grid < 1) grid = 1;
+  k_pack_lists<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(m, buf);
   return (int)hipGetLastError();
 }
 

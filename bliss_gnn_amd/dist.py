@@ -103,9 +103,15 @@ def exp3_all_ranks_static(sampler, mfgs, g):
     fac_all = buf[tot:tot + n_fac].view(torch.bfloat16)      # [2 * n_fac] bf16 view of the same storage
     factors = [fac_all[offs[i]:offs[i] + caps[i]] for i in range(L)]
     sampler.exp3(mfgs, g, apply=False, factors=factors, bounds=caps)      # rewards + factors, nothing applied yet
-    # positions and true counts (LayerCounts::B) of all blocks: one multi-tensor copy
-    torch._foreach_copy_([buf[offs[i]:offs[i] + caps[i]] for i in range(L)] + [buf[tot + n_fac + i:tot + n_fac + i + 1] for i in range(L)],
-                         [m.pos[:caps[i]] for i, m in enumerate(mfgs)] + [m._counts_dev[4:5] for m in mfgs])
+    # positions and true counts (LayerCounts::B) of all blocks: one launch, only the entries that exist
+    import ctypes as C
+    from . import _lib
+    pk = _lib.PackLists()
+    for i, m in enumerate(mfgs):
+        pk.pos[i], pk.n_dev[i] = m.pos.data_ptr(), m._counts_dev.data_ptr() + 16
+        pk.pos_off_words[i], pk.count_off_words[i], pk.bound[i] = offs[i], tot + n_fac + i, caps[i]
+    pk.n_blocks = L
+    _lib.check(_lib.lib.bliss_pack_lists(C.byref(pk), buf.data_ptr(), torch.cuda.current_stream().cuda_stream), "bliss_pack_lists")
     gath = torch.empty(world * n_pad, dtype=torch.int32, device=g.device)
     dist.all_gather_into_tensor(gath, buf)
     # every rank's lists, rank after rank (rank order on every rank: the rows stay bit-identical), all blocks: ONE launch

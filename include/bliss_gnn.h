@@ -311,6 +311,17 @@ typedef struct {
 } bliss_exp3_rank_lists_t;
 int bliss_exp3_apply_ranks(const bliss_exp3_rank_lists_t* lists, const int32_t* gathered, int32_t* barrier, int32_t* err, void* stream);
 
+/* Fill one rank's packed buffer for that exchange in ONE launch: for every block the first min(*n_dev[b], bound[b])
+ * positions (blk_pos) go to buf + pos_off_words[b], the true count *n_dev[b] to buf[count_off_words[b]] (the factors are
+ * written in place by bliss_exp3_update's factor_out). */
+typedef struct {
+  const int32_t* pos[BLISS_EXP3_MAX_BLOCKS];
+  const int32_t* n_dev[BLISS_EXP3_MAX_BLOCKS];
+  int32_t pos_off_words[BLISS_EXP3_MAX_BLOCKS], count_off_words[BLISS_EXP3_MAX_BLOCKS], bound[BLISS_EXP3_MAX_BLOCKS];
+  int32_t n_blocks;
+} bliss_pack_lists_t;
+int bliss_pack_lists(const bliss_pack_lists_t* lists, int32_t* buf, void* stream);
+
 /* F.normalize(row, p=1, dim=0), bandit_sampler.py:249, bit-exact: norm = bf16(exact sum).  The pass
  * over the row is skipped on the device when norm == 1.0 (x / 1.0 == x).  scratch: int64[BLISS_NORM_SCRATCH], zero-initialised
  * once by the caller and left zero ([0] afterwards holds norm bits | skip << 16 | err << 20). */
