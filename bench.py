@@ -6,9 +6,12 @@ One *step* = sample_blocks (3 layers) + feature gather + SAGE forward + backward
 Reddit-shaped synthetic graph, 3-layer SAGE, poisson-bandit sampler, fanouts 4096/2048/1024, batch 256.
 Synthetic data (no network): seeded Chung-Lu graph with Reddit's |V|, |E|, F, classes.
 
-    python bench.py --gpus N --steps K --warmup W      (N > 1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, every rank holds a replica of the graph
+N > 1: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment, as the driver
+does), or started plainly -- then this process starts N fresh ranks itself (a child ``python -m torch.distributed.run``,
+before anything here has touched the GPU) and exits with the child's code.  ``--gpus`` that disagrees with WORLD_SIZE is
+an error.  Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, every rank holds a replica of the graph
 and samples its own batch (weak scaling); gradients are all-reduced over RCCL and the EXP3 updates are
 all-gathered so that the bandit state stays identical on every rank.
 """
@@ -28,8 +31,9 @@ import torch.distributed as dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400,
+                    help="timed steps; the default window is long enough to contain the occasional EXP3 renormalisation passes")
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="reddit", choices=["cora", "pubmed", "reddit", "yelp"])
     ap.add_argument("--sampler", default="poisson-bandit", choices=["poisson-bandit", "poisson-ladies"],
                     help="train_lightning.py:536-540; poisson-ladies = the static-weight baseline sampler (no EXP3 update)")
@@ -42,7 +46,53 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: run the replica exchange path (gradient all-reduce, EXP3 all-gather + apply) on a world of "
                          "one rank -- what the multi-GPU step costs per GPU before any communication time")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction plumbing only (gloo, no GPU, no kernels): what a CPU-only box can check of --gpus N")
     return ap.parse_args()
+
+
+def relaunch_ranks(args):
+    """--gpus N > 1 without a launcher: start N ranks as a CHILD process tree (never re-exec: nothing here has touched the
+    GPU yet, and nothing will in this parent) and exit with its code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """No GPU: every rank joins a gloo group, 'steps' are empty, the timing reduction and the JSON line are the real ones."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    t1 = time.perf_counter()
+    dt = time.perf_counter() - t1 + 1e-9
+    t = torch.tensor([dt, float(rank)], dtype=torch.float64)
+    ranks = [rank]
+    if world > 1:
+        dist.barrier()
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        ranks, dt = [int(x) for x in got], float(tmax[0])
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no kernels)", "value": None, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "ranks": ranks, "scaling": "weak"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def percentiles(xs):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    q = lambda f: xs[min(len(xs) - 1, max(0, int(round(f * (len(xs) - 1)))))]
+    return {"p10": q(0.10), "median": q(0.50), "p90": q(0.90), "min": xs[0], "max": xs[-1], "n": len(xs)}
 
 
 def algorithmic_bytes(sizes, feat, dims):
@@ -57,9 +107,16 @@ def algorithmic_bytes(sizes, feat, dims):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus, or without a "
+                         "launcher)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     force_dist = args.force_dist and world == 1
     if world > 1 or force_dist:
         from bliss_gnn_amd.dist import want_hw_queues
@@ -136,18 +193,21 @@ def main():
                 raise
             print("rank %d: graph capture failed (%r); falling back to the eager step" % (rank, e), file=sys.stderr)
             graphed, step = False, None
-            sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000, eta=eta,
-                                                    model="sage")
+            if args.sampler == "poisson-ladies":
+                sampler = bg.PoissonLadiesSampler(fan)
+            else:
+                sampler = bg.PoissonBanditLadiesSampler(fan, importance_sampling=1, node_embedding="features", num_steps=3000,
+                                                        eta=eta, model=args.model)
     if not graphed:
         step = TrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"], grad_sync=grad_sync, exp3_sync=exp3_sync)
     pipelined = isinstance(step, PipelinedTrainStep)
 
-    def advance(n, eager=False):
+    def advance(n, eager=False, pair_events=None):
         """Run exactly n train steps; returns the per-step block sizes (one list per sampled batch)."""
         sizes = []
         while n > 0:
             if pipelined and n >= 2 and not eager:
-                sizes += step.run(loader, n // 2)
+                sizes += step.run(loader, n // 2, pair_events=pair_events)
                 n -= n // 2 * 2
             elif pipelined and n >= 2:
                 step.eager_pair(loader)
@@ -170,10 +230,15 @@ def main():
 
     advance(args.warmup)
     sync()
+    pair_events = [] if pipelined else None
     t1 = time.perf_counter()
-    all_sizes = advance(args.steps)
+    all_sizes = advance(args.steps, pair_events=pair_events)
     sync()
     dt = time.perf_counter() - t1
+    # per-step device time: differences of timing events recorded on the critical stream at every pair boundary (two steps)
+    step_ms = []
+    if pair_events:
+        step_ms = [0.5 * a.elapsed_time(b) for a, b in zip(pair_events[:-1], pair_events[1:])]
     n_edges = sum(x["B"] for sz in all_sizes for x in sz)
     n_frontier = sum(x["E"] for sz in all_sizes for x in sz)
     sizes_acc = [{k: sum(sz[l][k] for sz in all_sizes) for k in all_sizes[0][l]} for l in range(len(all_sizes[0]))]
@@ -188,11 +253,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline:
         torch.cuda.synchronize()
         timer.enable("all")
-        advance(6, eager=True)
+        calib_sizes = advance(6, eager=True)
         torch.cuda.synchronize()
         calib = timer.read()
+        # every library kernel with an algorithmic-byte model, the random-number generator included (one launch per step)
         hbm_kernels = {k: v for k, v in calib.items()
-                       if roofline.algorithmic_bytes(k, dict(S=1, E=1, C=1, K=1, B=1), [1, 1, 1], 0) and k != "k_mt19937_uniform"}
+                       if roofline.algorithmic_bytes(k, dict(S=1, E=1, C=1, K=1, B=1), [1, 1, 1], 0)}
+        for k, v in hbm_kernels.items():
+            tot = sum(roofline.algorithmic_bytes(k, s_, dims, l) for sz in calib_sizes for l, s_ in enumerate(sz))
+            v["alg_bytes_per_launch"] = tot / max(v["launches"], 1)
+            v["GBps"] = v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
         dominant = max(hbm_kernels, key=lambda k: hbm_kernels[k]["total_ms"])
         timer.enable(dominant)                       # only this kernel carries events now
         n_dom = min(args.steps, 30) // 2 * 2
@@ -224,6 +294,10 @@ def main():
         "sizes_per_step": mean_sizes, "algorithmic_bytes_per_step": alg,
         "algorithmic_GBps": alg["total"] * (args.steps / dt) / 1e9, "frac_of_8TBps": alg["total"] * (args.steps / dt) / 8e12,
         "setup_s": t_setup,
+        # `value` is the mean over the whole timed window (EXP3 renormalisation passes included when they fall into it);
+        # the distribution of the per-step device time over the same window, from events at every two-step boundary:
+        "value_is": "mean over %d consecutive steps" % args.steps,
+        "step_ms_percentiles": percentiles(step_ms),
     }
 
     if dom_timing:
@@ -240,7 +314,10 @@ def main():
                 want = "true>" if dominant == "k_spmm_bwd" else "false>"
                 rows = [v for k, v in raw.items() if k.startswith("k_spmm<") and k.endswith(want)]
             else:
-                rows = [v for k, v in raw.items() if k.split("<")[0] == dominant]
+                # timer id -> profiler symbol where the two differ
+                sym = {"k_mt19937_uniform": "k_mt19937_stream", "k_select_pass2": "k_select_fused", "k_bitmap_scan": "k_bitmap_tiles",
+                       "k_indptr_scan": "k_block_scans", "k_block_transpose": "k_tr_sort_lists"}.get(dominant, dominant)
+                rows = [v for k, v in raw.items() if k.split("<")[0] == sym]
             if rows:
                 # KiB counters; FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B tallied per 128-B request on gfx950);
                 # launch-weighted mean over the instantiations
@@ -253,11 +330,22 @@ def main():
                            "measured_over": "%d kernel-by-kernel runs of the same step right after the timed region" % n_dom,
                            "algorithmic_bytes_per_launch": per_launch,
                            "kernel_time_share_in_calibration": {k: round(v["total_ms"] / max(sum(x["total_ms"] for x in calib.values()), 1e-9), 4)
-                                                                for k, v in sorted(calib.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}}
+                                                                for k, v in sorted(calib.items(), key=lambda kv: -kv[1]["total_ms"])[:8]},
+                           # the other library kernels of the step, same definition (HIP events, kernel-by-kernel launches)
+                           "all_kernels": {k: {"avg_launch_us": round(v["avg_us"], 2), "launches_per_step": round(v["launches"] / 6.0, 2),
+                                               "algorithmic_bytes_per_launch": round(v["alg_bytes_per_launch"]),
+                                               "achieved_GBps": round(v["GBps"], 1), "frac": round(v["GBps"] / roofline.HBM_PEAK_GBPS, 5)}
+                                           for k, v in sorted(hbm_kernels.items(), key=lambda kv: -kv[1]["total_ms"])}}
     if rank == 0 and world == 1 and args.cpu_baseline_steps != 0:
         out["cpu_baseline"] = cpu_baseline(g, feats, labels, train_nid, cfg, fan, eta, hidden, args.cpu_baseline_steps)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    # teardown in dependency order: the batch in flight, every stream of the loop, the captured graphs (they hold RCCL
+    # nodes), only then the communicator -- graphs that outlive it abort the process at exit
+    if hasattr(step, "close"):
+        step.close()
+    del step
+    torch.cuda.synchronize()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

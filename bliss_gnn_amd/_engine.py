@@ -226,11 +226,12 @@ class LayerEngine:
         return self._finish(out, cnts)
 
     # ------------------------------------------------------------------ non-Poisson samplers (multinomial draw)
-    def sample_blocks_multinomial(self, w_rows, seeds, fanouts, mode, eta, replace=False):
+    def sample_blocks_multinomial(self, w_rows, seeds, fanouts, mode, eta, replace=False, fp32_importance=False):
         """BanditLadiesSampler / LadiesSampler (bandit_sampler.py:84-99, ladies_sampler.py:54-69): the node importances
         are computed on the device; the draw is ``torch.multinomial`` itself, on the host, on those bits (ATen's CPU
         kernel takes its exponentials from an MKL stream seeded by the global generator -- there is nothing to restate),
-        so this path syncs once per layer like the reference does."""
+        so this path syncs once per layer like the reference does.  ``fp32_importance``: hand the draw fp32 importances
+        (LadiesSampler's non-importance branch builds fp32 ones, ladies_sampler.py:50; ATen draws in the input's dtype)."""
         seeds = seeds.to(torch.int32).contiguous()
         L = len(fanouts)
         self._ensure(int(seeds.numel()), fanouts)
@@ -259,6 +260,8 @@ class LayerEngine:
                 torch.cuda.current_stream().synchronize()
                 Cn = int(self.counts_host[10 * n + 2])
                 prob = self.ws[n].p[:Cn].cpu()
+                if fp32_importance:
+                    prob = prob.float()
                 chosen = torch.multinomial(prob, min(int(fanouts[n]), Cn), replacement=replace)        # bandit_sampler.py:98
                 chosen_dev = chosen.to(torch.int32).to(dev)
                 _lib.check(_lib.lib.bliss_multinomial_select(C.byref(c_ws), chosen_dev.data_ptr(), int(chosen_dev.numel()), st),

@@ -245,7 +245,13 @@ __global__ void __launch_bounds__(E3_TPB) k_exp3_apply_ranks(ApplyLists m, const
       __syncthreads();
       if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (r + 1) * G) __builtin_amdgcn_s_sleep(2);
+        // bounded like every other device-side wait here (k_flag_wait, rng_stream_acquire): a workgroup that never arrives
+        // (the grid not co-resident after all) flags the step invalid instead of hanging the GPU
+        long long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (r + 1) * G) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1ll << 24)) { bad |= BLISS_ERR_FLAG_TIMEOUT; break; }
+        }
       }
       __syncthreads();
     }
@@ -492,7 +498,19 @@ int bliss_exp3_apply_ranks(const bliss_exp3_rank_lists_t* lists, const int32_t* 
   }
   m.n_blocks = lists->n_blocks; m.n_ranks = lists->n_ranks; m.rank_stride = lists->rank_stride_words;
   int grid = (int)((most + E3_TPB - 1) / E3_TPB);
-  if (grid > APPLY_MAX_WGS) grid = APPLY_MAX_WGS;      // all workgroups must be resident together (grid barrier)
+  // all workgroups must be resident together (grid barrier): at most a quarter of what the device can hold of this kernel
+  // (the loop's other streams keep CUs busy beside it), never more than APPLY_MAX_WGS
+  static int resident_cap = 0;
+  if (!resident_cap) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_exp3_apply_ranks, E3_TPB, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      return BLISS_EINVAL;
+    long long cap = (long long)per_cu * prop.multiProcessorCount / 4;
+    resident_cap = (int)(cap < 1 ? 1 : (cap > APPLY_MAX_WGS ? APPLY_MAX_WGS : cap));
+  }
+  if (grid > resident_cap) grid = resident_cap;
   k_exp3_apply_ranks<<<grid, E3_TPB, 0, (hipStream_t)stream>>>(m, gathered, barrier, err);
   return (int)hipGetLastError();
 }

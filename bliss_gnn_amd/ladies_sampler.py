@@ -28,7 +28,8 @@ class LadiesSampler(BlockSampler):
         self._engine = None
 
     def _mode(self):
-        # (the reference's non-importance branch builds an fp32 ``ones`` for ladies, ladies_sampler.py:50; bf16 here)
+        # (the reference's non-importance branch builds fp32 ones, ladies_sampler.py:50: 0 / 1 are the same numbers in bf16 on
+        # the device; the host draw of the multinomial variant gets them as fp32, see sample_blocks)
         return _lib.MODE_LADIES | (0 if self.importance_sampling else _lib.MODE_UNIFORM_NODES)
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
@@ -41,7 +42,8 @@ class LadiesSampler(BlockSampler):
         if self._poisson:
             blks = self._engine.sample_blocks([w_pos] * len(order), seed_nodes, fan, self._mode(), 0.0, self.eps, uniforms)
         else:                                                            # select_neighbors :54-69 (torch.multinomial)
-            blks = self._engine.sample_blocks_multinomial([w_pos] * len(order), seed_nodes, fan, self._mode(), 0.0, self.replace)
+            blks = self._engine.sample_blocks_multinomial([w_pos] * len(order), seed_nodes, fan, self._mode(), 0.0, self.replace,
+                                                          fp32_importance=not self.importance_sampling)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights            # :100

@@ -230,6 +230,27 @@ class GraphedTrainStep:
         """Per block (input-most first): the true S, E, C, K, B of the last step."""
         return [dict(S=c.S, E=c.E, C=c.C, K=c.K, B=c.B) for c in reversed(self.last_counts)]
 
+    def _graph_attrs(self):
+        return ("graph",)
+
+    def close(self):
+        """Quiesce the device and destroy the captured graphs NOW.  A distributed run must call this before
+        ``destroy_process_group()``: the graphs hold RCCL nodes, and graphs that outlive their communicator (destroyed at
+        interpreter exit, after the process group) abort the process."""
+        import gc
+        torch.cuda.synchronize()
+        for name in self._graph_attrs():
+            v = getattr(self, name, None)
+            if isinstance(v, list):
+                setattr(self, name, [None] * len(v))
+            elif v is not None:
+                setattr(self, name, None)
+        self.loss = None
+        if hasattr(self, "losses"):
+            self.losses = None
+        gc.collect()
+        torch.cuda.synchronize()
+
 
 class PipelinedTrainStep(GraphedTrainStep):
     """Two train steps per call, software-pipelined: while the backward pass and Adam of batch ``a`` run on one stream,
@@ -494,11 +515,13 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._finish_pair()
         return self.losses
 
-    def run(self, loader, n_pairs, ring=4):
+    def run(self, loader, n_pairs, ring=4, pair_events=None):
         """``n_pairs`` calls without a host round trip in between: the generator state is chained on the device from
         batch to batch (torch's CPU generator is brought up to date once, at the end), and sizes / error words come back
         through a small ring of pinned buffers while later pairs are already running.  Returns the block sizes of every
-        batch sampled, in order."""
+        batch sampled, in order.  ``pair_events``: a list that receives one timing event per pair boundary (recorded on
+        the critical stream at the start of every pair and after the last one): consecutive differences are the device
+        time of two train steps each."""
         eng = self.sampler._engine
         L = len(self.sampler.nodes_per_layer)
         if getattr(self, "_ring", None) is None or len(self._ring) != ring:
@@ -527,6 +550,10 @@ class PipelinedTrainStep(GraphedTrainStep):
         for k in range(n_pairs):
             while pending and pending[0] <= k - ring:    # this pair reuses that pair's record
                 collect(pending.pop(0) % ring)
+            if pair_events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(main)
+                pair_events.append(ev)
             last = k == n_pairs - 1
             r = self._ring[k % ring]
             for cur, nxt in ((0, 1), (1, 0)):
@@ -557,6 +584,10 @@ class PipelinedTrainStep(GraphedTrainStep):
                 eng.static_rng_end(0)
                 r[L * 10:].copy_(eng._slot_counts[0], non_blocking=True)
                 self._join()
+                if pair_events is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(main)
+                    pair_events.append(ev)
                 self._ring_ev[k % ring].record(main)
                 pending.append(k)
         for i in pending:
@@ -588,6 +619,18 @@ class PipelinedTrainStep(GraphedTrainStep):
         main.synchronize()
         self.num_steps += 1
         return loss.detach()
+
+    def _graph_attrs(self):
+        return ("graph", "g_main", "g_fwd", "g_bwd", "g_smp", "g_blk")
+
+    def close(self):
+        """Train the batch still in flight (``drain``), wait for every stream of the loop, then destroy the graphs."""
+        if self.graph and self.mfgs[0] is not None:
+            self.drain()
+        for st in (self.side, self.third):
+            st.synchronize()
+        super().close()
+        self.mfgs = [None, None]
 
     def sizes2(self):
         """sizes() for each of the two batches sampled by the last call."""

@@ -120,18 +120,19 @@ def bandit_case(name, indptr, indices, eid, seeds_per_step, fanouts, eta, torch_
     print("wrote", name, {k: v.shape for k, v in list(out.items())[:0]})
 
 
-def ladies_case(name, indptr, indices, eid, seeds, fanouts, torch_seed, poisson=True):
+def ladies_case(name, indptr, indices, eid, seeds, fanouts, torch_seed, poisson=True, importance_sampling=True):
     g = ref_graph(indptr, indices, eid)
     og = bo.CSC(indptr, indices, eid)
     cls = ref_ladies.PoissonLadiesSampler if poisson else ref_ladies.LadiesSampler
-    sampler = cls(fanouts)
+    sampler = cls(fanouts, importance_sampling=importance_sampling)
     edge_w = bo.normalized_edata(og)
     out = dict(indptr=indptr.numpy(), indices=indices.numpy(), eid=eid.numpy(), fanouts=np.array(fanouts),
-               torch_seed=np.array(torch_seed), seeds=seeds.numpy(), edge_w=bits(edge_w), poisson=np.array(int(poisson)))
+               torch_seed=np.array(torch_seed), seeds=seeds.numpy(), edge_w=bits(edge_w), poisson=np.array(int(poisson)),
+               importance_sampling=np.array(int(importance_sampling)))
     torch.manual_seed(torch_seed)
     inp, outp, mfgs = sampler.sample_blocks(g, seeds)
     torch.manual_seed(torch_seed)
-    o_inp, _, o_blocks = bo.sample_blocks_ladies(og, seeds, fanouts, edge_w, poisson=poisson)
+    o_inp, _, o_blocks = bo.sample_blocks_ladies(og, seeds, fanouts, edge_w, poisson=poisson, importance_sampling=importance_sampling)
     assert torch.equal(o_inp, inp.long())
     for l, (b, ob) in enumerate(zip(mfgs, o_blocks)):
         check_block(ob, b, False, f"{name} layer{l}")
@@ -166,6 +167,9 @@ def main():
     bandit_case("synth0_bandit_multinomial", ip, ix, ei, steps, [40, 20, 10], 0.1, 300, poisson=False)
     bandit_case("synth0_poisson_bandit_uniform_nodes", ip, ix, ei, steps, [40, 20, 10], 0.1, 302, importance_sampling=0)
     ladies_case("synth0_ladies_multinomial", ip, ix, ei, steps[0], [40, 20, 10], 301, poisson=False)
+    # LadiesSampler(importance_sampling=False), ladies_sampler.py:49-51: fp32 ones as importances (unreachable from the CLI,
+    # train_lightning.py:360 passes only the fanouts; CPU tensors only -- torch.ones(...) there has no device)
+    ladies_case("synth0_ladies_multinomial_uniform_nodes", ip, ix, ei, steps[0], [40, 20, 10], 303, poisson=False, importance_sampling=False)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,7 @@ def test_poisson_ladies_golden(cuda, name):
     (20000, 400000, [1024, 512, 256], 128, 0.1, 1),
     (5000, 15000, [4096, 2048, 1024], 64, 0.4, 2),       # fanout > candidates: the C <= fanout early-out
     (50000, 2000000, [2048, 1024, 512], 256, 0.1, 3),    # long columns, many waves per destination
+    (19717, 88651, [512, 256, 128], 32, 0.1, 4),         # BASELINE config 2 at full size (Pubmed-like); the scale loop hits its 50-iteration cap
 ])
 def test_bandit_vs_oracle_random_graphs(cuda, V, E, fan, batch, eta, seed):
     """Three consecutive train steps on seeded graphs the oracle finishes in seconds: ids, probabilities,
@@ -643,7 +644,8 @@ def test_multinomial_samplers_golden(cuda, name):
             sampler.exp3(blocks, g)
             assert np.array_equal(z[f"s{step}_exp3_weights"], bf16_bits(sampler.exp3_weights))
     else:
-        sampler = bg.LadiesSampler(fan)
+        # (..._uniform_nodes: LadiesSampler(importance_sampling=False), ladies_sampler.py:49-51 -- fp32 ones as importances)
+        sampler = bg.LadiesSampler(fan, importance_sampling=bool(int(z["importance_sampling"])) if "importance_sampling" in z else True)
         torch.manual_seed(seed)
         _, _, blocks = sampler.sample_blocks(g, torch.from_numpy(z["seeds"]).to(cuda))
         for l, blk in enumerate(blocks):
@@ -964,19 +966,22 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             assert torch.equal(pa, pb)
 
 
-def test_apply_ranks_matches_sequential_applies(cuda):
+@pytest.mark.parametrize("V,n_edges,R,bounds", [(2000, 30001, 4, [20000, 9000]),
+                                                # lists longer than the grid cap (256 workgroups x 256 threads): every workgroup
+                                                # strides, the grid barrier runs with the full resident grid, 8 ranks
+                                                (30000, 400001, 8, [70000, 30000]),
+                                                (30000, 400001, 2, [66000, 66000])])
+def test_apply_ranks_matches_sequential_applies(cuda, V, n_edges, R, bounds):
     """bliss_exp3_apply_ranks (the update lists of all ranks and blocks in one launch, grid barrier between ranks) leaves
     the bits of the same lists applied one bliss_exp3_apply at a time in rank order: positions repeated across ranks,
     neighbouring positions (two bf16 share a 32-bit word), an odd row length (second row starts mid-word), short counts."""
     from oracle import bliss_oracle as bo
     bg = _bg()
     gen = torch.Generator().manual_seed(11)
-    V = 2000
-    og = bo.prepare_graph(torch.randint(0, V, (30001,), generator=gen), torch.randint(0, V, (30001,), generator=gen), V)
+    og = bo.prepare_graph(torch.randint(0, V, (n_edges,), generator=gen), torch.randint(0, V, (n_edges,), generator=gen), V)
     E = og.num_edges
     g = bg.Graph(og.indptr.to(cuda), og.indices.to(cuda), og.eid.to(cuda))
     w0 = (torch.rand(2, E, generator=gen) * 1e-3 + 1e-6).bfloat16()
-    R, bounds = 4, [20000, 9000]
     offs, tot = [0, bounds[0]], sum(bounds)
     n_fac = (tot + 1) // 2
     n_pad = (tot + n_fac + 2 + 3) // 4 * 4
@@ -1343,6 +1348,43 @@ def test_sage_epilogue_kernel(cuda):
     assert torch.equal(ar.grad.view(torch.int16), want.view(torch.int16)) and torch.equal(br.grad, ar.grad)
 
 
+_FULL = {}
+
+
+def _full_size_csc(name, cuda):
+    """The full-size synthetic graph of a BASELINE config, generated once per test session (Reddit-like: ~114 M edges)."""
+    from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc
+    if name not in _FULL:
+        cfg = CONFIGS[name]
+        _FULL.clear()                                                            # one resident graph at a time
+        _FULL[name] = chung_lu_csc(cfg["num_nodes"], cfg["num_edges"], seed=0, device=cuda)
+    return _FULL[name]
+
+
+def _check_block_invariants(bg, g, blocks, cuda):
+    """Size-independent structure of one sample_blocks result: every block is a CSR by destination in frontier order whose
+    edges exist in the graph (pos -> indices, inside the seed's column), sources numbered once and consistently (seeds
+    first, P = 1 for seeds), a layer's seeds = the previous layer's kept nodes."""
+    seeds_l = None
+    for b in reversed(blocks):                                       # sampling order: output-most block first
+        S, K, B = b.num_dst_nodes(), b.num_src_nodes(), b.num_edges()
+        nid = b.srcdata[bg.NID].long()
+        assert B == int(b.indptr[-1]) and bool((b.indptr[1:] >= b.indptr[:-1]).all())
+        assert bool((b.dst[1:] >= b.dst[:-1]).all()) and int(b.src.max()) < K
+        assert torch.equal(b.dst.long(), torch.repeat_interleave(torch.arange(S, device=cuda), (b.indptr[1:] - b.indptr[:-1]).long()))
+        pos = b.pos.long()
+        assert torch.equal(g.indices[pos].long(), nid[b.src.long()])                    # the edge exists, source id right
+        col = nid[b.dst.long()]
+        assert bool(((pos >= g.indptr[col]) & (pos < g.indptr[col + 1])).all())          # in the seed's CSC column
+        assert bool((pos[1:] > pos[:-1])[b.dst[1:] == b.dst[:-1]].all())                 # frontier order inside a column
+        assert nid.unique().numel() == K                                                # sources numbered once
+        if seeds_l is not None:
+            assert torch.equal(nid[:S], seeds_l)                                        # this layer's seeds = previous kept nodes
+        if "node_prob" in b.srcdata:
+            assert bool((b.srcdata["node_prob"][:S].view(torch.int16) == 0x3F80).all())     # P = 1 for seeds
+        seeds_l = nid
+
+
 def test_full_size_properties_reddit_like(cuda, monkeypatch):
     """BASELINE config 3 at full size (|V| = 232,965, |E| ~ 114 M, batch 256, fanouts 4096/2048/1024), where the oracle is
     too slow: size-independent properties of two consecutive steps --
@@ -1352,10 +1394,10 @@ def test_full_size_properties_reddit_like(cuda, monkeypatch):
       * the incrementally maintained exact row sums equal a from-scratch exact sum of the weight rows after the update,
       * torch's CPU generator advanced by exactly sum(C) draws."""
     from bliss_gnn_amd import _lib
-    from bliss_gnn_amd.synth import CONFIGS, chung_lu_csc
+    from bliss_gnn_amd.synth import CONFIGS
     bg = _bg()
     cfg = CONFIGS["reddit"]
-    ip, ix, ei = chung_lu_csc(cfg["num_nodes"], cfg["num_edges"], seed=0, device=cuda)
+    ip, ix, ei = _full_size_csc("reddit", cuda)
     gen = torch.Generator().manual_seed(1)
     batches = [torch.randperm(cfg["num_nodes"], generator=gen)[:cfg["batch"]].to(torch.int32).to(cuda) for _ in range(2)]
     results = []
@@ -1385,23 +1427,7 @@ def test_full_size_properties_reddit_like(cuda, monkeypatch):
         if bins == "1":
             assert sampler._engine.n_bins > 0
             for blocks in steps:
-                seeds_l = None
-                for b in reversed(blocks):                                       # sampling order: output-most block first
-                    S, K, B = b.num_dst_nodes(), b.num_src_nodes(), b.num_edges()
-                    nid = b.srcdata[bg.NID].long()
-                    assert B == int(b.indptr[-1]) and bool((b.indptr[1:] >= b.indptr[:-1]).all())
-                    assert bool((b.dst[1:] >= b.dst[:-1]).all()) and int(b.src.max()) < K
-                    assert torch.equal(b.dst.long(), torch.repeat_interleave(torch.arange(S, device=cuda), (b.indptr[1:] - b.indptr[:-1]).long()))
-                    pos = b.pos.long()
-                    assert torch.equal(g.indices[pos].long(), nid[b.src.long()])                    # the edge exists, source id right
-                    col = nid[b.dst.long()]
-                    assert bool(((pos >= g.indptr[col]) & (pos < g.indptr[col + 1])).all())          # in the seed's CSC column
-                    assert bool((pos[1:] > pos[:-1])[b.dst[1:] == b.dst[:-1]].all())                 # frontier order inside a column
-                    assert nid.unique().numel() == K                                                # sources numbered once
-                    if seeds_l is not None:
-                        assert torch.equal(nid[:S], seeds_l)                                        # this layer's seeds = previous kept nodes
-                    assert bool((b.srcdata["node_prob"][:S].view(torch.int16) == 0x3F80).all())     # P = 1 for seeds
-                    seeds_l = nid
+                _check_block_invariants(bg, g, blocks, cuda)
             for l in range(3):                                                   # exact incremental row sum == from-scratch exact sum
                 fresh = torch.zeros(96, dtype=torch.int64, device=cuda)
                 _lib.check(_lib.lib.bliss_row_sum(sampler._w_pos[l].data_ptr(), g.num_edges(), fresh.data_ptr(), 0), "row_sum")
@@ -1415,3 +1441,70 @@ def test_full_size_properties_reddit_like(cuda, monkeypatch):
             assert torch.equal(a.edata["edge_weights"].view(torch.int16), b.edata["edge_weights"].view(torch.int16))
             assert torch.equal(a.edata["rewards"].view(torch.int16), b.edata["rewards"].view(torch.int16))
     assert torch.equal(sam_a._w_pos.view(torch.int16), sam_b._w_pos.view(torch.int16))
+
+
+def _static_vs_exact_step(bg, cuda, name, make_model, model_kind, multilabel):
+    """One train step on capacity-padded (static-shape) blocks vs the same step on exact-size blocks, full-size graph:
+    same loss bits, same EXP3 rows, same generator state; block invariants; finite gradients."""
+    from bliss_gnn_amd.synth import CONFIGS, node_data
+    from bliss_gnn_amd.train import BatchLoader, GraphedTrainStep, TrainStep
+    cfg = CONFIGS[name]
+    ip, ix, ei = _full_size_csc(name, cuda)
+    feats, labels, train_nid = node_data(cfg["num_nodes"], cfg["feat"], cfg["classes"], cfg["n_train"], seed=1, device=cuda,
+                                         multilabel=multilabel)
+    outs = []
+    for static in (False, True):
+        g = bg.Graph(ip, ix, ei, ndata={"features": feats, "labels": labels})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler(cfg["fanouts"], importance_sampling=1, node_embedding="features", eta=0.1, model=model_kind)
+        torch.manual_seed(0)
+        model = make_model(cfg).to(cuda).bfloat16()
+        loader = BatchLoader(train_nid, cfg["batch"], seed=5).forever()
+        torch.manual_seed(9)
+        if static:
+            step = GraphedTrainStep(g, sampler, model, cfg["batch"], multilabel=multilabel)
+            step.calibrate(loader, steps=3)
+            loss = step.eager_step(next(loader))
+            sizes = step.sizes()
+        else:
+            for _ in range(3):
+                sampler.sample_blocks(g, next(loader))
+            step = TrainStep(g, sampler, model, multilabel=multilabel)
+            loss = step(next(loader))
+            blocks = step.last["mfgs"]
+            _check_block_invariants(bg, g, blocks, cuda)
+            for l, b in enumerate(blocks):
+                assert b.srcdata["embed_norm"].shape == (b.num_src_nodes(),) and b.edata["rewards"].shape == (b.num_edges(),)
+                assert bool(torch.isfinite(b.edata["rewards"].float()).all())
+                if model_kind == "gat":
+                    assert b.edata["a_ij"].shape == (b.num_edges(),)                   # head-mean pre-softmax logits, model.py:224-227
+            assert step.last["pred"].shape == (cfg["batch"], cfg["classes"])
+            assert all(bool(torch.isfinite(p.grad.float()).all()) for p in model.parameters() if p.grad is not None)
+            sizes = [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in blocks]
+        sampler.check_errors()
+        assert float(loss) == float(loss)
+        w = sampler._w_pos
+        outs.append((float(loss), w.view(torch.int16).clone(), torch.get_rng_state(), sizes,
+                     [p.detach().clone() for p in model.parameters()]))
+        assert bool((w.view(torch.int16) != 0x3F80).any())                             # the bandit update moved some weights
+    assert outs[0][3] == outs[1][3]
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    for a, b in zip(outs[0][4], outs[1][4]):
+        assert torch.equal(a, b)
+
+
+def test_full_size_gat_reddit_like(cuda):
+    """BASELINE config 4 at full size: GATv2 (heads 4/4/1, hidden 256) on the Reddit-like graph, fanouts 4096/2048/1024,
+    batch 256 -- one forward/backward/Adam + exp3(model='gat') step (model.py:207-234, bandit_sampler.py:146-154)."""
+    from bliss_gnn_amd.model import GATv2
+    _static_vs_exact_step(_bg(), cuda, "reddit",
+                          lambda cfg: GATv2(3, cfg["feat"], 256, cfg["classes"], [4, 4, 1], torch.relu, 0.0, 0.0, 0.2, False), "gat", False)
+
+
+def test_full_size_sage_yelp_like(cuda):
+    """BASELINE config 5's graph on one GPU (|V| = 716,847, |E| ~ 14 M, F = 300, 100 classes, multilabel -> BCEWithLogits,
+    train_lightning.py:77-79, load_graph.py:69-71): one SAGE step, padded == exact."""
+    from bliss_gnn_amd.model import SAGE
+    _static_vs_exact_step(_bg(), cuda, "yelp",
+                          lambda cfg: SAGE(cfg["feat"], 256, cfg["classes"], 3, torch.relu, 0.0), "sage", True)

@@ -58,7 +58,8 @@ def test_ladies_matches_reference_run(name):
     edge_w = bits_to_bf16(z["edge_w"])
     torch.manual_seed(int(z["torch_seed"]))
     _, _, blocks = bo.sample_blocks_ladies(g, torch.from_numpy(z["seeds"]), z["fanouts"].tolist(), edge_w,
-                                           poisson=bool(int(z["poisson"])))
+                                           poisson=bool(int(z["poisson"])),
+                                           importance_sampling=bool(int(z["importance_sampling"])) if "importance_sampling" in z else True)
     for l, blk in enumerate(blocks):
         _check_block(z, f"l{l}_", blk, False)
 
