@@ -132,8 +132,13 @@ class LayerEngine:
             self.counts_host = torch.empty(len(fan) * 10, dtype=torch.int32).pin_memory()
             # one random stream per call: the layers consume consecutive slices of it
             self.rng_cap = sum(c["C"] for c in self.caps)
-            self.rng_out = torch.empty(self.rng_cap + 2 * 624, dtype=torch.float32, device=dev)
-            self.rng_raw = torch.empty(624 * (self.rng_cap // 624 + 3), dtype=torch.int32, device=dev)
+            # (jump-ahead tables for this capacity: the stream is then generated by several workgroups at once, csrc/rng.hip)
+            plan = (C.c_int32 * 4)()
+            _lib.check(_lib.lib.bliss_rng_prepare(self.rng_cap, plan), "bliss_rng_prepare")
+            self.rng_plan = tuple(plan)
+            n_words = 624 * (max(plan[3], self.rng_cap // 624 + 1) + 2)
+            self.rng_out = torch.empty(n_words, dtype=torch.float32, device=dev)
+            self.rng_raw = torch.empty(n_words, dtype=torch.int32, device=dev)
             self.rng_ctl = torch.zeros(8 + len(fan), dtype=torch.int32, device=dev)     # ctl[8] + per-layer offsets
 
     def _bin_buffers(self):

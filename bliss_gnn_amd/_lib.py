@@ -89,6 +89,8 @@ SIGNATURES = {
     "bliss_rng_stream_end": [_P, _P, _P, _I32, _P, _P],
     "bliss_rng_stream_chain": [_P, _P, _P, _P, _I32, _P, _I32, _P, _P],
     "bliss_rng_stream_ready": [_P],
+    "bliss_rng_prepare": [_I32, _P],
+    "bliss_mt_jump_poly": [_I64, _P],
     "bliss_flag_wait": [_P, _P, _P],
     "bliss_flag_raise": [_P, _P],
     "bliss_gather_rows": [_P, _I64, _P, _I32, _I32, _P, _I64, _P, _P],

@@ -13,6 +13,10 @@
 #include "common.cuh"
 #include "bliss_gnn.h"
 #include "prof.h"
+#include "mt_jump.h"
+#include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -138,12 +142,16 @@ __device__ __forceinline__ void mt_produce_wave(const uint32_t* od, uint32_t* nw
 // The serial chain (wave 0) is kept free of everything else: waves 1..3 temper and store block i while wave 0 makes
 // block i+1 (one workgroup barrier per block); progress is published every MT_PUBLISH_EVERY blocks, one period late, and
 // the stop word is polled one period ahead, so that neither the write-through stores nor that load are ever waited for.
+// max_blocks >= 0: stop after that many regenerated blocks (the head of the parallel generator below: the stretches take
+// over from there); zero_words / zero_n: scratch of the jump kernels, cleared here (a kernel, not a memset node).
 __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restrict__ state, int* ctl, float* __restrict__ out,
-                                                        uint32_t* __restrict__ raw, int cap_total) {
+                                                        uint32_t* __restrict__ raw, int cap_total, int max_blocks,
+                                                        uint32_t* __restrict__ zero_words, int zero_n) {
   __shared__ __attribute__((aligned(16))) uint32_t buf[2][MT_N];
   __shared__ int stop_sh;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __builtin_amdgcn_s_setprio(3);      // the chain shares its SIMD with the sampler's waves: let the arbiter pick it first
+  for (int i = tid; i < zero_n; i += 256) zero_words[i] = 0u;
   for (int i = tid; i < MT_N; i += 256) { const uint32_t v = state[i]; buf[0][i] = v; raw[i] = v; }
   const int left = (int)state[MT_N], next = (int)state[MT_N + 1];
   if (tid == 0) stop_sh = -1;
@@ -158,7 +166,7 @@ __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restri
   // top of iteration i: blocks 1..i-1 are stored, block i sits in buf[cur] (block 0 = the entry state)
   for (int i = 0;; ++i) {
     covered = avail + (i > 0 ? i - 1 : 0) * MT_N;
-    const bool more = covered < cap_total;
+    const bool more = covered < cap_total && (max_blocks < 0 || i - 1 < max_blocks);
     if ((i % MT_PUBLISH_EVERY) == 0 || !more) {
       // Progress is published one period late so that nobody waits for write-through stores on the critical path: a
       // storing wave issues exactly two stores per block and nothing else, its stores retire in order, so vmcnt(2 *
@@ -191,6 +199,83 @@ __global__ void __launch_bounds__(256) k_mt19937_stream(const uint32_t* __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // final drain: everything generated is visible ...
   __syncthreads();
   if (tid == 0) __hip_atomic_store(ctl + 0, covered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and published
+}
+
+
+// ---- parallel variant: jump-ahead (mt_jump.hip) ---------------------------------------------------------------------
+// One wave cannot walk the recurrence faster than ~0.5 us per 624 numbers, and a Reddit-like call consumes ~800 blocks.
+// MT19937 is linear over GF(2): the state `n` words ahead is a fixed binary convolution of the word sequence x_1 ..
+// x_{19936+624} with the coefficients of t^(n-1) mod phi (mt_jump.hip).  So:
+//   1. k_mt19937_stream (above, max_blocks = b0 = 32) generates blocks 1 .. b0 as before -- which ARE x_1 .. (raw blocks);
+//   2. k_mt_jump: for every stretch s >= 1 the state of block b0 + s J, the convolution split over JUMP_SLICES workgroups
+//      per stretch (each takes 1024 coefficients, window of the sequence in LDS, partial states XOR-ed together);
+//   3. k_mt_stretch: one workgroup per stretch generates its J blocks exactly like the serial kernel (one wave on the
+//      chain, three tempering and storing); the last one to finish publishes the whole stream.
+// Same numbers, same `out` / `raw` layout, same state hand-back as the serial generator.
+#define JUMP_SLICE_BITS 1024
+#define JUMP_DEG 19937
+#define JUMP_SLICES ((JUMP_DEG + JUMP_SLICE_BITS - 1) / JUMP_SLICE_BITS)
+__global__ void __launch_bounds__(256) k_mt_jump(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ poly,
+                                                 uint32_t* __restrict__ start) {
+  __shared__ uint32_t win[JUMP_SLICE_BITS + 768];
+  const int tid = threadIdx.x, s = blockIdx.y + 1;
+  const int i0 = blockIdx.x * JUMP_SLICE_BITS;
+  const int nbits = min(JUMP_SLICE_BITS, JUMP_DEG - i0);
+  // win[j] = x_{1 + i0 + j}; new_state[k] ^= win[(i - i0) + k] for every coefficient i of this slice
+  for (int j = tid; j < JUMP_SLICE_BITS + 768; j += 256) win[j] = j < nbits + MT_N ? raw[1 + i0 + j] : 0u;
+  __syncthreads();
+  const uint32_t* pw = poly + (size_t)s * MT_N + (i0 >> 5);
+  uint32_t a0 = 0, a1 = 0, a2 = 0;
+  const uint32_t* w0 = win + tid;
+  for (int w = 0; w < (nbits + 31) / 32; ++w) {
+    uint32_t bits = __builtin_amdgcn_readfirstlane(pw[w]);
+    const int left = nbits - w * 32;
+    if (left < 32) bits &= (1u << left) - 1u;
+    while (bits) {                                       // wave-uniform: scalar loop over the set coefficients
+      const int j = w * 32 + __builtin_ctz(bits);
+      bits &= bits - 1u;
+      a0 ^= w0[j]; a1 ^= w0[j + 256]; a2 ^= w0[j + 512];
+    }
+  }
+  uint32_t* dst = start + (size_t)s * MT_N;
+  if (a0) atomicXor(dst + tid, a0);
+  if (a1) atomicXor(dst + tid + 256, a1);
+  if (tid + 512 < MT_N && a2) atomicXor(dst + tid + 512, a2);
+}
+
+__global__ void __launch_bounds__(256) k_mt_stretch(const uint32_t* __restrict__ start, int b0, int J, int n_stretch, int* ctl,
+                                                    float* __restrict__ out, uint32_t* __restrict__ raw, int* done) {
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2][MT_N];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = blockIdx.x;
+  const int first = b0 + s * J;                          // block index of this stretch's start state
+  const uint32_t* src = s == 0 ? raw + (size_t)b0 * MT_N : start + (size_t)s * MT_N;
+  for (int i = tid; i < MT_N; i += 256) buf[0][i] = src[i];
+  __syncthreads();
+  int cur = 0;
+  for (int i = 0; i <= J; ++i) {                         // top: block first + i sits in buf[cur], not stored yet (i >= 1)
+    if (wave == 0) {
+      if (i < J) mt_produce_wave(buf[cur], buf[cur ^ 1], lane);
+    } else if (i >= 1) {
+      const int g = tid - 64;
+      if (g < MT_N / 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&buf[cur][g * 4]);
+        const size_t o = (size_t)(first + i) * MT_N + g * 4;
+        *reinterpret_cast<uint4*>(raw + o) = v;
+        store_sc1_x4(out + o, mt_uniform(v.x), mt_uniform(v.y), mt_uniform(v.z), mt_uniform(v.w));
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this stretch's numbers have reached memory ...
+  __syncthreads();
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == n_stretch - 1) {                         // ... and so have everybody else's: publish the whole stream
+      const int avail = MT_N - __hip_atomic_load(ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl + 0, avail + (b0 + n_stretch * J) * MT_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // main stream, one wave: wait until the generator has produced the numbers layer `n` needs; hand the layer its offset
@@ -288,6 +373,51 @@ hipEvent_t next_event() {
   return e;
 }
 
+// the parallel generator's plan for one stream capacity (bliss_rng_prepare); device buffers live as long as the process
+struct RngPlan {
+  int cap_total, b0, J, n_stretch, total_blocks;
+  uint32_t* d_poly;      // [n_stretch][624] coefficients of t^((b0 + s J) 624 - 1) mod phi   (s = 0 unused)
+  uint32_t* d_start;     // [n_stretch][624] start states (XOR-accumulated by k_mt_jump) + the done counter behind them
+};
+std::vector<RngPlan> g_plans;
+std::mutex g_plan_mu;
+
+const RngPlan* find_plan(int cap_total) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (const auto& p : g_plans) if (p.cap_total == cap_total) return &p;
+  return nullptr;
+}
+
+void plan_shape(int cap_total, RngPlan* p) {
+  p->cap_total = cap_total;
+  p->b0 = 33;                                            // x_1 .. x_{19936 + 624} live in raw blocks 0 .. 32
+  const int need = (cap_total + MT_N - 1) / MT_N + 1;    // blocks that cover cap_total numbers whatever the entry block still holds
+  const char* serial = getenv("BLISS_RNG_SERIAL");
+  if ((serial && serial[0] == '1') || need <= p->b0 + 16) { p->n_stretch = 0; p->J = 0; p->total_blocks = need; return; }
+  const int rest = need - p->b0;
+  int n = (rest + 7) / 8;                                // >= 8 blocks per stretch; at most 32 stretches
+  if (n > 32) n = 32;
+  p->n_stretch = n;
+  p->J = (rest + n - 1) / n;
+  p->total_blocks = p->b0 + n * p->J;
+}
+
+// the generator of one call on the library's stream: serial kernel, or head + jumps + stretches
+int launch_generator(const uint32_t* state, int* ctl, float* out, uint32_t* raw, int cap_total) {
+  const RngPlan* p = find_plan(cap_total);
+  if (!p || p->n_stretch == 0) {
+    PROF_LAUNCH(BK_MT19937, g_side, k_mt19937_stream<<<1, 256, 0, g_side>>>(state, ctl, out, raw, cap_total, -1, nullptr, 0));
+    return (int)hipGetLastError();
+  }
+  int* done = (int*)(p->d_start + (size_t)p->n_stretch * MT_N);
+  PROF_LAUNCH(BK_MT19937, g_side, {
+    k_mt19937_stream<<<1, 256, 0, g_side>>>(state, ctl, out, raw, cap_total, p->b0, p->d_start, p->n_stretch * MT_N + 4);
+    if (p->n_stretch > 1) k_mt_jump<<<dim3(JUMP_SLICES, p->n_stretch - 1), 256, 0, g_side>>>(raw, p->d_poly, p->d_start);
+    k_mt_stretch<<<p->n_stretch, 256, 0, g_side>>>(p->d_start, p->b0, p->J, p->n_stretch, ctl, out, raw, done);
+  });
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -309,10 +439,34 @@ int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t
   k_rng_ctl_init<<<1, 64, 0, st>>>(ctl, (const uint32_t*)state);
   if ((e = hipEventRecord(fork, st)) != hipSuccess) return (int)e;
   if ((e = hipStreamWaitEvent(g_side, fork, 0)) != hipSuccess) return (int)e;
-  PROF_LAUNCH(BK_MT19937, g_side, k_mt19937_stream<<<1, 256, 0, g_side>>>((const uint32_t*)state, ctl, out, raw, cap_total));
+  if (int rc = launch_generator((const uint32_t*)state, ctl, out, raw, cap_total)) return rc;
   if ((e = hipEventRecord(jn, g_side)) != hipSuccess) return (int)e;
   g_join = jn;
   return (int)hipGetLastError();
+}
+
+int bliss_rng_prepare(int32_t cap_total, int32_t* plan4) {
+  if (cap_total <= 0 || !plan4) return BLISS_EINVAL;
+  const RngPlan* have = find_plan(cap_total);
+  RngPlan p;
+  if (have) p = *have;
+  else {
+    plan_shape(cap_total, &p);
+    p.d_poly = p.d_start = nullptr;
+    if (p.n_stretch > 0) {
+      std::vector<uint32_t> polys((size_t)p.n_stretch * MT_N, 0u);
+      // stretch s starts at block b0 + s J: jump of (b0 + s J) 624 words from x_0, i.e. the polynomial of that minus one
+      if (p.n_stretch > 1 && !mt_jump_polys((int64_t)(p.b0 + p.J) * MT_N - 1, (int64_t)p.J * MT_N, p.n_stretch - 1, polys.data() + MT_N))
+        return BLISS_EINVAL;
+      const size_t bytes = polys.size() * sizeof(uint32_t);
+      if (hipMalloc((void**)&p.d_poly, bytes) != hipSuccess || hipMalloc((void**)&p.d_start, bytes + 64) != hipSuccess) return BLISS_EINVAL;
+      if (hipMemcpy(p.d_poly, polys.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return BLISS_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans.push_back(p);
+  }
+  plan4[0] = p.b0; plan4[1] = p.J; plan4[2] = p.n_stretch; plan4[3] = p.total_blocks;
+  return 0;
 }
 
 int bliss_rng_stream_chain(void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, int32_t* counts_dev,
@@ -327,7 +481,7 @@ int bliss_rng_stream_chain(void* state, int32_t* ctl, float* out, uint32_t* raw,
   k_mt19937_chain<<<1, 256, 0, g_side>>>((uint32_t*)state, ctl, raw, cap_total, counts_dev, n_count_words, counts_host);
   if ((e = hipEventRecord(ready, g_side)) != hipSuccess) return (int)e;
   g_ready = ready;
-  PROF_LAUNCH(BK_MT19937, g_side, k_mt19937_stream<<<1, 256, 0, g_side>>>((const uint32_t*)state, ctl, out, raw, cap_total));
+  if (int rc = launch_generator((const uint32_t*)state, ctl, out, raw, cap_total)) return rc;
   if ((e = hipEventRecord(jn, g_side)) != hipSuccess) return (int)e;
   g_join = jn;
   return (int)hipGetLastError();

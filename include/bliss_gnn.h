@@ -177,6 +177,14 @@ int bliss_mt19937_uniform(void* state, const int32_t* n_dev, int32_t n_word_offs
  *   end:   join, then advance `state` by exactly the number of draws the layers consumed; a stream that ran
  *          short or a generator that made no progress sets bit 128 in *err_word (a counts record's err). */
 int bliss_rng_stream_begin(const void* state, int32_t* ctl, float* out, uint32_t* raw, int32_t cap_total, void* stream);
+/* Optional, once per cap_total, outside any stream capture (allocates, copies): lets `begin` / `chain` generate the stream
+ * of a call with SEVERAL workgroups -- MT19937 jump-ahead: the state n words ahead is a fixed GF(2) convolution of the word
+ * sequence with t^(n-1) mod the generator's characteristic polynomial (csrc/mt_jump.hip) -- instead of one wave walking
+ * the recurrence: same numbers, same out / raw layout.  plan4 = {first parallel block, blocks per stretch, stretches (0 =
+ * serial), total blocks}; `out` and `raw` must then hold 624 * (total blocks + 2) elements.  BLISS_RNG_SERIAL=1 keeps the
+ * serial generator.  bliss_mt_jump_poly (host only, no GPU): the 19937 coefficients of t^n_words mod phi as 624 uint32. */
+int bliss_rng_prepare(int32_t cap_total, int32_t* plan4);
+int bliss_mt_jump_poly(int64_t n_words, uint32_t* poly_words);
 int bliss_rng_stream_wait(int32_t* ctl, const void* counts, int32_t* layer_off, int is_last, int32_t cap_total, void* stream);
 int bliss_rng_stream_end(void* state, const int32_t* ctl, const uint32_t* raw, int32_t cap_total, int32_t* err_word,
                          void* stream);
