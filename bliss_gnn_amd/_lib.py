@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbliss_gnn.so")
 
 EINVAL = -1
-MODE_BANDIT, MODE_LADIES, MODE_UNIFORM_NODES = 0, 1, 4
+MODE_BANDIT, MODE_LADIES, MODE_UNIFORM_NODES, MODE_PARTIALS = 0, 1, 4, 8
 
 ERR_BITS = {
     1: "frontier larger than 2^31-1 edges",
@@ -99,6 +99,10 @@ SIGNATURES = {
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
     "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],
+    "bliss_cand_importance": [_P, _I32, C.c_int, _P, _P, _P],
+    "bliss_poisson_scale": [_P, _P, _I32, _D, _P, _P],
+    "bliss_keyed_select": [_P, _P, _P, _I32, _P, C.c_uint64, C.c_uint64, _I32, _P, _P, _P],
+    "bliss_exp3_normalize_global": [_P, _I64, _P, _P, _P, _P, _P],
     "bliss_build_block": [C.POINTER(Graph), C.POINTER(NodeMaps), _P, _P, _I32, C.c_int, _F, _F, _I64, C.POINTER(LayerWs), C.POINTER(BlockOut), _P],
     "bliss_normalized_edata": [C.POINTER(Graph), _P, _P],
     "bliss_embed_norm": [_P, _I32, _I32, _I64, _P, _P],

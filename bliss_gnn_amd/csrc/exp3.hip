@@ -303,11 +303,15 @@ __global__ void k_zero_i64(int64_t* p, int n) { if ((int)threadIdx.x < n) p[thre
 // skip << 16 | err << 20 (for the host), [1] ticket, [2 ..] replicas of the renormalised row's exact sum.  Every workgroup
 // derives the norm from the (read-only) exact row sum; if it is 1.0 nothing is touched.  Otherwise the last workgroup to
 // finish installs the new exact sum -- the others have all read row_sum long before (they read it first thing).
-__device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out, int wg, int nwg) {
+// norm_src (optional): take the norm from THESE limbs instead of row_sum -- a destination-range shard normalises its part
+// of the row by the exact sum over ALL shards (an all-reduce of the limb arrays; integer sums commute), and row_sum still
+// receives the exact sum of this shard's renormalised part.
+__device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out, int wg, int nwg,
+                                                   const int64_t* norm_src = nullptr) {
   __shared__ int sh_norm, sh_last;
   if (threadIdx.x == 0) {
     int bad = 0;
-    const bf16_t nb = limbs_to_bf16(row_sum, &bad);
+    const bf16_t nb = limbs_to_bf16(norm_src ? norm_src : row_sum, &bad);
     sh_norm = (int)nb | (bad << 20);
     if (wg == 0) {
       scratch[0] = (int64_t)nb | ((int64_t)(nb == 0x3f80) << 16) | ((int64_t)bad << 20);
@@ -377,8 +381,9 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
   }
 }
 
-__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out) {
-  normalize_row_body(w, n, row_sum, scratch, norm_out, blockIdx.x, gridDim.x);
+__global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out,
+                                                          const int64_t* norm_src) {
+  normalize_row_body(w, n, row_sum, scratch, norm_out, blockIdx.x, gridDim.x, norm_src);
 }
 // the rows of all layers in one launch: gridDim.x / n_rows workgroups per row
 __global__ void __launch_bounds__(E3_TPB) k_normalize_rows(const Exp3Multi m, int64_t n, int per_row) {
@@ -521,7 +526,18 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   if (grid > 1024) grid = 1024;                      // usually every workgroup returns at once (norm == 1.0): keep the launch small
   if (grid < 1) grid = 1;
-  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16));
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16, nullptr));
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum, const int64_t* norm_limbs, int64_t* scratch,
+                                void* norm_out_bf16, void* stream) {
+  if (!w_pos || !row_sum || !norm_limbs || !scratch || num_edges <= 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16, norm_limbs));
   return (int)hipGetLastError();
 }
 

@@ -1260,8 +1260,10 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   if (n_seeds < 0 && !n_seeds_dev) return BLISS_EINVAL;
   if (n_seeds > cap_s) return BLISS_EINVAL;
   const int uniform_nodes = (mode & BLISS_MODE_UNIFORM_NODES) ? 1 : 0;
-  mode &= ~BLISS_MODE_UNIFORM_NODES;
+  const bool partials_only = (mode & BLISS_MODE_PARTIALS) != 0;
+  mode &= ~(BLISS_MODE_UNIFORM_NODES | BLISS_MODE_PARTIALS);
   if (mode != BLISS_MODE_BANDIT && mode != BLISS_MODE_LADIES) return BLISS_EINVAL;
+  if (partials_only && ws->n_bins <= 0) return BLISS_EINVAL;                 // the per-source sums come from the binned pipeline
   hipStream_t st = (hipStream_t)stream_;
   LayerCounts* cnt = (LayerCounts*)ws->counts;
   const bf16_t* w = (const bf16_t*)w_pos;
@@ -1298,6 +1300,7 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
         cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
+    if (partials_only) return (int)hipGetLastError();    // a shard stops here: (source, partial sum) go to the source owners
     int* tile_sum = ws->word_prefix;                     // [MAX_TILES] tile totals, then the word prefixes
     int* word_prefix = ws->word_prefix + MAX_TILES;
     PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_tiles<<<grid_for(frontier_bound, (int64_t)BTILE * 32, MAX_TILES), 1024, 0, st>>>(ws->bitmap, word_prefix, tile_sum, cnt));
@@ -1343,6 +1346,13 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   PROF_LAUNCH(BK_SELECT2, st, k_select_fused<<<grid_for(cand_bound, CHUNK, 1 << 20), TPB, 0, st>>>(
       (const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid,
       (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map));
+  return (int)hipGetLastError();
+}
+
+int bliss_poisson_scale(int32_t* hist, void* counts, int32_t fanout, double eps, int32_t* scratch, void* stream_) {
+  if (!hist || !counts || !scratch || fanout < 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(hist, (LayerCounts*)counts, fanout, eps, nullptr, nullptr, 0, 0, scratch));
   return (int)hipGetLastError();
 }
 

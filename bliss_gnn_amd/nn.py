@@ -136,8 +136,11 @@ class SAGEConv(nn.Module):
 
     def forward(self, graph, feat, edge_weight=None, parts=False):
         """``parts=True`` returns (fc_self(h_dst), h_neigh) un-added, for a caller that fuses the sum with what follows."""
-        feat_src = self.feat_drop(feat)
-        feat_dst = feat_src[: graph.num_dst_nodes()]
+        if isinstance(feat, tuple):                  # (feat_src, feat_dst) like dglnn.SAGEConv: destinations that are not the
+            feat_src, feat_dst = self.feat_drop(feat[0]), self.feat_drop(feat[1])      # leading source rows (shard blocks)
+        else:
+            feat_src = self.feat_drop(feat)
+            feat_dst = feat_src[: graph.num_dst_nodes()]
         lin_before_mp = self._in_src_feats > self._out_feats
         if lin_before_mp:
             h_neigh = weighted_aggregate(graph, self.fc_neigh(feat_src), edge_weight, mean=True)

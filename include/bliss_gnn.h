@@ -34,6 +34,11 @@ extern "C" {
 #define BLISS_ROWSUM_SLOTS 32
 #define BLISS_NORM_SCRATCH (2 + 3 * BLISS_ROWSUM_SLOTS)
 #define BLISS_MODE_UNIFORM_NODES 4   /* OR-ed in: importance_sampling=False, p_j = [j has an out-edge] (bandit_sampler.py:77-81) */
+#define BLISS_MODE_PARTIALS 8        /* OR-ed in (bliss_frontier_prob, binned pipeline only): stop after the per-source reduction --
+                                      * a destination-range shard owns only some columns, so its sums over sources are PARTIAL:
+                                      * seeds' sums in seed_acc (fifth int64 array), the others as (first position << 32 | node,
+                                      * sum) in touched_key / touched_sum, their number in bin_cursor[n_bins]; exact Q.44 integers
+                                      * that the source owners add up (bliss_gnn_amd/shard.py) */
 
 /* The message graph g as the sampler sees it (train_lightning.py:373: CSC only). */
 typedef struct {
@@ -202,6 +207,25 @@ int bliss_rng_stream_ready(void* stream);
 /* The library-owned generator stream as an integer (hipStream_t; created on first use), so that a caller can record an
  * event behind the kernels `chain` enqueued there -- e.g. to know when counts_host has been written. */
 int64_t bliss_rng_stream_handle(void);
+
+/* ---- destination-range shards (no reference counterpart: the reference is single-device) ----------
+ * The by-source reduction of compute_prob (bandit_sampler.py:67-75) crosses shards; everything per candidate then happens at
+ * the candidate's owner on plain lists:
+ *   bliss_cand_importance: p_j = sqrt(bf16(exact sum)) (:75) from the summed Q.44 partials (uniform_nodes: [sum != 0], :79-81);
+ *   bliss_poisson_scale:   the fixed point c of :391-401 from the GLOBAL histogram of p's bit patterns (hist int32[32768],
+ *                          left zeroed) and the global candidate count counts->C; writes counts->{c, iters, all_one};
+ *                          scratch: int32[counts->C / 1024 + 2];
+ *   bliss_keyed_select:    P_j = seed ? 1 : min(c p_j, 1) (:403-406) and the Poisson draw u < P (:422-424) with the
+ *                          counter-based uniform of (seed, step, layer, node id) -- SplitMix64 finaliser, top 24 bits -- since
+ *                          shards cannot share torch's serial stream; keep[j] = 1 iff drawn. */
+int bliss_cand_importance(const int64_t* sums, int32_t n, int uniform_nodes, void* p_bf16, int32_t* err, void* stream);
+int bliss_poisson_scale(int32_t* hist, void* counts, int32_t fanout, double eps, int32_t* scratch, void* stream);
+int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is_seed, int32_t n, const void* counts,
+                       uint64_t seed, uint64_t step, int32_t layer, void* P_bf16, uint8_t* keep, void* stream);
+/* bliss_exp3_normalize with the norm taken from norm_limbs (int64[3 * BLISS_ROWSUM_SLOTS], e.g. the all-reduced row sums of
+ * all shards) instead of row_sum; row_sum receives the exact sum of THIS row part after the division. */
+int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum, const int64_t* norm_limbs, int64_t* scratch,
+                                void* norm_out_bf16, void* stream);
 
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);
