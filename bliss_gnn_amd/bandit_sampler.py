@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._engine import LayerEngine, _stream
-from .graph import EID, NID, Graph
+from .graph import EID, NID, Graph, as_graph
 
 
 def find_indices_in(a, b):
@@ -83,7 +83,14 @@ class BanditLadiesSampler(BlockSampler):
         return _lib.MODE_BANDIT | (0 if self.importance_sampling else _lib.MODE_UNIFORM_NODES)
 
     # -- state ------------------------------------------------------------------------------
+    def _graph(self, g):
+        """The bliss Graph behind ``g`` (a DGLGraph-like object is converted once and cached, graph.as_graph)."""
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        return as_graph(g, self._graphs)
+
     def _bind(self, g):
+        g = self._graph(g)
         if self._engine is None or self._engine.g is not g:
             self._engine = LayerEngine(g)
         return self._engine
@@ -126,6 +133,7 @@ class BanditLadiesSampler(BlockSampler):
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """bandit_sampler.py:341-367.  ``uniforms``: optional list (sampling order, last layer first)
         of fp32 vectors used instead of the global CPU generator."""
+        g = self._graph(g)
         eng = self._bind(g)
         self._ensure_weights(g)
         output_nodes = seed_nodes
@@ -149,6 +157,7 @@ class BanditLadiesSampler(BlockSampler):
         before and ``finish_static()`` after the stream has been synchronised.  Padded rows / edges are inert:
         ids past the true K point at node 0 and no edge references them; edges past the true B are ignored by
         every kernel (the true counts live on the device)."""
+        g = self._graph(g)
         eng = self._bind(g)
         self._ensure_weights(g)
         order = list(reversed(range(len(self.nodes_per_layer))))
@@ -173,6 +182,7 @@ class BanditLadiesSampler(BlockSampler):
         ``factors[idx]`` (bf16 [B]), the multiplicative updates; ``apply_updates`` then applies every
         rank's updates in rank order.  ``bounds[idx]``: process at most that many edges of block idx (the length of
         ``factors[idx]``); a longer block is flagged (error bit 8)."""
+        g = self._graph(g)
         self._bind(g)
         st = _stream()
         edge_w_pos = g.edata_by_position(self.edge_weight)

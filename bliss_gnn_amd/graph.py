@@ -27,8 +27,9 @@ class Graph:
         self.indptr = indptr.contiguous()
         self.indices = indices.contiguous()
         self.eid = None if eid is None else eid.to(torch.int32).contiguous()
-        self.ndata = dict(ndata or {})
-        self.edata = dict(edata or {})
+        # plain dicts are copied; any other mapping (a DGL frame seen through as_graph) is kept LIVE
+        self.ndata = dict(ndata or {}) if ndata is None or isinstance(ndata, dict) else ndata
+        self.edata = dict(edata or {}) if edata is None or isinstance(edata, dict) else edata
         self.idtype = torch.int32
         self._inv_eid = None
         self._pos_cache = {}
@@ -90,6 +91,56 @@ class Graph:
         if hit is None or hit[0] != tag:
             self._pos_cache[key] = (tag, self.by_position(t).contiguous())
         return self._pos_cache[key][1]
+
+
+class _FrameView:
+    """A live, read-mostly view of somebody else's frame (``dgl_graph.ndata`` / ``.edata``): what the samplers and the lazy
+    block frames need of a mapping, without copying its tensors."""
+
+    def __init__(self, frame):
+        self._f = frame
+
+    def __getitem__(self, key):
+        return self._f[key]
+
+    def __setitem__(self, key, value):
+        self._f[key] = value
+
+    def __contains__(self, key):
+        return key in self._f
+
+    def keys(self):
+        return self._f.keys()
+
+    def items(self):
+        return [(k, self._f[k]) for k in self._f.keys()]
+
+
+def as_graph(g, cache=None):
+    """``g`` as a bliss Graph.  A bliss Graph passes through; anything else is taken to be a DGLGraph-like object -- what
+    ``dgl.dataloading.DataLoader(g, ...)`` hands to ``sampler.sample(g, ids)`` (train_lightning.py:396-408) and what the
+    callback hands to ``sampler.exp3(mfgs, g)`` (:469-471) -- and is read through the four members it must expose:
+    ``adj_tensors('csc') -> (indptr, indices, edge_ids)``, ``ndata``, ``edata``, ``num_nodes()``.  The CSC arrays are
+    converted once (int64 indptr, int32 indices / edge ids, as train_lightning.py:340-342 makes them) and cached in
+    ``cache`` (a dict owned by the caller, keyed by ``id(g)``); the frames stay live views."""
+    if isinstance(g, Graph):
+        return g
+    key = id(g)
+    if cache is not None and key in cache and cache[key][0] is g:
+        return cache[key][1]
+    if not all(hasattr(g, a) for a in ("adj_tensors", "ndata", "edata", "num_nodes")):
+        raise TypeError("expected a bliss_gnn_amd.Graph or a DGLGraph-like object exposing adj_tensors('csc'), ndata, edata, "
+                        "num_nodes(); got %r" % type(g).__name__)
+    indptr, indices, eids = g.adj_tensors("csc")
+    if int(indptr.numel()) != int(g.num_nodes()) + 1:
+        raise ValueError("adj_tensors('csc') returned an indptr that does not match num_nodes()")
+    n = int(indices.numel())
+    identity = eids is None or eids.numel() == 0 or bool((eids == torch.arange(n, device=eids.device, dtype=eids.dtype)).all())
+    bg = Graph(indptr.to(torch.int64), indices.to(torch.int32), None if identity else eids.to(torch.int32),
+               ndata=_FrameView(g.ndata), edata=_FrameView(g.edata))
+    if cache is not None:
+        cache[key] = (g, bg)
+    return bg
 
 
 class _LazyFrame(dict):
@@ -198,6 +249,35 @@ class Block:
             for f, s in zip((self.srcdata, self.dstdata, self.edata), saved):
                 dict.clear(f)
                 dict.update(f, s)
+
+    # -- the message-passing calls the reference's layers make on a block (model.py:82, :98) ------
+    def apply_edges(self, func):
+        """``graph.apply_edges(fn.u_add_v('el', 'er', 'e'))`` (model.py:82): materialises the per-edge tensor, as DGL does
+        (bliss_gnn_amd.nn.GATv2Conv fuses this step away; this entry exists so that layer code written against DGL runs)."""
+        if getattr(func, "kind", None) != "u_add_v":
+            raise NotImplementedError("apply_edges: only fn.u_add_v is used by the reference (model.py:82)")
+        self.edata[func.out] = self.srcdata[func.lhs][self.src.long()] + self.dstdata[func.rhs][self.dst.long()]
+
+    def update_all(self, message_func, reduce_func):
+        """``graph.update_all(fn.u_mul_e(h, w, 'm') | fn.copy_u(h, 'm'), fn.sum('m', out) | fn.mean('m', out))`` on the SpMM
+        kernels (csrc/spmm.hip, csrc/gat.hip); the result lands in ``dstdata[out]`` (model.py:98-99)."""
+        from . import nn as bnn
+        kind, red = getattr(message_func, "kind", None), getattr(reduce_func, "kind", None)
+        if kind not in ("u_mul_e", "copy_u") or red not in ("sum", "mean") or reduce_func.msg != message_func.out:
+            raise NotImplementedError("update_all: (u_mul_e | copy_u) with (sum | mean), as the reference's layers use them")
+        h = self.srcdata[message_func.lhs]
+        w = self.edata[message_func.rhs] if kind == "u_mul_e" else None
+        S = self.num_dst_nodes()
+        if h.dim() == 3 and w is not None and w.dim() == 3:                        # GAT: [K,H,D] x [B,H,1]  (model.py:98)
+            if red != "sum":
+                raise NotImplementedError("per-head messages are summed in the reference (model.py:98)")
+            K, H, D = h.shape
+            out = bnn._GatAggregate.apply(w.reshape(-1, H), h.reshape(K, H * D), self, H, D).view(S, H, D)
+        else:
+            h2 = h.reshape(h.shape[0], -1)
+            out = bnn.weighted_aggregate(self, h2, None if w is None else w.reshape(-1), mean=(red == "mean"))
+            out = out.view((S,) + tuple(h.shape[1:]))
+        self.dstdata[reduce_func.out] = out
 
     def transposed(self):
         """Edges grouped by SOURCE (stable: ascending edge index inside a source): ``(t_indptr int32

@@ -34,6 +34,7 @@ class LadiesSampler(BlockSampler):
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None, uniforms=None):
         """ladies_sampler.py:109-123."""
+        g = self._graph(g)
         self._bind(g)
         w_pos = g.edata_by_position(self.edge_weight)                    # :114
         output_nodes = seed_nodes
@@ -52,7 +53,14 @@ class LadiesSampler(BlockSampler):
 
 
     # -- static-shape variant (graph-capturable; Poisson only): same contract as PoissonBanditLadiesSampler's ------------
+    def _graph(self, g):
+        from .graph import as_graph
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        return as_graph(g, self._graphs)
+
     def _bind(self, g):
+        g = self._graph(g)
         if self._engine is None or self._engine.g is not g:
             self._engine = LayerEngine(g)
         return self._engine
@@ -60,6 +68,7 @@ class LadiesSampler(BlockSampler):
     def sample_blocks_static(self, g, seed_nodes, slot=0, chain_rng=False, external_rng=False, part=None):
         if not self._poisson:
             raise NotImplementedError("the multinomial draw is torch.multinomial on the host: no static-shape variant")
+        g = self._graph(g)
         eng = self._bind(g)
         w_pos = g.edata_by_position(self.edge_weight)
         order = list(reversed(range(len(self.nodes_per_layer))))

@@ -293,6 +293,14 @@ class _GatAggregate(torch.autograd.Function):
         return da, d_feat, None, None, None
 
 
+def edge_softmax(graph, logits):
+    """``dglnn.functional.edge_softmax(graph, e)`` (model.py:88-90): softmax over the in-edges of every destination,
+    per head; ``logits`` [B, H, 1] (or [B, H])."""
+    shape = logits.shape
+    H = shape[1] if logits.dim() > 1 else 1
+    return _EdgeSoftmax.apply(logits.reshape(shape[0], H), graph, H).view(shape)
+
+
 class GATv2Conv(nn.Module):
     """The reference's ``custom_GATv2Conv`` (model.py:13-112): dglnn.GATv2Conv with the forward that returns the
     PRE-softmax logits as "attention" (:108-110) and ignores ``edge_weight`` (:91-96 are commented out).
