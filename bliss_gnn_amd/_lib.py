@@ -72,6 +72,15 @@ class PackLists(C.Structure):                          # bliss_pack_lists_t
                 ("bound", C.c_int32 * EXP3_MAX_BLOCKS), ("n_blocks", C.c_int32)]
 
 
+ADAM_MAX_TENSORS = 32
+
+
+class AdamTensors(C.Structure):                        # bliss_adam_t
+    _fields_ = [("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
+                ("numel", C.c_int64 * ADAM_MAX_TENSORS), ("count", C.c_int32)]
+
+
 class BlockOut(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("pos", C.c_void_p),
                 ("eid", C.c_void_p), ("edge_weights", C.c_void_p), ("q_ij", C.c_void_p), ("t_indptr", C.c_void_p),
@@ -99,6 +108,7 @@ SIGNATURES = {
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
     "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],
+    "bliss_adam_step": [C.POINTER(AdamTensors), _P, _F, _F, _F, _F, _P],
     "bliss_cand_importance": [_P, _I32, C.c_int, _P, _P, _P],
     "bliss_poisson_scale": [_P, _P, _I32, _D, _P, _P],
     "bliss_keyed_select": [_P, _P, _P, _I32, _P, C.c_uint64, C.c_uint64, _I32, _P, _P, _P],

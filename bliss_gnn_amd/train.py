@@ -45,13 +45,25 @@ class BatchLoader:
             yield from iter(self)
 
 
+def make_adam(model, lr, capturable=False):
+    """th.optim.Adam(self.parameters(), lr) (train_lightning.py:206).  For the reference's precision (bf16 module on the GPU,
+    :596-618) this is the one-launch gfx950 Adam of csrc/optim.hip; anything else gets torch's own."""
+    ps = list(model.parameters())
+    if ps and all(p.is_cuda and p.dtype == torch.bfloat16 and p.is_contiguous() for p in ps) and len(ps) <= _lib.ADAM_MAX_TENSORS:
+        from .optim import Adam
+        return Adam(ps, lr=lr)
+    if capturable:
+        return torch.optim.Adam(ps, lr=lr, capturable=True, fused=True)
+    return torch.optim.Adam(ps, lr=lr)
+
+
 class TrainStep:
     """One optimiser step of ModelLightning (train_lightning.py:50-216) with the bandit callback."""
 
     def __init__(self, g, sampler, model, lr=0.002, multilabel=False, bandit=True, grad_sync=None, exp3_sync=None):
         self.g, self.sampler, self.model = g, sampler, model
         self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()   # :77-79
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr)                           # :206
+        self.opt = make_adam(model, lr)                                                  # :206
         self.bandit = bandit and hasattr(sampler, "exp3")          # train_lightning.py:469: only for the bandit samplers
         self.grad_sync, self.exp3_sync = grad_sync, exp3_sync
         self.num_steps = 0
@@ -126,8 +138,9 @@ class GraphedTrainStep:
         self.g, self.sampler, self.model, self.bs = g, sampler, model, int(batch_size)
         self.distributed = distributed          # replicas: gradient all-reduce + EXP3 exchange recorded in the graph too
         self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()
-        # one fused multi-tensor kernel instead of ~40 foreach launches (each >= 5 us inside a graph)
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, fused=True)
+        # ONE launch for all parameter tensors (csrc/optim.hip; torch's foreach path is ~40 launches of >= 5 us inside a graph,
+        # its fused multi-tensor kernel ~50 us)
+        self.opt = make_adam(model, lr, capturable=True)
         self.seeds = torch.zeros(self.bs, dtype=torch.int32, device=g.device)
         self.graph = None
         self.num_steps = 0

@@ -227,6 +227,21 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
 int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum, const int64_t* norm_limbs, int64_t* scratch,
                                 void* norm_out_bf16, void* stream);
 
+/* th.optim.Adam(self.parameters(), lr) (train_lightning.py:205-206) for a bf16 module: parameters, gradients and both moment
+ * buffers bf16, one launch over all tensors, math in fp32, one rounding per stored value.  state: float[4] on the device --
+ * [0] step count (incremented by the launch), [1] learning rate (the caller rewrites it when its scheduler does,
+ * train_lightning.py:208: a captured graph keeps working), [2] internal ticket (zero-initialised). */
+#define BLISS_ADAM_MAX_TENSORS 32
+typedef struct {
+  void* param[BLISS_ADAM_MAX_TENSORS];
+  const void* grad[BLISS_ADAM_MAX_TENSORS];
+  void* exp_avg[BLISS_ADAM_MAX_TENSORS];
+  void* exp_avg_sq[BLISS_ADAM_MAX_TENSORS];
+  int64_t numel[BLISS_ADAM_MAX_TENSORS];
+  int32_t count;
+} bliss_adam_t;
+int bliss_adam_step(const bliss_adam_t* tensors, float* state, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* normalized_edata    bandit_sampler.py:20-27: w_pos[p] = bf16(1 / bf16(indeg(dst(p)))). */
 int bliss_normalized_edata(const bliss_graph_t* g, void* w_pos, void* stream);
 

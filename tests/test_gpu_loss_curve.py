@@ -47,7 +47,9 @@ def _run(cuda, feat_scale):
         same_blocks.append(all(torch.equal(b.srcdata[bg.NID].cpu().long(), ob.src_nid) and torch.equal(b.src.cpu().long(), ob.src)
                                for b, ob in zip(step.last["mfgs"], r_blocks)))
     sampler.check_errors()
-    moved = bool((sampler._w_pos.view(torch.int16) != 0x3F80).any())
+    # (the L1 renormalisation rescales a uniform row to 1/|E|: "moved" = some weight differs from its row's others)
+    w = sampler._w_pos.view(torch.int16)
+    moved = bool((w != w[:, :1]).any())
     return torch.tensor(ours), torch.tensor(theirs), same_blocks, moved
 
 

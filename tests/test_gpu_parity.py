@@ -1516,3 +1516,41 @@ def test_full_size_sage_yelp_like(cuda):
     from bliss_gnn_amd.model import SAGE
     _static_vs_exact_step(_bg(), cuda, "yelp",
                           lambda cfg: SAGE(cfg["feat"], 256, cfg["classes"], 3, torch.relu, 0.0), "sage", True)
+
+
+def test_one_launch_adam_matches_fp32_restatement(cuda):
+    """csrc/optim.hip: th.optim.Adam's update (train_lightning.py:206; defaults betas (0.9, 0.999), eps 1e-8) on bf16
+    parameters / gradients / moments, math in fp32, one rounding per stored value -- against the same formulas in torch
+    fp32 with the same rounding points, over several steps and a learning-rate change (StepLR, :208)."""
+    from bliss_gnn_amd.optim import Adam
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(256, 602), (256,), (41, 256), (7,), (3, 5, 11)]
+    ps = [torch.nn.Parameter((torch.randn(s, generator=gen) * 0.1).bfloat16().to(cuda)) for s in shapes]
+    ref_p = [p.detach().float().clone() for p in ps]
+    ref_m = [torch.zeros_like(x) for x in ref_p]
+    ref_v = [torch.zeros_like(x) for x in ref_p]
+    opt = Adam(ps, lr=0.002)
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 0.002
+    for step in range(1, 8):
+        if step == 5:
+            lr = 0.002 * 0.01
+            opt.param_groups[0]["lr"] = lr
+        for i, p in enumerate(ps):
+            g = (torch.randn(p.shape, generator=gen) * (0.01 if i % 2 else 1.0)).bfloat16()
+            p.grad = g.to(cuda)
+            gf = g.float().to(cuda)
+            m = ref_m[i] + (gf - ref_m[i]) * (1.0 - b1)
+            v = b2 * ref_v[i] + (1.0 - b2) * gf * gf
+            bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+            denom = v.sqrt() / (bc2 ** 0.5) + eps
+            ref_p[i] = (ref_p[i] - (lr / bc1) * (m / denom)).bfloat16().float()
+            ref_m[i], ref_v[i] = m.bfloat16().float(), v.bfloat16().float()
+        opt.step()
+    assert opt.step_count == 7
+    for p, rp, i in zip(ps, ref_p, range(len(ps))):
+        st = opt.state[p]
+        d = (p.detach().float() - rp).abs()
+        ulp = rp.abs().clamp(min=1e-3) * 2.0 ** -7
+        assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 0.01        # at most an ulp, and almost never
+        assert torch.allclose(st["exp_avg"].float(), ref_m[i], rtol=2 ** -7, atol=1e-9)
+        assert torch.allclose(st["exp_avg_sq"].float(), ref_v[i], rtol=2 ** -7, atol=1e-12)
