@@ -72,6 +72,16 @@ class PackLists(C.Structure):                          # bliss_pack_lists_t
                 ("bound", C.c_int32 * EXP3_MAX_BLOCKS), ("n_blocks", C.c_int32)]
 
 
+class TileGemm(C.Structure):                           # bliss_tile_gemm_t
+    _fields_ = [("a1", C.c_void_p), ("a1_stride", C.c_int64), ("ids", C.c_void_p),
+                ("w1", C.c_void_p), ("w1_stride", C.c_int64), ("k1", C.c_int32),
+                ("a2", C.c_void_p), ("a2_stride", C.c_int64), ("w2", C.c_void_p), ("w2_stride", C.c_int64), ("k2", C.c_int32),
+                ("bias", C.c_void_p), ("m_bound", C.c_int32), ("m_dev", C.c_void_p), ("n", C.c_int32),
+                ("out", C.c_void_p), ("out_stride", C.c_int64), ("a_copy", C.c_void_p), ("copy_stride", C.c_int64),
+                ("in_norm", C.c_void_p), ("out_norm", C.c_void_p),
+                ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_ctr", C.c_void_p)]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -108,6 +118,7 @@ SIGNATURES = {
     "bliss_mt19937_uniform": [_P, _P, _I32, _P, _I32, _P],
     "bliss_poisson_select": [C.POINTER(LayerWs), _I32, _D, _P, _P, _P, C.c_int, _I32, _I64, _P],
     "bliss_multinomial_select": [C.POINTER(LayerWs), _P, _I32, _P],
+    "bliss_tile_gemm": [C.POINTER(TileGemm), C.POINTER(TileGemm), _P],
     "bliss_adam_step": [C.POINTER(AdamTensors), _P, _F, _F, _F, _F, _P],
     "bliss_cand_importance": [_P, _I32, C.c_int, _P, _P, _P],
     "bliss_poisson_scale": [_P, _P, _I32, _D, _P, _P],

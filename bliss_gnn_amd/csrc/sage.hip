@@ -1,0 +1,303 @@
+// The dense transforms of a SAGE layer on the matrix cores, fused with what surrounds them.
+//
+// model.py:321-333 -> dglnn.SAGEConv('mean') [DGL-recalled, SURVEY.md m2-m5]:  rst = fc_self(h_dst) + fc_neigh o mean_w(h)
+// with fc_neigh BEFORE the aggregation iff in > out, then relu + dropout, and model.py:318-320 takes the row norms of
+// every layer's input.  The reference (and round 1 here) runs each Linear as a library GEMM with its own launch, plus a
+// gather kernel in front and an element-wise epilogue behind; at these sizes (a few thousand rows) every launch costs
+// more than its arithmetic.  k_tile_gemm is ONE launch for
+//     out[r, :] = epilogue( A1[r, :] . W1^T  (+ A2[r, :] . W2^T)  + bias )
+// where the rows of A1 may be gathered through an index (blocks[0].srcdata['features'] = features[input_nodes],
+// train_lightning.py:138 -- the gather IS the A-operand load), the epilogue is bf16 rounding, optional ReLU, optional
+// dropout, and the kernel also leaves the row norms of its INPUT rows (embed_norm of this layer) and of its OUTPUT rows
+// (embed_norm of the next layer).  Two argument sets can share a launch (blockIdx.y): fc_neigh over all source rows and
+// fc_self over the destination rows of a W-first layer.
+//
+// Shape of the work: a workgroup (4 waves) owns 64 rows and all N <= 256 output columns.  The 64 input rows are staged
+// ONCE in LDS (64 x K bf16 <= 132 KB for K <= 1024; 160 KB per CU), which is also where the input norms are taken in
+// exactly k_embed_norm's order (same bits as the unfused path).  Wave w computes columns 64 w .. 64 w + 63 as 2 x 2 tiles
+// of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
+// 16-byte global (L2) reads of W[n][k..k+7] -- nn.Linear keeps W as [out, in], i.e. K-contiguous, exactly the B layout
+// the instruction wants, so no operand is ever transposed.  fp32 accumulation over all of K (and both products), one
+// rounding to bf16 at the store.  A row's result depends on nothing but that row: capacity-padded and exact-size blocks
+// give identical bits.
+#include "common.cuh"
+#include "bliss_gnn.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define TG_TPB 256
+#define TG_M 64
+
+struct TileGemm {
+  const bf16_t* a1; long long a1_stride; const int* ids;
+  const bf16_t* w1; long long w1_stride; int k1;
+  const bf16_t* a2; long long a2_stride; const bf16_t* w2; long long w2_stride; int k2;
+  const bf16_t* bias;
+  int m_bound; const int* m_dev; int n;
+  bf16_t* out; long long out_stride;
+  bf16_t* a_copy; long long copy_stride;
+  bf16_t* in_norm; bf16_t* out_norm;
+  int relu; unsigned drop_thresh; float drop_scale; unsigned seed; unsigned long long* ctr;
+};
+
+__device__ __forceinline__ int k_pad16(int k) { return (k + 15) & ~15; }
+// LDS row stride (elements): K rounded to 16, plus 8: the stride is then 4 (mod 8) dwords, so the 16-byte fragment reads
+// of 8 consecutive rows fall into 8 different 4-bank groups (and a 64-row tile of 602-wide rows stays below 80 KB: two
+// workgroups per CU)
+__device__ __host__ __forceinline__ int lds_stride(int k) {
+  return ((k + 15) & ~15) + 8;
+}
+
+__device__ __forceinline__ uint32_t tg_drop_hash(uint32_t seed, uint32_t ctr, uint32_t idx) {   // = drop_hash of spmm.hip
+  uint32_t x = idx * 0x9e3779b1u + seed;
+  x ^= ctr * 0x85ebca77u + 0x165667b1u;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  x += ctr; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+  return x;
+}
+
+// sum of squares of one LDS row in k_embed_norm's order (spmm.hip): vec4 = the 4-columns-per-lane walk, else 1 per lane
+__device__ __forceinline__ float row_sumsq(const bf16_t* sh, int dim, int vec4, int lane) {
+  float s = 0.f;
+  if (vec4) {
+    for (int c = lane * 4; c < dim; c += 256) {
+      const float a = bf2f(sh[c]), b = bf2f(sh[c + 1]), cc = bf2f(sh[c + 2]), d = bf2f(sh[c + 3]);
+      s += a * a; s += b * b; s += cc * cc; s += d * d;
+    }
+  } else {
+    for (int c = lane; c < dim; c += 64) { const float a = bf2f(sh[c]); s += a * a; }
+  }
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  return s;
+}
+
+// stage 16 rows of one operand into LDS (this wave's rows), zero-padded to the 16-multiple; optional copy-out and norms
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long long a_stride, const int* __restrict__ ids, int k,
+                                           int row0, int M, bf16_t* tile, int stride, bf16_t* __restrict__ copy, long long copy_stride,
+                                           bf16_t* __restrict__ norm_out, int wave, int lane) {
+  const int kp = k_pad16(k);
+  const bool even = (k % 2 == 0) && (a_stride % 2 == 0) && (((uintptr_t)a) % 4 == 0);
+  for (int rr = 0; rr < 16; ++rr) {
+    const int lr = wave * 16 + rr, r = row0 + lr;
+    bf16_t* sh = tile + (size_t)lr * stride;
+    if (r < M) {
+      const bf16_t* src = a + (long long)(ids ? ids[r] : r) * a_stride;
+      bf16_t* cp = copy ? copy + (long long)r * copy_stride : nullptr;
+      if (even) {
+        for (int c = lane * 2; c < k; c += 128) {
+          const uint32_t v = *reinterpret_cast<const uint32_t*>(src + c);
+          *reinterpret_cast<uint32_t*>(sh + c) = v;
+          if (cp) {
+            if (copy_stride % 2 == 0) *reinterpret_cast<uint32_t*>(cp + c) = v;
+            else { cp[c] = (bf16_t)(v & 0xffffu); cp[c + 1] = (bf16_t)(v >> 16); }
+          }
+        }
+      } else {
+        for (int c = lane; c < k; c += 64) { const bf16_t v = src[c]; sh[c] = v; if (cp) cp[c] = v; }
+      }
+      for (int c = k + lane; c < kp; c += 64) sh[c] = 0;
+    } else {
+      for (int c = lane; c < kp; c += 64) sh[c] = 0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (norm_out) {
+    const int vec4 = (k % 4 == 0);
+    for (int rr = 0; rr < 16; ++rr) {
+      const int lr = wave * 16 + rr, r = row0 + lr;
+      if (r >= M) break;
+      const float s = row_sumsq(tile + (size_t)lr * stride, k, vec4, lane);
+      if (lane == 0) norm_out[r] = f2bf(sqrtf(s));
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8_t load_b_frag(const bf16_t* __restrict__ w, long long w_stride, int n, int N, int kk, int K) {
+  union { uint4 u; bf16x8_t v; bf16_t e[8]; } x;
+  x.u = make_uint4(0, 0, 0, 0);
+  if (n < N && kk < K) {
+    const bf16_t* p = w + (long long)n * w_stride + kk;
+    if (kk + 8 <= K) {
+      if ((((uintptr_t)p) & 3) == 0) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+        x.u = make_uint4(q[0], q[1], q[2], q[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x.e[j] = p[j];
+      }
+    } else {
+      for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j] : (bf16_t)0;
+    }
+  }
+  return x.v;
+}
+
+__device__ __forceinline__ void mma_product(const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w, long long w_stride,
+                                            int n0, int N, int lane, f32x16_t acc[2][2]) {
+  const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
+  bf16x8_t b_cur[2], b_nxt[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) b_cur[nb] = load_b_frag(w, w_stride, n0 + 32 * nb + r, N, 8 * h, k);
+  for (int k0 = 0; k0 < kp; k0 += 16) {
+    if (k0 + 16 < kp) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) b_nxt[nb] = load_b_frag(w, w_stride, n0 + 32 * nb + r, N, k0 + 16 + 8 * h, k);
+    }
+    bf16x8_t a[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)(32 * m + r) * stride + k0 + 8 * h);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b_cur[nb], acc[m][nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) b_cur[nb] = b_nxt[nb];
+  }
+}
+
+__device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int M = p.m_bound;
+  if (p.m_dev) { const int t = *p.m_dev; M = t < M ? t : M; }
+  const int row0 = blockIdx.x * TG_M;
+  const uint32_t ctr = p.drop_thresh ? (uint32_t)__hip_atomic_load(p.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const int N = p.n;
+  if (row0 < p.m_bound) {
+    if (row0 >= M) {
+      // a tile of capacity padding: nothing to compute, but what later passes read of these rows must be finite (zero)
+      for (int lr = wave; lr < TG_M; lr += TG_TPB / 64) {
+        const int r = row0 + lr;
+        if (r >= p.m_bound) break;
+        for (int c = lane; c < N; c += 64) p.out[(long long)r * p.out_stride + c] = 0;
+        if (p.a_copy) for (int c = lane; c < p.k1; c += 64) p.a_copy[(long long)r * p.copy_stride + c] = 0;
+        if (lane == 0) { if (p.in_norm) p.in_norm[r] = 0; if (p.out_norm) p.out_norm[r] = 0; }
+      }
+    } else {
+      const int s1 = lds_stride(p.k1), s2 = p.k2 ? lds_stride(p.k2) : 0;
+      bf16_t* t1 = lds;
+      bf16_t* t2 = lds + (size_t)TG_M * s1;
+      stage_rows(p.a1, p.a1_stride, p.ids, p.k1, row0, M, t1, s1, p.a_copy, p.copy_stride, p.in_norm, wave, lane);
+      if (p.k2) stage_rows(p.a2, p.a2_stride, nullptr, p.k2, row0, M, t2, s2, nullptr, 0, nullptr, wave, lane);
+      // rows of the last real tile that are padding: zero copy / norms (their outputs are written as zeros below)
+      if (p.a_copy || p.in_norm)
+        for (int lr = wave; lr < TG_M; lr += TG_TPB / 64) {
+          const int r = row0 + lr;
+          if (r < M || r >= p.m_bound) continue;
+          if (p.a_copy) for (int c = lane; c < p.k1; c += 64) p.a_copy[(long long)r * p.copy_stride + c] = 0;
+          if (lane == 0 && p.in_norm) p.in_norm[r] = 0;
+        }
+      __syncthreads();
+      const int n0 = wave * 64;
+      f32x16_t acc[2][2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][nb][i] = 0.f;
+      if (n0 < N) {
+        mma_product(t1, s1, p.k1, p.w1, p.w1_stride, n0, N, lane, acc);
+        if (p.k2) mma_product(t2, s2, p.k2, p.w2, p.w2_stride, n0, N, lane, acc);
+      }
+      __syncthreads();                                  // every wave is done reading the staged rows: reuse the LDS for the output tile
+      const int so = ((N + 63) & ~63) + 8;
+      bf16_t* ot = lds;
+      if (n0 < N) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + 32 * nb + (lane & 31);
+            const float bv = (p.bias && col < N) ? bf2f(p.bias[col]) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int lr = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+              float t = rbf(acc[m][nb][i] + bv);           // fp32 accumulator + bias, ONE rounding to bf16
+              if (p.relu) t = t > 0.f ? t : 0.f;
+              if (p.drop_thresh) {
+                const bool keep = tg_drop_hash(p.seed, ctr, (uint32_t)((row0 + lr) * N + col)) >= p.drop_thresh;
+                t = keep ? rbf(t * p.drop_scale) : 0.f;
+              }
+              ot[(size_t)lr * so + col] = (row0 + lr < M && col < N) ? f2bf(t) : (bf16_t)0;
+            }
+          }
+      }
+      __syncthreads();
+      const int vec4 = (N % 4 == 0);
+      for (int rr = 0; rr < 16; ++rr) {
+        const int lr = wave * 16 + rr, r = row0 + lr;
+        if (r >= p.m_bound) break;
+        const bf16_t* sh = ot + (size_t)lr * so;
+        bf16_t* o = p.out + (long long)r * p.out_stride;
+        for (int c = lane; c < N; c += 64) o[c] = sh[c];
+        if (p.out_norm) {
+          const float s = r < M ? row_sumsq(sh, N, vec4, lane) : 0.f;
+          if (lane == 0) p.out_norm[r] = f2bf(sqrtf(s));
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(TG_TPB) k_tile_gemm(TileGemm p0, TileGemm p1, int n_sets) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t tg_lds[];
+  tile_gemm_body(blockIdx.y == 0 ? p0 : p1, tg_lds);
+  // dropout stream: the last workgroup of the launch bumps the device-resident launch counter (everybody has read it)
+  unsigned long long* ctr = p0.drop_thresh ? p0.ctr : (n_sets > 1 && p1.drop_thresh ? p1.ctr : nullptr);
+  if (ctr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+      if (atomicAdd(ctr + 1, 1ull) == total - 1) {
+        __hip_atomic_store(ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(ctr, 1ull);
+      }
+    }
+  }
+}
+
+bool convert(const bliss_tile_gemm_t* a, TileGemm* p, size_t* lds_bytes, int* tiles) {
+  if (!a->a1 || !a->w1 || !a->out || a->k1 <= 0 || a->k1 > 1024 || a->n <= 0 || a->n > 256 || a->m_bound <= 0) return false;
+  if (a->k2 < 0 || a->k2 > 1024 || (a->k2 > 0 && (!a->a2 || !a->w2))) return false;
+  if (a->drop_p < 0.f || a->drop_p >= 1.f || (a->drop_p > 0.f && !a->drop_ctr)) return false;
+  p->a1 = (const bf16_t*)a->a1; p->a1_stride = a->a1_stride; p->ids = a->ids;
+  p->w1 = (const bf16_t*)a->w1; p->w1_stride = a->w1_stride; p->k1 = a->k1;
+  p->a2 = (const bf16_t*)a->a2; p->a2_stride = a->a2_stride; p->w2 = (const bf16_t*)a->w2; p->w2_stride = a->w2_stride; p->k2 = a->k2;
+  p->bias = (const bf16_t*)a->bias; p->m_bound = a->m_bound; p->m_dev = a->m_dev; p->n = a->n;
+  p->out = (bf16_t*)a->out; p->out_stride = a->out_stride; p->a_copy = (bf16_t*)a->a_copy; p->copy_stride = a->copy_stride;
+  p->in_norm = (bf16_t*)a->in_norm; p->out_norm = (bf16_t*)a->out_norm; p->relu = a->relu;
+  p->drop_thresh = a->drop_p > 0.f ? (unsigned)((double)a->drop_p * 4294967296.0) : 0u;
+  p->drop_scale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
+  p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr;
+  const size_t stage = (size_t)TG_M * (lds_stride(a->k1) + (a->k2 ? lds_stride(a->k2) : 0)) * sizeof(bf16_t);
+  const size_t outt = (size_t)TG_M * (((a->n + 63) & ~63) + 8) * sizeof(bf16_t);
+  *lds_bytes = stage > outt ? stage : outt;
+  *tiles = (a->m_bound + TG_M - 1) / TG_M;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int bliss_tile_gemm(const bliss_tile_gemm_t* first, const bliss_tile_gemm_t* second, void* stream) {
+  if (!first) return BLISS_EINVAL;
+  TileGemm p0, p1;
+  size_t l0 = 0, l1 = 0;
+  int t0 = 0, t1 = 0;
+  if (!convert(first, &p0, &l0, &t0)) return BLISS_EINVAL;
+  p1 = p0;
+  if (second && !convert(second, &p1, &l1, &t1)) return BLISS_EINVAL;
+  const size_t lds = l0 > l1 ? l0 : l1;
+  if (lds > 160 * 1024) return BLISS_EINVAL;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    if (hipFuncSetAttribute((const void*)k_tile_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BLISS_EINVAL;
+    lds_set = lds;
+  }
+  const dim3 grid(t0 > t1 ? t0 : t1, second ? 2 : 1);
+  k_tile_gemm<<<grid, TG_TPB, lds, (hipStream_t)stream>>>(p0, p1, second ? 2 : 1);
+  return (int)hipGetLastError();
+}

@@ -173,6 +173,19 @@ class _LazyFrame(dict):
             return v
         raise KeyError(key)
 
+    def lazy(self, key):
+        """``frame[key]`` as a not-yet-gathered (table, ids) pair when the frame has not materialised it and the rows are
+        bf16 features (nn.LazyRows: the fused SAGE transform gathers them as its operand load); else the tensor itself."""
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
+        if self._parent is not None and key in self._parent:
+            src = self._parent[key]
+            idx = self._index_fn()
+            if src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32 and idx.is_contiguous():
+                from .nn import LazyRows
+                return LazyRows(src, idx)
+        return self[key]
+
     def row_norm_of(self, t):
         """bf16 row norms of ``t`` if ``t`` is a tensor this frame gathered with the fused kernel, else None."""
         for v, nrm in self._row_norms:

@@ -48,7 +48,58 @@ class SAGE(nn.Module):
             self._drop_ctr[key] = torch.zeros(2, dtype=torch.int64, device=device)
         return self._drop_ctr[key], (torch.cuda.initial_seed() ^ (0x9E3779B1 * (l + 1))) & 0xFFFFFFFF
 
+    accepts_lazy_rows = True        # forward() takes blocks[0].srcdata.lazy('features'): the gather becomes an operand load
+
+    def _mfma_ok(self, x):
+        """The fused matrix-core path (csrc/sage.hip) covers the reference's configuration: bf16 on the GPU, ReLU, every
+        layer within the tile kernel's limits (in <= 1024, out <= 256)."""
+        from .nn import tile_gemm_ok
+        act = self.activation
+        relu = act in (torch.relu, torch.nn.functional.relu) or isinstance(act, nn.ReLU)
+        dims = all(tile_gemm_ok(l._in_src_feats, l._out_feats) and l.fc_self.bias is not None and l.norm is None and l.activation is None
+                   and l.feat_drop.p == 0 for l in self.layers)
+        return relu and dims and x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.dropout, nn.Dropout)
+
+    def _forward_mfma(self, blocks, x):
+        """model.py:312-333 with the Linear layers on hand-written MFMA tiles: per W-first layer ONE launch for fc_neigh +
+        fc_self (+ the feature gather and the input norms), per aggregate-first layer ONE launch for both Linears, the
+        bias, ReLU, dropout and the next layer's norms.  The aggregation stays the merge-style SpMM of csrc/spmm.hip."""
+        from .nn import LazyRows, _SageDualLinear, _SageLinearPair, weighted_aggregate
+        h, norm, n_layers = x, None, len(self.layers)
+        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+            last = l == n_layers - 1
+            S_b, K_b = block.num_dst_nodes(), block.num_src_nodes()
+            cd = block._counts_dev.data_ptr() if block._nnz_ptr else 0           # capacity-padded block: true S, K on the device
+            src_dev, dst_dev = (cd + 12, cd) if cd else (0, 0)
+            ew = block.edata["edge_weights"] if "edge_weights" in block.edata else None
+            p = self.dropout.p if (self.training and not last) else 0.0
+            ctr, seed = self._dropout_state(l, x.device) if p > 0 else (None, 0)
+            fc_n, fc_s = layer.fc_neigh, layer.fc_self
+            if layer._in_src_feats > layer._out_feats:                           # fc_neigh before the aggregation
+                table, ids = (h.table, h.ids) if isinstance(h, LazyRows) else (h, None)
+                z, y, _rows, in_norm = _SageLinearPair.apply(table, ids, fc_n.weight, fc_s.weight, fc_s.bias, K_b, S_b, src_dev, dst_dev)
+                block.srcdata["embed_norm"] = in_norm if norm is None else norm  # model.py:318-320 (same bits either way)
+                agg = weighted_aggregate(block, z, ew, mean=True)
+                if last:
+                    h, norm = y + agg, None
+                else:
+                    h, norm = sage_epilogue(y, agg, p, ctr, seed)
+            else:
+                if isinstance(h, LazyRows):
+                    h = h.materialize()
+                block.srcdata["embed_norm"] = embed_norm(h) if norm is None else norm
+                agg = weighted_aggregate(block, h, ew, mean=True)
+                h, norm = _SageDualLinear.apply(agg, h[:S_b], fc_n.weight, fc_s.weight, fc_s.bias, not last, p, ctr, seed, S_b, dst_dev)
+                if last:
+                    norm = None
+        return h
+
     def forward(self, blocks, x):
+        from .nn import LazyRows
+        if self._mfma_ok(x):
+            return self._forward_mfma(blocks, x)
+        if isinstance(x, LazyRows):
+            x = x.materialize()
         h, norm = x, _gathered_norm(blocks, x)
         for l, (layer, block) in enumerate(zip(self.layers, blocks)):
             block.srcdata["embed_norm"] = embed_norm(h) if norm is None else norm          # model.py:318-320

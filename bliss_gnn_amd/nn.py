@@ -114,6 +114,119 @@ def sage_epilogue(self_out, neigh, p, ctr, seed):
     return _SageEpilogue.apply(self_out, neigh, p, ctr, seed)
 
 
+# ------------------------------------------------------------------------------------------------ MFMA tile GEMM (csrc/sage.hip)
+TILE_GEMM_MAX_K, TILE_GEMM_MAX_N = 1024, 256
+
+
+class LazyRows:
+    """``table[ids]`` not gathered yet: ``block.srcdata.lazy('features')``.  SAGE.forward hands it to the fused transform,
+    whose A-operand load IS the gather (train_lightning.py:138 + model.py:318-329 in one launch)."""
+
+    def __init__(self, table, ids):
+        self.table, self.ids = table, ids
+        self.shape, self.dtype, self.device = (ids.numel(), table.shape[1]), table.dtype, table.device
+        self.is_cuda = table.is_cuda
+
+    def materialize(self):
+        return torch.index_select(self.table, 0, self.ids)
+
+
+def _tg_args(a1, w1, out, m_bound, ids=None, a2=None, w2=None, bias=None, m_dev=0, a_copy=None, in_norm=None, out_norm=None,
+             relu=False, p=0.0, seed=0, ctr=None):
+    import ctypes as C
+    t = _lib.TileGemm()
+    t.a1, t.a1_stride, t.ids = a1.data_ptr(), a1.stride(0), 0 if ids is None else ids.data_ptr()
+    t.w1, t.w1_stride, t.k1 = w1.data_ptr(), w1.stride(0), w1.shape[1]
+    if a2 is not None:
+        t.a2, t.a2_stride, t.w2, t.w2_stride, t.k2 = a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), w2.shape[1]
+    t.bias = 0 if bias is None else bias.data_ptr()
+    t.m_bound, t.m_dev, t.n = int(m_bound), int(m_dev), w1.shape[0]
+    t.out, t.out_stride = out.data_ptr(), out.stride(0)
+    if a_copy is not None:
+        t.a_copy, t.copy_stride = a_copy.data_ptr(), a_copy.stride(0)
+    t.in_norm = 0 if in_norm is None else in_norm.data_ptr()
+    t.out_norm = 0 if out_norm is None else out_norm.data_ptr()
+    t.relu, t.drop_p, t.drop_seed, t.drop_ctr = int(relu), float(p), int(seed) & 0xFFFFFFFF, 0 if ctr is None else ctr.data_ptr()
+    return t
+
+
+def _tile_gemm(first, second=None):
+    import ctypes as C
+    _lib.check(_lib.lib.bliss_tile_gemm(C.byref(first), None if second is None else C.byref(second), _stream()), "bliss_tile_gemm")
+
+
+def _bf16c(t):
+    t = t if t.dtype == torch.bfloat16 else t.bfloat16()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class _SageLinearPair(torch.autograd.Function):
+    """fc_neigh over all source rows and fc_self (+bias) over the destination rows of a W-first SAGEConv layer (in > out,
+    [DGL-recalled] SURVEY.md m2/m4) in ONE launch; with ``ids`` the rows are gathered from ``x`` (a node-feature table) on
+    the fly.  Returns (Z [K, out], Y [S, out], the input rows [K, in], their bf16 norms [K])."""
+
+    @staticmethod
+    def forward(ctx, x, ids, w_neigh, w_self, b_self, n_src, n_dst, src_dev, dst_dev):
+        x, wn, ws = _bf16c(x), _bf16c(w_neigh), _bf16c(w_self)
+        dev, n_out = x.device, wn.shape[0]
+        z = torch.empty(n_src, n_out, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(n_dst, n_out, dtype=torch.bfloat16, device=dev)
+        norm = torch.empty(n_src, dtype=torch.bfloat16, device=dev)
+        rows = torch.empty(n_src, x.shape[1], dtype=torch.bfloat16, device=dev) if ids is not None else x
+        _tile_gemm(_tg_args(x, wn, z, n_src, ids=ids, m_dev=src_dev, a_copy=rows if ids is not None else None, in_norm=norm),
+                   _tg_args(x, ws, y, n_dst, ids=ids, bias=b_self, m_dev=dst_dev))
+        ctx.save_for_backward(rows, wn, ws)
+        ctx.gathered, ctx.n_dst, ctx.has_bias = ids is not None, n_dst, b_self is not None
+        ctx.mark_non_differentiable(rows, norm) if ids is not None else ctx.mark_non_differentiable(norm)
+        return z, y, rows, norm
+
+    @staticmethod
+    def backward(ctx, dz, dy, _drows, _dnorm):
+        rows, wn, ws = ctx.saved_tensors
+        dz, dy = _bf16c(dz), _bf16c(dy)
+        d_wn = dz.t() @ rows
+        d_ws = dy.t() @ rows[: ctx.n_dst]
+        d_b = dy.sum(0) if ctx.has_bias else None
+        dx = None
+        if not ctx.gathered and ctx.needs_input_grad[0]:
+            dx = dz @ wn
+            dx[: ctx.n_dst] += dy @ ws
+        return dx, None, d_wn, d_ws, d_b, None, None, None, None
+
+
+class _SageDualLinear(torch.autograd.Function):
+    """An aggregate-first SAGEConv layer's tail (in <= out): fc_neigh(h_neigh) + fc_self(h_dst) + bias, ReLU, dropout and the
+    row norms of the result (model.py:321-333, :318-320 of the next layer) in ONE launch: both products accumulate in the
+    same fp32 registers, one rounding to bf16."""
+
+    @staticmethod
+    def forward(ctx, a_neigh, a_self, w_neigh, w_self, bias, relu, p, ctr, seed, n_rows, rows_dev):
+        a1, a2, w1, w2 = _bf16c(a_neigh), _bf16c(a_self), _bf16c(w_neigh), _bf16c(w_self)
+        out = torch.empty(n_rows, w1.shape[0], dtype=torch.bfloat16, device=a1.device)
+        norm = torch.empty(n_rows, dtype=torch.bfloat16, device=a1.device)
+        _tile_gemm(_tg_args(a1, w1, out, n_rows, a2=a2, w2=w2, bias=bias, m_dev=rows_dev, out_norm=norm, relu=relu, p=p, seed=seed, ctr=ctr))
+        ctx.save_for_backward(a1, a2, w1, w2, out)
+        ctx.relu, ctx.p, ctx.has_bias = relu, float(p), bias is not None
+        ctx.mark_non_differentiable(norm)
+        return out, norm
+
+    @staticmethod
+    def backward(ctx, dout, _dnorm):
+        a1, a2, w1, w2, out = ctx.saved_tensors
+        d = _bf16c(dout)
+        if ctx.relu or ctx.p > 0:
+            din = torch.empty_like(out)
+            _lib.check(_lib.lib.bliss_sage_epilogue_bwd(d.data_ptr(), d.stride(0), out.data_ptr(), out.stride(0), out.shape[0],
+                                                        out.shape[1], ctx.p, din.data_ptr(), din.stride(0), _stream()),
+                       "bliss_sage_epilogue_bwd")
+            d = din
+        return (d @ w1, d @ w2, d.t() @ a1, d.t() @ a2, d.sum(0) if ctx.has_bias else None, None, None, None, None, None, None)
+
+
+def tile_gemm_ok(in_feats, out_feats):
+    return in_feats <= TILE_GEMM_MAX_K and out_feats <= TILE_GEMM_MAX_N
+
+
 class SAGEConv(nn.Module):
     """dglnn.SAGEConv(in_feats, out_feats, 'mean') as used at model.py:303-308, 321-329."""
 

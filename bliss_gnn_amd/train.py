@@ -45,6 +45,14 @@ class BatchLoader:
             yield from iter(self)
 
 
+def _inputs(model, mfgs):
+    """``mfgs[0].srcdata['features']`` (train_lightning.py:138); for a model whose first layer gathers the rows as its operand
+    load (model.SAGE on the MFMA path) the not-yet-gathered (table, ids) pair instead."""
+    if getattr(model, "accepts_lazy_rows", False):
+        return mfgs[0].srcdata.lazy("features")
+    return mfgs[0].srcdata["features"]
+
+
 def make_adam(model, lr, capturable=False):
     """th.optim.Adam(self.parameters(), lr) (train_lightning.py:206).  For the reference's precision (bf16 module on the GPU,
     :596-618) this is the one-launch gfx950 Adam of csrc/optim.hip; anything else gets torch's own."""
@@ -90,7 +98,7 @@ class TrainStep:
     def __call__(self, seeds):
         input_nodes, output_nodes, mfgs = self.sampler.sample(self.g, seeds)
         self._ema(mfgs)
-        batch_inputs = mfgs[0].srcdata["features"]                                       # :138
+        batch_inputs = _inputs(self.model, mfgs)                                         # :138
         batch_labels = mfgs[-1].dstdata["labels"]                                        # :139
         batch_pred = self.model(mfgs, batch_inputs)                                      # :141
         loss = self.loss_fn(batch_pred, batch_labels)                                    # :142
@@ -167,7 +175,7 @@ class GraphedTrainStep:
 
     def _body(self):
         input_nodes, output_nodes, mfgs = self.sampler.sample_blocks_static(self.g, self.seeds)
-        x = mfgs[0].srcdata["features"]
+        x = _inputs(self.model, mfgs)
         y = mfgs[-1].dstdata["labels"]
         pred = self.model(mfgs, x)
         loss = self.loss_fn(pred, y)
@@ -308,7 +316,7 @@ class PipelinedTrainStep(GraphedTrainStep):
                                                  part=part)[2]
 
     def _forward(self, mfgs):
-        pred = self.model(mfgs, mfgs[0].srcdata["features"])
+        pred = self.model(mfgs, _inputs(self.model, mfgs))
         loss = self.loss_fn(pred, mfgs[-1].dstdata["labels"])
         if not hasattr(self.sampler, "exp3"):                      # LADIES samplers keep no bandit state
             return loss

@@ -227,6 +227,27 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
 int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum, const int64_t* norm_limbs, int64_t* scratch,
                                 void* norm_out_bf16, void* stream);
 
+/* The Linear layers of dglnn.SAGEConv (model.py:303-308, 321-329; fc_neigh / fc_self) on the matrix cores, one launch:
+ *   out[r, :] = epilogue( A1[r, :] . W1^T (+ A2[r, :] . W2^T) + bias ),   r < min(m_bound, *m_dev)
+ * bf16 in, fp32 accumulation (v_mfma_f32_32x32x16_bf16), one rounding to bf16; W as nn.Linear stores it ([n, k], row stride
+ * w_stride elements).  ids != NULL: row r of A1 is a1[ids[r]] (the feature gather of train_lightning.py:138 as the operand
+ * load); a_copy (optional) receives those rows (the weight gradients need them).  in_norm / out_norm (optional): bf16 row
+ * norms of the A1 rows / of the stored output rows (model.py:318-320), in bliss_embed_norm's summation order.  relu,
+ * drop_p > 0 (drop_ctr: device uint64[2] launch counter + ticket, zero-initialised; drop_seed): model.py:330-332.  Rows at or
+ * beyond *m_dev (capacity padding) are written as zeros.  k1, k2 <= 1024, n <= 256.  Two argument sets may share one launch. */
+typedef struct {
+  const void* a1; int64_t a1_stride; const int32_t* ids;
+  const void* w1; int64_t w1_stride; int32_t k1;
+  const void* a2; int64_t a2_stride; const void* w2; int64_t w2_stride; int32_t k2;
+  const void* bias;
+  int32_t m_bound; const int32_t* m_dev; int32_t n;
+  void* out; int64_t out_stride;
+  void* a_copy; int64_t copy_stride;
+  void* in_norm; void* out_norm;
+  int32_t relu; float drop_p; uint32_t drop_seed; void* drop_ctr;
+} bliss_tile_gemm_t;
+int bliss_tile_gemm(const bliss_tile_gemm_t* first, const bliss_tile_gemm_t* second_or_null, void* stream);
+
 /* th.optim.Adam(self.parameters(), lr) (train_lightning.py:205-206) for a bf16 module: parameters, gradients and both moment
  * buffers bf16, one launch over all tensors, math in fp32, one rounding per stored value.  state: float[4] on the device --
  * [0] step count (incremented by the launch), [1] learning rate (the caller rewrites it when its scheduler does,

@@ -1554,3 +1554,117 @@ def test_one_launch_adam_matches_fp32_restatement(cuda):
         assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 0.01        # at most an ulp, and almost never
         assert torch.allclose(st["exp_avg"].float(), ref_m[i], rtol=2 ** -7, atol=1e-9)
         assert torch.allclose(st["exp_avg_sq"].float(), ref_v[i], rtol=2 ** -7, atol=1e-12)
+
+
+def _tile_gemm_ref(a1, w1, a2=None, w2=None, bias=None, relu=False):
+    acc = a1.float() @ w1.float().t()
+    if a2 is not None:
+        acc = acc + a2.float() @ w2.float().t()
+    if bias is not None:
+        acc = acc + bias.float()
+    return torch.relu(acc) if relu else acc
+
+
+@pytest.mark.parametrize("K,N,M,gather", [(602, 256, 777, True), (256, 41, 300, False), (500, 256, 64, True), (37, 200, 130, False),
+                                          (1024, 256, 65, False)])
+def test_mfma_tile_gemm_vs_fp32(cuda, K, N, M, gather):
+    """csrc/sage.hip: out = A . W^T (+ bias) on v_mfma_f32_32x32x16_bf16 tiles, fp32 accumulation, one bf16 rounding --
+    against torch fp32 (tolerance: one bf16 ulp of the fp32 result; the north star's 1e-4 rel holds for the accumulators,
+    the rounding to bf16 is the layer's own storage format).  Asymmetric random operands catch row/column swaps; K = 602 / 37
+    exercise the k tail, N = 41 / 200 the column tail, M the row tail; gathered rows, their copy, input / output norms in
+    bliss_embed_norm's bits, capacity rows beyond the device-resident true count written as zeros."""
+    import ctypes as C
+    from bliss_gnn_amd import nn as bnn
+    gen = torch.Generator().manual_seed(K + N)
+    table = torch.randn(2000, K, generator=gen).bfloat16().to(cuda)
+    ids = torch.randint(0, 2000, (M + 70,), generator=gen).to(torch.int32).to(cuda)
+    a = table[ids.long()] if gather else torch.randn(M + 70, K, generator=gen).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).bfloat16().to(cuda)
+    bias = torch.randn(N, generator=gen).bfloat16().to(cuda)
+    m_bound = M + 70
+    m_dev = torch.tensor([M], dtype=torch.int32, device=cuda)
+    out = torch.full((m_bound, N), float("nan"), dtype=torch.bfloat16, device=cuda)
+    copy = torch.full((m_bound, K), float("nan"), dtype=torch.bfloat16, device=cuda)
+    in_norm = torch.full((m_bound,), float("nan"), dtype=torch.bfloat16, device=cuda)
+    out_norm = torch.full((m_bound,), float("nan"), dtype=torch.bfloat16, device=cuda)
+    bnn._tile_gemm(bnn._tg_args(table if gather else a, w, out, m_bound, ids=ids if gather else None, bias=bias, m_dev=m_dev.data_ptr(),
+                                a_copy=copy if gather else None, in_norm=in_norm, out_norm=out_norm))
+    torch.cuda.synchronize()
+    ref = _tile_gemm_ref(a[:M], w, bias=bias)
+    got = out[:M].float()
+    ulp = ref.abs().clamp(min=2.0 ** -20) * 2.0 ** -7
+    assert bool(((got - ref).abs() <= ulp).all()), float(((got - ref).abs() / ulp).max())
+    assert torch.equal(out[M:], torch.zeros_like(out[M:]))                                   # capacity padding: zeros, never NaN
+    assert torch.equal(in_norm[:M].view(torch.int16), bnn.embed_norm(a[:M].contiguous()).view(torch.int16))
+    assert torch.equal(out_norm[:M].view(torch.int16), bnn.embed_norm(out[:M].contiguous()).view(torch.int16))
+    assert bool((in_norm[M:] == 0).all()) and bool((out_norm[M:] == 0).all())
+    if gather:
+        assert torch.equal(copy[:M].view(torch.int16), a[:M].view(torch.int16)) and bool((copy[M:] == 0).all())
+
+
+def test_mfma_dual_product_and_pair_launch(cuda):
+    """The two uses in SAGE.forward: (i) aggregate-first layer: agg . Wn^T + h_dst . Ws^T + b, ReLU, norms -- one launch, both
+    products in the same fp32 accumulators; (ii) W-first layer: fc_neigh over K rows and fc_self over the first S rows in one
+    launch (blockIdx.y), autograd included (weight / input gradients vs torch)."""
+    from bliss_gnn_amd import nn as bnn
+    gen = torch.Generator().manual_seed(9)
+    S, Kr, D, N = 333, 900, 256, 256
+    agg = torch.randn(S, D, generator=gen).bfloat16().to(cuda).requires_grad_()
+    h = torch.randn(Kr, D, generator=gen).bfloat16().to(cuda).requires_grad_()
+    wn = (torch.randn(N, D, generator=gen) / 16).bfloat16().to(cuda).requires_grad_()
+    ws = (torch.randn(N, D, generator=gen) / 16).bfloat16().to(cuda).requires_grad_()
+    b = torch.randn(N, generator=gen).bfloat16().to(cuda).requires_grad_()
+    out, norm = bnn._SageDualLinear.apply(agg, h[:S], wn, ws, b, True, 0.0, None, 0, S, 0)
+    ref = _tile_gemm_ref(agg.detach(), wn.detach(), h.detach()[:S], ws.detach(), b.detach(), relu=True)
+    ulp = ref.abs().clamp(min=2.0 ** -20) * 2.0 ** -7
+    assert bool(((out.float() - ref).abs() <= ulp).all())
+    assert torch.equal(norm.view(torch.int16), bnn.embed_norm(out.detach()).view(torch.int16))
+    g = torch.randn(S, N, generator=gen).bfloat16().to(cuda)
+    out.backward(g)
+    d = torch.where(out > 0, g.float(), torch.zeros_like(g.float()))
+    for got, want in ((wn.grad, d.t() @ agg.detach().float()), (ws.grad, d.t() @ h.detach().float()[:S]), (b.grad, d.sum(0)),
+                      (agg.grad, d @ wn.detach().float()), (h.grad[:S], d @ ws.detach().float())):
+        assert torch.allclose(got.float(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+    # (ii)
+    F, Kb, Sb = 602, 500, 120
+    x = torch.randn(Kb, F, generator=gen).bfloat16().to(cuda).requires_grad_()
+    wn2 = (torch.randn(N, F, generator=gen) / 24).bfloat16().to(cuda).requires_grad_()
+    ws2 = (torch.randn(N, F, generator=gen) / 24).bfloat16().to(cuda).requires_grad_()
+    b2 = torch.randn(N, generator=gen).bfloat16().to(cuda).requires_grad_()
+    z, y, rows, in_norm = bnn._SageLinearPair.apply(x, None, wn2, ws2, b2, Kb, Sb, 0, 0)
+    rz, ry = _tile_gemm_ref(x.detach(), wn2.detach()), _tile_gemm_ref(x.detach()[:Sb], ws2.detach(), bias=b2.detach())
+    for got, want in ((z, rz), (y, ry)):
+        assert bool(((got.float() - want).abs() <= want.abs().clamp(min=2.0 ** -20) * 2.0 ** -7).all())
+    assert rows is x or torch.equal(rows, x.detach())
+    gz, gy = torch.randn(Kb, N, generator=gen).bfloat16().to(cuda), torch.randn(Sb, N, generator=gen).bfloat16().to(cuda)
+    torch.autograd.backward([z, y], [gz, gy])
+    want_dx = gz.float() @ wn2.detach().float()
+    want_dx[:Sb] += gy.float() @ ws2.detach().float()
+    for got, want in ((wn2.grad, gz.float().t() @ x.detach().float()), (ws2.grad, gy.float().t() @ x.detach().float()[:Sb]),
+                      (b2.grad, gy.float().sum(0)), (x.grad, want_dx)):
+        assert torch.allclose(got.float(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+
+
+def test_sage_mfma_path_matches_unfused_path(cuda):
+    """SAGE.forward through the fused MFMA kernels == the round-1 path (library GEMMs + separate gather / epilogue) within
+    bf16 rounding, same embed_norm bits on the input layer, and the lazy feature gather == the materialised one bit for bit."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(6000, 100000, seed=13)
+    feats = torch.randn(6000, 602, generator=torch.Generator().manual_seed(1)).bfloat16().to(cuda)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats})
+    g.edata["w"] = bg.normalized_edata(g)
+    torch.manual_seed(3)
+    _, _, blocks = bg.PoissonBanditLadiesSampler([400, 200, 100], eta=0.1).sample_blocks(g, torch.arange(64, dtype=torch.int32, device=cuda))
+    torch.manual_seed(0)
+    model = SAGE(602, 256, 41, 3, torch.relu, 0.0).to(cuda).bfloat16()
+    a = model(blocks, blocks[0].srcdata.lazy("features"))
+    norms_a = [b.srcdata["embed_norm"].clone() for b in blocks]
+    b_ = model(blocks, blocks[0].srcdata["features"])                      # materialised rows, still the MFMA path
+    assert torch.equal(a, b_)
+    model._mfma_ok = lambda x: False                                       # the unfused path
+    c = model(blocks, blocks[0].srcdata["features"])
+    assert torch.equal(norms_a[0].view(torch.int16), blocks[0].srcdata["embed_norm"].view(torch.int16))
+    scale = float(c.float().abs().max())
+    assert float((a.float() - c.float()).abs().max()) <= 3 * 2.0 ** -8 * scale
