@@ -23,6 +23,7 @@
 #include "common.cuh"
 #include "bliss_gnn.h"
 #include "prof.h"
+#include <cstdlib>
 
 #define TPB 256
 #define ITEMS 4
@@ -90,30 +91,31 @@ __device__ __forceinline__ bf16_t edge_q_pre(bf16_t w, bf16_t wsum, float a, flo
 // ---------------------------------------------------------------- K_a: seed columns -> seg_ptr
 // also resets the counts record and zeroes the per-seed accumulators (a kernel, not hipMemsetAsync: memset nodes
 // of a captured HIP graph were observed to leave this buffer stale on replay -- ROCm 7.2)
-__global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
-                                                   LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
-                                                   unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
-                                                   int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
-                                                   int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
-                                                   int* __restrict__ span_seg, long long frontier_cap, int* entry_flag) {
-  __shared__ int sh[17];
-  __shared__ int st_sh[1024];
+// (wg / n_wgs: this workgroup's index and the number of workgroups doing THIS job -- k_seg_col runs the column sums in the
+// same launch on further workgroups; keep_sums: those workgroups write the first two per-seed accumulators, leave them alone)
+__device__ __forceinline__ void seg_scan_body(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
+                                              LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
+                                              unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
+                                              int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
+                                              int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
+                                              int* __restrict__ span_seg, long long frontier_cap, int* entry_flag,
+                                              int wg, int n_wgs, bool keep_sums, int* sh, int* st_sh) {
   // This kernel runs <=> everything enqueued before this layer has completed (stream / graph order): tell a consumer on
   // another stream (bliss_flag_wait) without an event, i.e. without cutting a captured graph in two.
-  if (entry_flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(entry_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (entry_flag && wg == 0 && threadIdx.x == 0) __hip_atomic_store(entry_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
-  if (blockIdx.x > 0 || gridDim.x == 1) {                            // the zeroing does not wait for the serial scan
-    const int nz = gridDim.x > 1 ? gridDim.x - 1 : 1, bz = gridDim.x > 1 ? blockIdx.x - 1 : 0;
+  if (wg > 0 || n_wgs == 1) {                                         // the zeroing does not wait for the serial scan
+    const int nz = n_wgs > 1 ? n_wgs - 1 : 1, bz = n_wgs > 1 ? wg - 1 : 0;
     const int t0 = bz * blockDim.x + threadIdx.x, step = nz * blockDim.x;
     // acc_w, acc_q, acc_wt (u64) + deg_blk (i32) + seed_p2 (u64)
-    for (int i = t0; i < cap_s * 5; i += step) seed_acc[i] = 0ull;
+    for (int i = (keep_sums ? 2 * cap_s : 0) + t0; i < cap_s * 5; i += step) seed_acc[i] = 0ull;
     if (src_cnt) for (int i = t0; i <= cap_k; i += step) src_cnt[i] = 0;
     if (bin_cursor) for (int i = t0; i <= n_bins; i += step) bin_cursor[i] = 0;   // [n_bins] = touched count
     // the seeds' local ids (scattered 4-byte stores): here, spread over several CUs, not in the one workgroup that scans
     for (int k = t0; k < S; k += step) { const int s = seeds[k]; if (s >= 0 && s < num_nodes) local_id[s] = k; }
-    if (gridDim.x > 1) return;
+    if (n_wgs > 1) return;
   }
   long long run = 0;
   constexpr int G = 4;                                  // four 1024-seed rounds have their pointer chases in flight together
@@ -172,6 +174,18 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
     cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
     cnt->err = any_bad;
   }
+}
+
+__global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
+                                                   LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
+                                                   unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
+                                                   int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
+                                                   int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
+                                                   int* __restrict__ span_seg, long long frontier_cap, int* entry_flag) {
+  __shared__ int sh[17];
+  __shared__ int st_sh[1024];
+  seg_scan_body(indptr, seeds, cnt, S_host, S_dev, cap_s, seed_acc, seg_ptr, local_id, num_nodes, src_cnt, cap_k, bin_cursor, n_bins,
+                col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, gridDim.x, false, sh, st_sh);
 }
 
 // ---------------------------------------------------------------- K_b: first appearance + sum_j w_ij
@@ -430,25 +444,38 @@ __device__ __forceinline__ void col_store(int k, long long ws_fixed, long long q
   seed_coef[k] = make_uint2((unsigned)wsum | ((unsigned)qsum << 16), __float_as_uint(rbf((1.0f / (float)n) * eta_f)));
 }
 
-__global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
-                                                      const long long* __restrict__ col_base, const int* __restrict__ span_seg,
-                                                      LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
-                                                      unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                                      uint2* __restrict__ seed_coef, int n_wave_wgs) {
-  __shared__ long long sh[COL_TPB / 64];
-  const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
-  if (cnt->E == 0) return;
+// NT threads per workgroup.  DIRECT: take a column's start and length from seeds -> indptr instead of k_seg_scan's tables --
+// the column sums need no frontier positions, so they can run BESIDE the scan (k_seg_col); wg / n_wgs as in seg_scan_body.
+template <int NT, bool DIRECT>
+__device__ __forceinline__ void col_sums_body(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
+                                              const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
+                                              const long long* __restrict__ col_base, int S, int num_nodes,
+                                              LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
+                                              unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
+                                              uint2* __restrict__ seed_coef, int n_wave_wgs, int wg, int n_wgs, long long* sh) {
+  const int tid = threadIdx.x, lane = lane_id();
   int bad = 0;
   // the first n_wave_wgs workgroups take the short columns (one per wave), the others the long ones (one per workgroup):
   // both kinds are latency chains, so they run side by side instead of one after the other
-  const int n_block_wgs = (int)gridDim.x - n_wave_wgs;
+  const int n_block_wgs = n_wgs - n_wave_wgs;
+  auto column = [&](int k, long long* p0, int* n) {
+    if (DIRECT) {
+      const int sd = seeds[k];
+      if (sd < 0 || sd >= num_nodes) { *n = 0; *p0 = 0; return; }
+      *p0 = indptr[sd];
+      *n = (int)(indptr[sd + 1] - *p0);
+    } else {
+      const int s0 = seg_ptr[k];
+      *n = seg_ptr[k + 1] - s0;
+      *p0 = col_base[k] + s0;
+    }
+  };
   // ---- columns up to COL_BIG edges: one per wave
-  if ((int)blockIdx.x < n_wave_wgs)
-  for (int k = blockIdx.x * (COL_TPB / 64) + (tid >> 6); k < S; k += n_wave_wgs * (COL_TPB / 64)) {
-    const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
+  if (wg < n_wave_wgs)
+  for (int k = wg * (NT / 64) + (tid >> 6); k < S; k += n_wave_wgs * (NT / 64)) {
+    long long p0; int n;
+    column(k, &p0, &n);
     if (n == 0 || n > COL_BIG) continue;              // wave-uniform
-    const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_R];
     long long part = 0;
     int emax = 1;
@@ -474,44 +501,83 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     const long long qs_fixed = wave_total_i64(part);
     if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
-  // ---- the long columns: one per workgroup, the first COL_RB * COL_TPB edges held in registers between the two sums
-  if ((int)blockIdx.x >= n_wave_wgs)
-  for (int k = (int)blockIdx.x - n_wave_wgs; k < S; k += n_block_wgs) {
-    const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
+  // ---- the long columns: one per workgroup, the first COL_RB * NT edges held in registers between the two sums
+  if (wg >= n_wave_wgs)
+  for (int k = wg - n_wave_wgs; k < S; k += n_block_wgs) {
+    long long p0; int n;
+    column(k, &p0, &n);
     if (n <= COL_BIG) continue;                       // block-uniform
-    const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_RB];
     long long part = 0;
     int emax = 1;
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r) {
-      const int i = tid + r * COL_TPB;
+      const int i = tid + r * NT;
       wr[r] = 0;
       if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(w[p0 + i]));
-    const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL_TPB>(emax, sh));
+    for (int i = tid + COL_RB * NT; i < n; i += NT) emax = max(emax, bf_exp_field(w[p0 + i]));
+    const int wfrac = rel_frac(FRAC_DST, block_max_u31<NT>(emax, sh));
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r)
-      if (tid + r * COL_TPB < n) part += bf_to_fixed(wr[r], wfrac, &bad);
+      if (tid + r * NT < n) part += bf_to_fixed(wr[r], wfrac, &bad);
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], wfrac, &bad);
-    const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
+    for (int i = tid + COL_RB * NT; i < n; i += NT) part += bf_to_fixed(w[p0 + i], wfrac, &bad);
+    const long long ws_fixed = block_sum_i64<NT>(part, sh);
     const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
     const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r) {
-      const int i = tid + r * COL_TPB;
+      const int i = tid + r * NT;
       if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(w[p0 + i], wsum, a, ome_f), FRAC_DST, &bad);
-    const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
+    for (int i = tid + COL_RB * NT; i < n; i += NT) part += bf_to_fixed(edge_q_pre(w[p0 + i], wsum, a, ome_f), FRAC_DST, &bad);
+    const long long qs_fixed = block_sum_i64<NT>(part, sh);
     if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
   if (bad) atomicOr(&cnt->err, bad);
+}
+
+__global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
+                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
+                                                      const long long* __restrict__ col_base, const int* __restrict__ span_seg,
+                                                      LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
+                                                      unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
+                                                      uint2* __restrict__ seed_coef, int n_wave_wgs) {
+  __shared__ long long sh[COL_TPB / 64];
+  if (cnt->E == 0) return;
+  col_sums_body<COL_TPB, false>(indptr, w, seeds, seg_ptr, col_base, cnt->S, 0, cnt, acc_w, acc_q, eta_f, ome_f, seed_coef, n_wave_wgs,
+                                blockIdx.x, gridDim.x, sh);
+}
+
+// k_seg_scan and k_col_sums in ONE launch: the first 1 + SEG_ZERO_WGS workgroups scan / zero, the others take the column
+// sums straight from seeds -> indptr.  One launch (and one serial scan) less on the sampler's critical chain per layer.
+#define SEGCOL_TPB 1024
+__global__ void __launch_bounds__(SEGCOL_TPB) k_seg_col(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
+                                                        LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
+                                                        unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
+                                                        int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
+                                                        int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
+                                                        int* __restrict__ span_seg, long long frontier_cap, int* entry_flag,
+                                                        const bf16_t* __restrict__ w, float eta_f, float ome_f,
+                                                        uint2* __restrict__ seed_coef, int n_wave_wgs) {
+  __shared__ int sh[17];
+  __shared__ int st_sh[1024];
+  __shared__ long long shl[SEGCOL_TPB / 64];
+  const int n_seg = 1 + SEG_ZERO_WGS;
+  if ((int)blockIdx.x < n_seg) {
+    seg_scan_body(indptr, seeds, cnt, S_host, S_dev, cap_s, seed_acc, seg_ptr, local_id, num_nodes, src_cnt, cap_k, bin_cursor, n_bins,
+                  col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, n_seg, true, sh, st_sh);
+    return;
+  }
+  int S = S_host >= 0 ? S_host : *S_dev;
+  if (S > cap_s) S = cap_s;
+  unsigned long long* acc_w = seed_acc;
+  col_sums_body<SEGCOL_TPB, true>(indptr, w, seeds, nullptr, nullptr, S, num_nodes, cnt, acc_w, acc_w + cap_s, eta_f, ome_f, seed_coef,
+                                  n_wave_wgs, (int)blockIdx.x - n_seg, (int)gridDim.x - n_seg, shl);
 }
 
 template <bool BANDIT>
@@ -1281,17 +1347,29 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
         g->num_edges > (long long)MAX_TILES * BTILE * 32 || !ws->bin_cursor || !ws->bin_rec || !ws->bitmap || !ws->word_prefix || !ws->touched_key || !ws->touched_sum)
       return BLISS_EINVAL;
   }
-  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
-                                                            m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
-                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
-                                                            (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll), ws->entry_flag));
+  const long long fcap = (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll);
+  static const bool merged_ok = []() { const char* e = getenv("BLISS_SEG_COL"); return !(e && e[0] == '0'); }();
+  const bool merged = binned && mode == BLISS_MODE_BANDIT && merged_ok;
+  if (merged) {
+    // scan + zeroing and the column sums (sum_j w_ij, sum_k q_ik per seed) side by side in one launch
+    const int n_wave = grid_for(cap_s, SEGCOL_TPB / 64, 2048), n_long = cap_s < 1024 ? cap_s : 1024;
+    PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_col<<<1 + SEG_ZERO_WGS + n_wave + n_long, SEGCOL_TPB, 0, st>>>(
+        g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr, m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
+        ws->bin_cursor, ws->n_bins, (long long*)col_base, ws->span_seg, fcap, ws->entry_flag, w, eta_f, one_minus_eta_f,
+        (uint2*)(acc_w + 6 * (size_t)cap_s), n_wave));
+  } else {
+    PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
+                                                              m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
+                                                              binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
+                                                              fcap, ws->entry_flag));
+  }
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
     const int n_wave_wgs = grid_for(cap_s, COL_TPB / 64, 2048);
-    if (mode == BLISS_MODE_BANDIT)                       // the block passes need sum_j w_ij even when p_j does not
+    if (mode == BLISS_MODE_BANDIT && !merged)            // the block passes need sum_j w_ij even when p_j does not
       PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs));
     if (mode == BLISS_MODE_BANDIT)
       PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));

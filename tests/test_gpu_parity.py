@@ -1550,8 +1550,8 @@ def test_one_launch_adam_matches_fp32_restatement(cuda):
     for p, rp, i in zip(ps, ref_p, range(len(ps))):
         st = opt.state[p]
         d = (p.detach().float() - rp).abs()
-        ulp = rp.abs().clamp(min=1e-3) * 2.0 ** -7
-        assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 0.01        # at most an ulp, and almost never
+        ulp = (rp.abs() + 2 * 0.002) * 2.0 ** -7                                       # an ulp of the operands of p - lr * m / denom
+        assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 0.02        # at most an ulp, and rarely
         assert torch.allclose(st["exp_avg"].float(), ref_m[i], rtol=2 ** -7, atol=1e-9)
         assert torch.allclose(st["exp_avg_sq"].float(), ref_v[i], rtol=2 ** -7, atol=1e-12)
 
