@@ -12,10 +12,10 @@
 // (embed_norm of the next layer).  Two argument sets can share a launch (blockIdx.y): fc_neigh over all source rows and
 // fc_self over the destination rows of a W-first layer.
 //
-// Shape of the work: a workgroup (4 waves) owns 64 rows and all N <= 256 output columns.  The 64 input rows are staged
+// Shape of the work: a workgroup (8 waves) owns 64 rows and all N <= 256 output columns.  The 64 input rows are staged
 // ONCE in LDS (64 x K bf16 <= 132 KB for K <= 1024; 160 KB per CU), which is also where the input norms are taken in
-// exactly k_embed_norm's order (same bits as the unfused path).  Wave w computes columns 64 w .. 64 w + 63 as 2 x 2 tiles
-// of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
+// exactly k_embed_norm's order (same bits as the unfused path).  Wave w computes columns 32 w .. 32 w + 31 as two 32 x 32
+// tiles of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
 // 16-byte global (L2) reads of W[n][k..k+7] -- nn.Linear keeps W as [out, in], i.e. K-contiguous, exactly the B layout
 // the instruction wants, so no operand is ever transposed.  fp32 accumulation over all of K (and both products), one
 // rounding to bf16 at the store.  A row's result depends on nothing but that row: capacity-padded and exact-size blocks
@@ -28,7 +28,7 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-#define TG_TPB 256
+#define TG_TPB 512
 #define TG_M 64
 
 struct TileGemm {
@@ -74,178 +74,190 @@ __device__ __forceinline__ float row_sumsq(const bf16_t* sh, int dim, int vec4, 
   return s;
 }
 
-// stage 16 rows of one operand into LDS (this wave's rows), zero-padded to the 16-multiple; optional copy-out and norms
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long long a_stride, const int* __restrict__ ids, int k,
-                                           int row0, int M, bf16_t* tile, int stride, bf16_t* __restrict__ copy, long long copy_stride,
-                                           bf16_t* __restrict__ norm_out, int wave, int lane) {
+// Stage the 64 rows of one operand in LDS.  The loads of all rows are independent and issued together: wave w takes rows
+// w, w + 8, ... (8 rounds), a lane the dwords lane, lane + 64, ... of its row, so ~40 loads per lane are in flight before
+// the first LDS store -- the gather is latency-bound (a random 1.2 KB row per id), not bandwidth-bound.  row_id[lr] = the
+// source row of tile row lr or -1 (beyond the true row count: zeros).  Optional copy-out of the staged rows.
+#define TG_WAVES (TG_TPB / 64)
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long long a_stride, const int* row_id, int k,
+                                           int row0, int m_bound, bf16_t* tile, int stride, bf16_t* __restrict__ copy, long long copy_stride,
+                                           int wave, int lane) {
   const int kp = k_pad16(k);
   const bool even = (k % 2 == 0) && (a_stride % 2 == 0) && (((uintptr_t)a) % 4 == 0);
-  for (int rr = 0; rr < 16; ++rr) {
-    const int lr = wave * 16 + rr, r = row0 + lr;
-    bf16_t* sh = tile + (size_t)lr * stride;
-    if (r < M) {
-      const bf16_t* src = a + (long long)(ids ? ids[r] : r) * a_stride;
-      bf16_t* cp = copy ? copy + (long long)r * copy_stride : nullptr;
-      if (even) {
-        for (int c = lane * 2; c < k; c += 128) {
-          const uint32_t v = *reinterpret_cast<const uint32_t*>(src + c);
-          *reinterpret_cast<uint32_t*>(sh + c) = v;
-          if (cp) {
-            if (copy_stride % 2 == 0) *reinterpret_cast<uint32_t*>(cp + c) = v;
-            else { cp[c] = (bf16_t)(v & 0xffffu); cp[c + 1] = (bf16_t)(v >> 16); }
-          }
-        }
-      } else {
-        for (int c = lane; c < k; c += 64) { const bf16_t v = src[c]; sh[c] = v; if (cp) cp[c] = v; }
+  const bool copy32 = copy && (copy_stride % 2 == 0) && (((uintptr_t)copy) % 4 == 0);
+  if (even) {
+    const int dw = k / 2;
+    constexpr int MAXC = (1024 / 2 + 63) / 64;          // dwords per lane and row at the largest K
+    uint32_t v[TG_M / TG_WAVES][MAXC];
+#pragma unroll
+    for (int rd = 0; rd < TG_M / TG_WAVES; ++rd) {
+      const int id = row_id[rd * TG_WAVES + wave];
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(a + (long long)(id < 0 ? 0 : id) * a_stride);
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        v[rd][j] = (id >= 0 && c < dw) ? src[c] : 0u;
       }
-      for (int c = k + lane; c < kp; c += 64) sh[c] = 0;
-    } else {
-      for (int c = lane; c < kp; c += 64) sh[c] = 0;
     }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (norm_out) {
-    const int vec4 = (k % 4 == 0);
-    for (int rr = 0; rr < 16; ++rr) {
-      const int lr = wave * 16 + rr, r = row0 + lr;
-      if (r >= M) break;
-      const float s = row_sumsq(tile + (size_t)lr * stride, k, vec4, lane);
-      if (lane == 0) norm_out[r] = f2bf(sqrtf(s));
+#pragma unroll
+    for (int rd = 0; rd < TG_M / TG_WAVES; ++rd) {
+      const int lr = rd * TG_WAVES + wave, r = row0 + lr;
+      uint32_t* sh = reinterpret_cast<uint32_t*>(tile + (size_t)lr * stride);
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < kp / 2) sh[c] = v[rd][j];                // (c >= dw: the zero padding up to the 16-multiple)
+        if (copy && r < m_bound && c < dw) {
+          if (copy32) reinterpret_cast<uint32_t*>(copy + (long long)r * copy_stride)[c] = v[rd][j];
+          else { bf16_t* cp = copy + (long long)r * copy_stride + 2 * c; cp[0] = (bf16_t)(v[rd][j] & 0xffffu); cp[1] = (bf16_t)(v[rd][j] >> 16); }
+        }
+      }
+    }
+  } else {
+    for (int rd = 0; rd < TG_M / TG_WAVES; ++rd) {
+      const int lr = rd * TG_WAVES + wave, r = row0 + lr, id = row_id[lr];
+      const bf16_t* src = a + (long long)(id < 0 ? 0 : id) * a_stride;
+      bf16_t* sh = tile + (size_t)lr * stride;
+      for (int c = lane; c < kp; c += 64) {
+        const bf16_t x = (id >= 0 && c < k) ? src[c] : (bf16_t)0;
+        sh[c] = x;
+        if (copy && r < m_bound && c < k) copy[(long long)r * copy_stride + c] = x;
+      }
     }
   }
 }
 
-__device__ __forceinline__ bf16x8_t load_b_frag(const bf16_t* __restrict__ w, long long w_stride, int n, int N, int kk, int K) {
+__device__ __forceinline__ bf16x8_t load_b_frag(const bf16_t* __restrict__ w, long long w_stride, int n, int kk, int K) {
   union { uint4 u; bf16x8_t v; bf16_t e[8]; } x;
-  x.u = make_uint4(0, 0, 0, 0);
-  if (n < N && kk < K) {
-    const bf16_t* p = w + (long long)n * w_stride + kk;
-    if (kk + 8 <= K) {
-      if ((((uintptr_t)p) & 3) == 0) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-        x.u = make_uint4(q[0], q[1], q[2], q[3]);
-      } else {
+  const bf16_t* p = w + (long long)n * w_stride + kk;      // n is clamped by the caller: always a real row of W
+  if (kk + 8 <= K && (((uintptr_t)p) & 3) == 0) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    x.u = make_uint4(q[0], q[1], q[2], q[3]);
+  } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x.e[j] = p[j];
-      }
-    } else {
-      for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j] : (bf16_t)0;
-    }
+    for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j] : (bf16_t)0;
   }
   return x.v;
 }
 
+// one wave: 64 rows x 32 columns (n0 ..), all of K; B fragments come straight from global memory, TG_PD k-steps ahead
+#define TG_PD 8
 __device__ __forceinline__ void mma_product(const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w, long long w_stride,
-                                            int n0, int N, int lane, f32x16_t acc[2][2]) {
+                                            int n0, int N, int lane, f32x16_t acc[2]) {
   const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
-  bf16x8_t b_cur[2], b_nxt[2];
+  int n = n0 + r;
+  if (n >= N) n = N - 1;                                   // columns beyond N: computed from a real row, never stored
+  bf16x8_t b[TG_PD];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) b_cur[nb] = load_b_frag(w, w_stride, n0 + 32 * nb + r, N, 8 * h, k);
-  for (int k0 = 0; k0 < kp; k0 += 16) {
-    if (k0 + 16 < kp) {
+  for (int j = 0; j < TG_PD; ++j) {
+    const int kk = 16 * j + 8 * h;
+    if (16 * j < kp) b[j] = load_b_frag(w, w_stride, n, kk, k);
+  }
+  for (int k0 = 0; k0 < kp; k0 += 16 * TG_PD) {
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) b_nxt[nb] = load_b_frag(w, w_stride, n0 + 32 * nb + r, N, k0 + 16 + 8 * h, k);
+    for (int j = 0; j < TG_PD; ++j) {
+      const int ks = k0 + 16 * j;
+      if (ks < kp) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)r * stride + ks + 8 * h);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)(32 + r) * stride + ks + 8 * h);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[j], acc[1], 0, 0, 0);
+        const int kn = ks + 16 * TG_PD;
+        if (kn < kp) b[j] = load_b_frag(w, w_stride, n, kn + 8 * h, k);
+      }
     }
-    bf16x8_t a[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)(32 * m + r) * stride + k0 + 8 * h);
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b_cur[nb], acc[m][nb], 0, 0, 0);
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) b_cur[nb] = b_nxt[nb];
   }
 }
 
-__device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds) {
+__device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, int* row_id) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int M = p.m_bound;
   if (p.m_dev) { const int t = *p.m_dev; M = t < M ? t : M; }
   const int row0 = blockIdx.x * TG_M;
   const uint32_t ctr = p.drop_thresh ? (uint32_t)__hip_atomic_load(p.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   const int N = p.n;
-  if (row0 < p.m_bound) {
-    if (row0 >= M) {
-      // a tile of capacity padding: nothing to compute, but what later passes read of these rows must be finite (zero)
-      for (int lr = wave; lr < TG_M; lr += TG_TPB / 64) {
-        const int r = row0 + lr;
-        if (r >= p.m_bound) break;
-        for (int c = lane; c < N; c += 64) p.out[(long long)r * p.out_stride + c] = 0;
-        if (p.a_copy) for (int c = lane; c < p.k1; c += 64) p.a_copy[(long long)r * p.copy_stride + c] = 0;
-        if (lane == 0) { if (p.in_norm) p.in_norm[r] = 0; if (p.out_norm) p.out_norm[r] = 0; }
-      }
-    } else {
-      const int s1 = lds_stride(p.k1), s2 = p.k2 ? lds_stride(p.k2) : 0;
-      bf16_t* t1 = lds;
-      bf16_t* t2 = lds + (size_t)TG_M * s1;
-      stage_rows(p.a1, p.a1_stride, p.ids, p.k1, row0, M, t1, s1, p.a_copy, p.copy_stride, p.in_norm, wave, lane);
-      if (p.k2) stage_rows(p.a2, p.a2_stride, nullptr, p.k2, row0, M, t2, s2, nullptr, 0, nullptr, wave, lane);
-      // rows of the last real tile that are padding: zero copy / norms (their outputs are written as zeros below)
-      if (p.a_copy || p.in_norm)
-        for (int lr = wave; lr < TG_M; lr += TG_TPB / 64) {
-          const int r = row0 + lr;
-          if (r < M || r >= p.m_bound) continue;
-          if (p.a_copy) for (int c = lane; c < p.k1; c += 64) p.a_copy[(long long)r * p.copy_stride + c] = 0;
-          if (lane == 0 && p.in_norm) p.in_norm[r] = 0;
+  if (row0 >= p.m_bound) return;                             // (workgroup-uniform: the other argument set has more tiles)
+  if (row0 >= M) {
+    // a tile of capacity padding: nothing to compute, but what later passes read of these rows must be finite (zero)
+    for (int lr = wave; lr < TG_M; lr += TG_WAVES) {
+      const int r = row0 + lr;
+      if (r >= p.m_bound) break;
+      for (int c = lane; c < N; c += 64) p.out[(long long)r * p.out_stride + c] = 0;
+      if (p.a_copy) for (int c = lane; c < p.k1; c += 64) p.a_copy[(long long)r * p.copy_stride + c] = 0;
+      if (lane == 0) { if (p.in_norm) p.in_norm[r] = 0; if (p.out_norm) p.out_norm[r] = 0; }
+    }
+    return;
+  }
+  const int s1 = lds_stride(p.k1), s2 = p.k2 ? lds_stride(p.k2) : 0;
+  bf16_t* t1 = lds;
+  bf16_t* t2 = lds + (size_t)TG_M * s1;
+  if (tid < TG_M) {
+    const int r = row0 + tid;
+    row_id[tid] = r < M ? (p.ids ? p.ids[r] : r) : -1;
+    row_id[TG_M + tid] = r < M ? r : -1;
+  }
+  __syncthreads();
+  stage_rows(p.a1, p.a1_stride, row_id, p.k1, row0, p.m_bound, t1, s1, p.a_copy, p.copy_stride, wave, lane);
+  if (p.k2) stage_rows(p.a2, p.a2_stride, row_id + TG_M, p.k2, row0, p.m_bound, t2, s2, nullptr, 0, wave, lane);
+  __syncthreads();
+  if (p.in_norm) {                                          // model.py:318-320 of THIS layer, in k_embed_norm's order
+    const int vec4 = (p.k1 % 4 == 0);
+    for (int lr = wave; lr < TG_M; lr += TG_WAVES) {
+      const int r = row0 + lr;
+      if (r >= p.m_bound) break;
+      const float ss = r < M ? row_sumsq(t1 + (size_t)lr * s1, p.k1, vec4, lane) : 0.f;
+      if (lane == 0) p.in_norm[r] = f2bf(sqrtf(ss));
+    }
+  }
+  const int n0 = wave * 32;
+  f32x16_t acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+  if (n0 < N) {
+    mma_product(t1, s1, p.k1, p.w1, p.w1_stride, n0, N, lane, acc);
+    if (p.k2) mma_product(t2, s2, p.k2, p.w2, p.w2_stride, n0, N, lane, acc);
+  }
+  __syncthreads();                                          // every wave is done reading the staged rows: reuse the LDS for the output tile
+  const int so = ((N + 31) & ~31) + 8;
+  bf16_t* ot = lds;
+  if (n0 < N) {
+    const int col = n0 + (lane & 31);
+    const float bv = (p.bias && col < N) ? bf2f(p.bias[col]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int lr = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        float t = rbf(acc[m][i] + bv);                       // fp32 accumulator + bias, ONE rounding to bf16
+        if (p.relu) t = t > 0.f ? t : 0.f;
+        if (p.drop_thresh) {
+          const bool keep = tg_drop_hash(p.seed, ctr, (uint32_t)((row0 + lr) * N + col)) >= p.drop_thresh;
+          t = keep ? rbf(t * p.drop_scale) : 0.f;
         }
-      __syncthreads();
-      const int n0 = wave * 64;
-      f32x16_t acc[2][2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[m][nb][i] = 0.f;
-      if (n0 < N) {
-        mma_product(t1, s1, p.k1, p.w1, p.w1_stride, n0, N, lane, acc);
-        if (p.k2) mma_product(t2, s2, p.k2, p.w2, p.w2_stride, n0, N, lane, acc);
+        ot[(size_t)lr * so + col] = (row0 + lr < M && col < N) ? f2bf(t) : (bf16_t)0;
       }
-      __syncthreads();                                  // every wave is done reading the staged rows: reuse the LDS for the output tile
-      const int so = ((N + 63) & ~63) + 8;
-      bf16_t* ot = lds;
-      if (n0 < N) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const int col = n0 + 32 * nb + (lane & 31);
-            const float bv = (p.bias && col < N) ? bf2f(p.bias[col]) : 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int lr = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-              float t = rbf(acc[m][nb][i] + bv);           // fp32 accumulator + bias, ONE rounding to bf16
-              if (p.relu) t = t > 0.f ? t : 0.f;
-              if (p.drop_thresh) {
-                const bool keep = tg_drop_hash(p.seed, ctr, (uint32_t)((row0 + lr) * N + col)) >= p.drop_thresh;
-                t = keep ? rbf(t * p.drop_scale) : 0.f;
-              }
-              ot[(size_t)lr * so + col] = (row0 + lr < M && col < N) ? f2bf(t) : (bf16_t)0;
-            }
-          }
-      }
-      __syncthreads();
-      const int vec4 = (N % 4 == 0);
-      for (int rr = 0; rr < 16; ++rr) {
-        const int lr = wave * 16 + rr, r = row0 + lr;
-        if (r >= p.m_bound) break;
-        const bf16_t* sh = ot + (size_t)lr * so;
-        bf16_t* o = p.out + (long long)r * p.out_stride;
-        for (int c = lane; c < N; c += 64) o[c] = sh[c];
-        if (p.out_norm) {
-          const float s = r < M ? row_sumsq(sh, N, vec4, lane) : 0.f;
-          if (lane == 0) p.out_norm[r] = f2bf(sqrtf(s));
-        }
-      }
+  }
+  __syncthreads();
+  const int vec4 = (N % 4 == 0);
+  for (int lr = wave; lr < TG_M; lr += TG_WAVES) {
+    const int r = row0 + lr;
+    if (r >= p.m_bound) break;
+    const bf16_t* sh = ot + (size_t)lr * so;
+    bf16_t* o = p.out + (long long)r * p.out_stride;
+    for (int c = lane; c < N; c += 64) o[c] = sh[c];
+    if (p.out_norm) {
+      const float ss = r < M ? row_sumsq(sh, N, vec4, lane) : 0.f;
+      if (lane == 0) p.out_norm[r] = f2bf(sqrtf(ss));
     }
   }
 }
 
 __global__ void __launch_bounds__(TG_TPB) k_tile_gemm(TileGemm p0, TileGemm p1, int n_sets) {
   extern __shared__ __attribute__((aligned(16))) bf16_t tg_lds[];
-  tile_gemm_body(blockIdx.y == 0 ? p0 : p1, tg_lds);
+  __shared__ int row_id[2 * TG_M];
+  tile_gemm_body(blockIdx.y == 0 ? p0 : p1, tg_lds, row_id);
   // dropout stream: the last workgroup of the launch bumps the device-resident launch counter (everybody has read it)
   unsigned long long* ctr = p0.drop_thresh ? p0.ctr : (n_sets > 1 && p1.drop_thresh ? p1.ctr : nullptr);
   if (ctr) {
@@ -274,7 +286,7 @@ bool convert(const bliss_tile_gemm_t* a, TileGemm* p, size_t* lds_bytes, int* ti
   p->drop_scale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr;
   const size_t stage = (size_t)TG_M * (lds_stride(a->k1) + (a->k2 ? lds_stride(a->k2) : 0)) * sizeof(bf16_t);
-  const size_t outt = (size_t)TG_M * (((a->n + 63) & ~63) + 8) * sizeof(bf16_t);
+  const size_t outt = (size_t)TG_M * (((a->n + 31) & ~31) + 8) * sizeof(bf16_t);
   *lds_bytes = stage > outt ? stage : outt;
   *tiles = (a->m_bound + TG_M - 1) / TG_M;
   return true;

@@ -1,8 +1,7 @@
 set -o pipefail
-O=gpurun_out/r02_b; mkdir -p $O
+O=gpurun_out/${1:-r02_c}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_loss_curve.py -x -q -s > $O/tests_e.log 2>&1; tail -5 $O/tests_e.log
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 100 --warmup 20 --cpu-baseline-steps 0 --tune-gemm 0 --no-roofline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 100 --warmup 20 --cpu-baseline-steps 0 --no-roofline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
 python scratch/timeline3.py $O/prof > $O/step_timeline.txt 2>&1
 cp $O/prof/*/*_kernel_stats.csv $O/kernel_stats_pipelined.csv
 rm -rf $O/prof

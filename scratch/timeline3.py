@@ -4,7 +4,7 @@ import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_gather_rows_norm' in r['Kernel_Name'] or 'k_tile_gemm' in r['Kernel_Name'] and 'true, ' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_exp3_update_multi' in r['Kernel_Name']]     # once per step (X follows F)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) * 2 // 3
 t0, t1 = int(rows[idx[which]]['Start_Timestamp']), int(rows[idx[which + 1]]['Start_Timestamp'])
 step = [r for r in rows if t0 <= int(r['Start_Timestamp']) < t1]
