@@ -12,10 +12,10 @@
 // (embed_norm of the next layer).  Two argument sets can share a launch (blockIdx.y): fc_neigh over all source rows and
 // fc_self over the destination rows of a W-first layer.
 //
-// Shape of the work: a workgroup (8 waves) owns 64 rows and all N <= 256 output columns.  The 64 input rows are staged
-// ONCE in LDS (64 x K bf16 <= 132 KB for K <= 1024; 160 KB per CU), which is also where the input norms are taken in
-// exactly k_embed_norm's order (same bits as the unfused path).  Wave w computes columns 32 w .. 32 w + 31 as two 32 x 32
-// tiles of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
+// Shape of the work: a workgroup (4 waves) owns 32 rows and all N <= 256 output columns.  The 32 input rows are staged
+// ONCE in LDS (32 x K bf16 <= 66 KB for K <= 1024, 39 KB for the 602-wide features: four workgroups per CU overlap each
+// other's latency chains), which is also where the input norms are taken in exactly k_embed_norm's order (same bits as the
+// unfused path).  Wave w computes columns 64 w .. 64 w + 63 as two 32 x 32 tiles of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
 // 16-byte global (L2) reads of W[n][k..k+7] -- nn.Linear keeps W as [out, in], i.e. K-contiguous, exactly the B layout
 // the instruction wants, so no operand is ever transposed.  fp32 accumulation over all of K (and both products), one
 // rounding to bf16 at the store.  A row's result depends on nothing but that row: capacity-padded and exact-size blocks
@@ -28,8 +28,8 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-#define TG_TPB 512
-#define TG_M 64
+#define TG_TPB 256
+#define TG_M 32
 
 struct TileGemm {
   const bf16_t* a1; long long a1_stride; const int* ids;
@@ -88,28 +88,32 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long lo
   if (even) {
     const int dw = k / 2;
     constexpr int MAXC = (1024 / 2 + 63) / 64;          // dwords per lane and row at the largest K
-    uint32_t v[TG_M / TG_WAVES][MAXC];
+    constexpr int RPW = TG_M / TG_WAVES, HALF = RPW / 2;  // rows per wave, staged in two batches (register budget: 4 workgroups per CU)
 #pragma unroll
-    for (int rd = 0; rd < TG_M / TG_WAVES; ++rd) {
-      const int id = row_id[rd * TG_WAVES + wave];
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(a + (long long)(id < 0 ? 0 : id) * a_stride);
+    for (int hb = 0; hb < 2; ++hb) {
+      uint32_t v[HALF][MAXC];
 #pragma unroll
-      for (int j = 0; j < MAXC; ++j) {
-        const int c = lane + 64 * j;
-        v[rd][j] = (id >= 0 && c < dw) ? src[c] : 0u;
+      for (int q = 0; q < HALF; ++q) {
+        const int id = row_id[(hb * HALF + q) * TG_WAVES + wave];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a + (long long)(id < 0 ? 0 : id) * a_stride);
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+          const int c = lane + 64 * j;
+          v[q][j] = (id >= 0 && c < dw) ? src[c] : 0u;
+        }
       }
-    }
 #pragma unroll
-    for (int rd = 0; rd < TG_M / TG_WAVES; ++rd) {
-      const int lr = rd * TG_WAVES + wave, r = row0 + lr;
-      uint32_t* sh = reinterpret_cast<uint32_t*>(tile + (size_t)lr * stride);
+      for (int q = 0; q < HALF; ++q) {
+        const int lr = (hb * HALF + q) * TG_WAVES + wave, r = row0 + lr;
+        uint32_t* sh = reinterpret_cast<uint32_t*>(tile + (size_t)lr * stride);
 #pragma unroll
-      for (int j = 0; j < MAXC; ++j) {
-        const int c = lane + 64 * j;
-        if (c < kp / 2) sh[c] = v[rd][j];                // (c >= dw: the zero padding up to the 16-multiple)
-        if (copy && r < m_bound && c < dw) {
-          if (copy32) reinterpret_cast<uint32_t*>(copy + (long long)r * copy_stride)[c] = v[rd][j];
-          else { bf16_t* cp = copy + (long long)r * copy_stride + 2 * c; cp[0] = (bf16_t)(v[rd][j] & 0xffffu); cp[1] = (bf16_t)(v[rd][j] >> 16); }
+        for (int j = 0; j < MAXC; ++j) {
+          const int c = lane + 64 * j;
+          if (c < kp / 2) sh[c] = v[q][j];               // (c >= dw: the zero padding up to the 16-multiple)
+          if (copy && r < m_bound && c < dw) {
+            if (copy32) reinterpret_cast<uint32_t*>(copy + (long long)r * copy_stride)[c] = v[q][j];
+            else { bf16_t* cp = copy + (long long)r * copy_stride + 2 * c; cp[0] = (bf16_t)(v[q][j] & 0xffffu); cp[1] = (bf16_t)(v[q][j] >> 16); }
+          }
         }
       }
     }
@@ -140,30 +144,41 @@ __device__ __forceinline__ bf16x8_t load_b_frag(const bf16_t* __restrict__ w, lo
   return x.v;
 }
 
-// one wave: 64 rows x 32 columns (n0 ..), all of K; B fragments come straight from global memory, TG_PD k-steps ahead
+// One wave: the tile's 32 rows x 64 columns (n0 ..), all of K.  B fragments come straight from global memory (L2), TG_PD
+// k-steps ahead; the first TG_PD steps' fragments are loaded by b_preload BEFORE the rows are staged -- they depend on
+// nothing, so their latency hides behind the row gather.
 #define TG_PD 8
-__device__ __forceinline__ void mma_product(const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w, long long w_stride,
-                                            int n0, int N, int lane, f32x16_t acc[2]) {
+struct BFrags { bf16x8_t f[TG_PD][2]; };
+__device__ __forceinline__ void b_preload(BFrags& b, const bf16_t* __restrict__ w, long long w_stride, int k, int n0, int N, int lane) {
   const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
-  int n = n0 + r;
-  if (n >= N) n = N - 1;                                   // columns beyond N: computed from a real row, never stored
-  bf16x8_t b[TG_PD];
 #pragma unroll
-  for (int j = 0; j < TG_PD; ++j) {
-    const int kk = 16 * j + 8 * h;
-    if (16 * j < kp) b[j] = load_b_frag(w, w_stride, n, kk, k);
-  }
+  for (int j = 0; j < TG_PD; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      int n = n0 + 32 * nb + r;
+      if (n >= N) n = N - 1;                               // columns beyond N: computed from a real row, never stored
+      if (16 * j < kp) b.f[j][nb] = load_b_frag(w, w_stride, n, 16 * j + 8 * h, k);
+    }
+}
+__device__ __forceinline__ void mma_product(BFrags& b, const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w,
+                                            long long w_stride, int n0, int N, int lane, f32x16_t acc[2]) {
+  const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
+  int n[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) { n[nb] = n0 + 32 * nb + r; if (n[nb] >= N) n[nb] = N - 1; }
   for (int k0 = 0; k0 < kp; k0 += 16 * TG_PD) {
 #pragma unroll
     for (int j = 0; j < TG_PD; ++j) {
       const int ks = k0 + 16 * j;
       if (ks < kp) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)r * stride + ks + 8 * h);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)(32 + r) * stride + ks + 8 * h);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[j], acc[1], 0, 0, 0);
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)r * stride + ks + 8 * h);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.f[j][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.f[j][1], acc[1], 0, 0, 0);
         const int kn = ks + 16 * TG_PD;
-        if (kn < kp) b[j] = load_b_frag(w, w_stride, n, kn + 8 * h, k);
+        if (kn < kp) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) b.f[j][nb] = load_b_frag(w, w_stride, n[nb], kn + 8 * h, k);
+        }
       }
     }
   }
@@ -191,6 +206,14 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   const int s1 = lds_stride(p.k1), s2 = p.k2 ? lds_stride(p.k2) : 0;
   bf16_t* t1 = lds;
   bf16_t* t2 = lds + (size_t)TG_M * s1;
+  const int n0 = wave * 64;
+  BFrags bfr;
+  float bias_v[2] = {0.f, 0.f};
+  if (n0 < N) {                                             // independent of the rows: in flight while they are gathered
+    b_preload(bfr, p.w1, p.w1_stride, p.k1, n0, N, lane);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) { const int col = n0 + 32 * nb + (lane & 31); if (p.bias && col < N) bias_v[nb] = bf2f(p.bias[col]); }
+  }
   if (tid < TG_M) {
     const int r = row0 + tid;
     row_id[tid] = r < M ? (p.ids ? p.ids[r] : r) : -1;
@@ -209,27 +232,29 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
       if (lane == 0) p.in_norm[r] = f2bf(sqrtf(ss));
     }
   }
-  const int n0 = wave * 32;
   f32x16_t acc[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   if (n0 < N) {
-    mma_product(t1, s1, p.k1, p.w1, p.w1_stride, n0, N, lane, acc);
-    if (p.k2) mma_product(t2, s2, p.k2, p.w2, p.w2_stride, n0, N, lane, acc);
+    mma_product(bfr, t1, s1, p.k1, p.w1, p.w1_stride, n0, N, lane, acc);
+    if (p.k2) {
+      b_preload(bfr, p.w2, p.w2_stride, p.k2, n0, N, lane);
+      mma_product(bfr, t2, s2, p.k2, p.w2, p.w2_stride, n0, N, lane, acc);
+    }
   }
   __syncthreads();                                          // every wave is done reading the staged rows: reuse the LDS for the output tile
-  const int so = ((N + 31) & ~31) + 8;
+  const int so = ((N + 63) & ~63) + 8;
   bf16_t* ot = lds;
   if (n0 < N) {
-    const int col = n0 + (lane & 31);
-    const float bv = (p.bias && col < N) ? bf2f(p.bias[col]) : 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {                            // (m = the wave's two column blocks)
+      const int col = n0 + 32 * m + (lane & 31);
+      const float bv = bias_v[m];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int lr = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int lr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
         float t = rbf(acc[m][i] + bv);                       // fp32 accumulator + bias, ONE rounding to bf16
         if (p.relu) t = t > 0.f ? t : 0.f;
         if (p.drop_thresh) {
@@ -238,6 +263,7 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
         }
         ot[(size_t)lr * so + col] = (row0 + lr < M && col < N) ? f2bf(t) : (bf16_t)0;
       }
+    }
   }
   __syncthreads();
   const int vec4 = (N % 4 == 0);
@@ -286,7 +312,7 @@ bool convert(const bliss_tile_gemm_t* a, TileGemm* p, size_t* lds_bytes, int* ti
   p->drop_scale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr;
   const size_t stage = (size_t)TG_M * (lds_stride(a->k1) + (a->k2 ? lds_stride(a->k2) : 0)) * sizeof(bf16_t);
-  const size_t outt = (size_t)TG_M * (((a->n + 31) & ~31) + 8) * sizeof(bf16_t);
+  const size_t outt = (size_t)TG_M * (((a->n + 63) & ~63) + 8) * sizeof(bf16_t);
   *lds_bytes = stage > outt ? stage : outt;
   *tiles = (a->m_bound + TG_M - 1) / TG_M;
   return true;
