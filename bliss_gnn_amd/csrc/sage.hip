@@ -131,53 +131,70 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long lo
   }
 }
 
-__device__ __forceinline__ bf16x8_t load_b_frag(const bf16_t* __restrict__ w, long long w_stride, int n, int kk, int K) {
-  union { uint4 u; bf16x8_t v; bf16_t e[8]; } x;
-  const bf16_t* p = w + (long long)n * w_stride + kk;      // n is clamped by the caller: always a real row of W
-  if (kk + 8 <= K && (((uintptr_t)p) & 3) == 0) {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-    x.u = make_uint4(q[0], q[1], q[2], q[3]);
-  } else {
+// W through LDS in slabs of 64 k: an MFMA B fragment is 16 bytes of ONE row of W per lane, so loading fragments straight
+// from global memory touches 32 different cache lines per wave instruction and uses a quarter of each (measured: the
+// texture path, not the matrix core, bounded the first version of this kernel at ~45 us per launch).  Staged through LDS,
+// 8 consecutive threads read one row's 128 contiguous bytes; the next slab is in flight (registers) while the current one
+// is multiplied.
+#define TG_SLAB 64
+#define TG_WSTRIDE (TG_SLAB + 8)
+#define TG_WROWS 256
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct WRegs { uint4 v[TG_WROWS * TG_SLAB / 8 / TG_TPB]; };      // 8 x 16 bytes per thread
+
+__device__ __forceinline__ void w_slab_load(WRegs& g, const bf16_t* __restrict__ w, long long w_stride, int N, int K, int slab, int tid) {
+  const int part = tid & 7, k = slab * TG_SLAB + 8 * part;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x.e[j] = (kk + j < K) ? p[j] : (bf16_t)0;
+  for (int i = 0; i < (int)(sizeof(g.v) / sizeof(g.v[0])); ++i) {
+    const int n = i * (TG_TPB / 8) + (tid >> 3);
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (n < N && k < K) {
+      const bf16_t* p = w + (long long)n * w_stride + k;
+      if (k + 8 <= K && (((uintptr_t)p) & 3) == 0) {
+        const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(p);
+        x = make_uint4(q[0], q[1], q[2], q[3]);
+      } else {
+        union { uint4 u; bf16_t e[8]; } t;
+        t.u = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) if (k + j < K) t.e[j] = p[j];
+        x = t.u;
+      }
+    }
+    g.v[i] = x;
   }
-  return x.v;
+}
+__device__ __forceinline__ void w_slab_store(const WRegs& g, bf16_t* wl, int tid) {
+  const int part = tid & 7;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(g.v) / sizeof(g.v[0])); ++i) {
+    const int n = i * (TG_TPB / 8) + (tid >> 3);
+    *reinterpret_cast<uint4*>(wl + (size_t)n * TG_WSTRIDE + 8 * part) = g.v[i];
+  }
 }
 
-// One wave: the tile's 32 rows x 64 columns (n0 ..), all of K.  B fragments come straight from global memory (L2), TG_PD
-// k-steps ahead; the first TG_PD steps' fragments are loaded by b_preload BEFORE the rows are staged -- they depend on
-// nothing, so their latency hides behind the row gather.
-#define TG_PD 8
-struct BFrags { bf16x8_t f[TG_PD][2]; };
-__device__ __forceinline__ void b_preload(BFrags& b, const bf16_t* __restrict__ w, long long w_stride, int k, int n0, int N, int lane) {
+// acc += A_tile[32 x K] . W[N x K]^T for this wave's 64 columns (n0 ..); all four waves take part in the slab traffic
+__device__ __forceinline__ void mma_product(const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w, long long w_stride,
+                                            int n0, int N, bf16_t* wl, int tid, int lane, f32x16_t acc[2]) {
   const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
+  const int nslab = (kp + TG_SLAB - 1) / TG_SLAB;
+  WRegs g;
+  w_slab_load(g, w, w_stride, N, k, 0, tid);
+  for (int sl = 0; sl < nslab; ++sl) {
+    __syncthreads();                                      // the previous slab has been consumed
+    w_slab_store(g, wl, tid);
+    if (sl + 1 < nslab) w_slab_load(g, w, w_stride, N, k, sl + 1, tid);
+    __syncthreads();
+    if (n0 < N) {
 #pragma unroll
-  for (int j = 0; j < TG_PD; ++j)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      int n = n0 + 32 * nb + r;
-      if (n >= N) n = N - 1;                               // columns beyond N: computed from a real row, never stored
-      if (16 * j < kp) b.f[j][nb] = load_b_frag(w, w_stride, n, 16 * j + 8 * h, k);
-    }
-}
-__device__ __forceinline__ void mma_product(BFrags& b, const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w,
-                                            long long w_stride, int n0, int N, int lane, f32x16_t acc[2]) {
-  const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
-  int n[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) { n[nb] = n0 + 32 * nb + r; if (n[nb] >= N) n[nb] = N - 1; }
-  for (int k0 = 0; k0 < kp; k0 += 16 * TG_PD) {
-#pragma unroll
-    for (int j = 0; j < TG_PD; ++j) {
-      const int ks = k0 + 16 * j;
-      if (ks < kp) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)r * stride + ks + 8 * h);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.f[j][0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.f[j][1], acc[1], 0, 0, 0);
-        const int kn = ks + 16 * TG_PD;
-        if (kn < kp) {
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) b.f[j][nb] = load_b_frag(w, w_stride, n[nb], kn + 8 * h, k);
+      for (int st = 0; st < TG_SLAB / 16; ++st) {
+        const int ks = sl * TG_SLAB + 16 * st;
+        if (ks < kp) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)r * stride + ks + 8 * h);
+          const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(wl + (size_t)(n0 + r) * TG_WSTRIDE + 16 * st + 8 * h);
+          const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(wl + (size_t)(n0 + 32 + r) * TG_WSTRIDE + 16 * st + 8 * h);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
         }
       }
     }
@@ -207,13 +224,10 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   bf16_t* t1 = lds;
   bf16_t* t2 = lds + (size_t)TG_M * s1;
   const int n0 = wave * 64;
-  BFrags bfr;
+  bf16_t* wl = lds + (size_t)TG_M * (s1 + s2);              // the W slab behind the staged rows
   float bias_v[2] = {0.f, 0.f};
-  if (n0 < N) {                                             // independent of the rows: in flight while they are gathered
-    b_preload(bfr, p.w1, p.w1_stride, p.k1, n0, N, lane);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) { const int col = n0 + 32 * nb + (lane & 31); if (p.bias && col < N) bias_v[nb] = bf2f(p.bias[col]); }
-  }
+  for (int nb = 0; nb < 2; ++nb) { const int col = n0 + 32 * nb + (lane & 31); if (p.bias && col < N) bias_v[nb] = bf2f(p.bias[col]); }
   if (tid < TG_M) {
     const int r = row0 + tid;
     row_id[tid] = r < M ? (p.ids ? p.ids[r] : r) : -1;
@@ -237,13 +251,8 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-  if (n0 < N) {
-    mma_product(bfr, t1, s1, p.k1, p.w1, p.w1_stride, n0, N, lane, acc);
-    if (p.k2) {
-      b_preload(bfr, p.w2, p.w2_stride, p.k2, n0, N, lane);
-      mma_product(bfr, t2, s2, p.k2, p.w2, p.w2_stride, n0, N, lane, acc);
-    }
-  }
+  mma_product(t1, s1, p.k1, p.w1, p.w1_stride, n0, N, wl, tid, lane, acc);
+  if (p.k2) mma_product(t2, s2, p.k2, p.w2, p.w2_stride, n0, N, wl, tid, lane, acc);
   __syncthreads();                                          // every wave is done reading the staged rows: reuse the LDS for the output tile
   const int so = ((N + 63) & ~63) + 8;
   bf16_t* ot = lds;
@@ -311,7 +320,7 @@ bool convert(const bliss_tile_gemm_t* a, TileGemm* p, size_t* lds_bytes, int* ti
   p->drop_thresh = a->drop_p > 0.f ? (unsigned)((double)a->drop_p * 4294967296.0) : 0u;
   p->drop_scale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr;
-  const size_t stage = (size_t)TG_M * (lds_stride(a->k1) + (a->k2 ? lds_stride(a->k2) : 0)) * sizeof(bf16_t);
+  const size_t stage = ((size_t)TG_M * (lds_stride(a->k1) + (a->k2 ? lds_stride(a->k2) : 0)) + (size_t)TG_WROWS * TG_WSTRIDE) * sizeof(bf16_t);
   const size_t outt = (size_t)TG_M * (((a->n + 63) & ~63) + 8) * sizeof(bf16_t);
   *lds_bytes = stage > outt ? stage : outt;
   *tiles = (a->m_bound + TG_M - 1) / TG_M;
