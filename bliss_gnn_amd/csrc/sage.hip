@@ -22,6 +22,7 @@
 // give identical bits.
 #include "common.cuh"
 #include "bliss_gnn.h"
+#include <cstdlib>
 
 namespace {
 
@@ -30,6 +31,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define TG_TPB 256
 #define TG_M 32
+#define TG_WAVES (TG_TPB / 64)
 
 struct TileGemm {
   const bf16_t* a1; long long a1_stride; const int* ids;
@@ -74,11 +76,41 @@ __device__ __forceinline__ float row_sumsq(const bf16_t* sh, int dim, int vec4, 
   return s;
 }
 
+// bf16 norms of this wave's rows of an LDS tile, each in k_embed_norm's summation order (row_sumsq), the rows side by side:
+// independent accumulators, so the LDS reads and the butterfly shuffles of the 8 rows overlap instead of queueing
+__device__ __forceinline__ void rows_norm(const bf16_t* tile, int stride, int dim, int row0, int M, int m_bound, bf16_t* __restrict__ out,
+                                          int wave, int lane) {
+  constexpr int RPW = TG_M / TG_WAVES;
+  float s[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) s[q] = 0.f;
+  if (dim % 4 == 0) {
+    for (int c = lane * 4; c < dim; c += 256)
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const bf16_t* sh = tile + (size_t)(q * TG_WAVES + wave) * stride + c;
+        const float a = bf2f(sh[0]), b = bf2f(sh[1]), cc = bf2f(sh[2]), d = bf2f(sh[3]);
+        s[q] += a * a; s[q] += b * b; s[q] += cc * cc; s[q] += d * d;
+      }
+  } else {
+    for (int c = lane; c < dim; c += 64)
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) { const float a = bf2f(tile[(size_t)(q * TG_WAVES + wave) * stride + c]); s[q] += a * a; }
+  }
+  for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) s[q] += __shfl_xor(s[q], d);
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int r = row0 + q * TG_WAVES + wave;
+    if (lane == 0 && r < m_bound) out[r] = r < M ? f2bf(sqrtf(s[q])) : (bf16_t)0;
+  }
+}
+
 // Stage the 64 rows of one operand in LDS.  The loads of all rows are independent and issued together: wave w takes rows
 // w, w + 8, ... (8 rounds), a lane the dwords lane, lane + 64, ... of its row, so ~40 loads per lane are in flight before
 // the first LDS store -- the gather is latency-bound (a random 1.2 KB row per id), not bandwidth-bound.  row_id[lr] = the
 // source row of tile row lr or -1 (beyond the true row count: zeros).  Optional copy-out of the staged rows.
-#define TG_WAVES (TG_TPB / 64)
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long long a_stride, const int* row_id, int k,
                                            int row0, int m_bound, bf16_t* tile, int stride, bf16_t* __restrict__ copy, long long copy_stride,
                                            int wave, int lane) {
@@ -88,9 +120,9 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long lo
   if (even) {
     const int dw = k / 2;
     constexpr int MAXC = (1024 / 2 + 63) / 64;          // dwords per lane and row at the largest K
-    constexpr int RPW = TG_M / TG_WAVES, HALF = RPW / 2;  // rows per wave, staged in two batches (register budget: 4 workgroups per CU)
+    constexpr int RPW = TG_M / TG_WAVES, HALF = RPW;      // rows per wave, all in flight together (LDS, not registers, bounds the occupancy)
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
+    for (int hb = 0; hb < 1; ++hb) {
       uint32_t v[HALF][MAXC];
 #pragma unroll
       for (int q = 0; q < HALF; ++q) {
@@ -98,8 +130,11 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ a, long lo
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a + (long long)(id < 0 ? 0 : id) * a_stride);
 #pragma unroll
         for (int j = 0; j < MAXC; ++j) {
+          // unconditional loads from clamped (always valid) addresses, masked afterwards: a load under a branch costs a full
+          // wait for everything outstanding, and these are meant to be in flight together
           const int c = lane + 64 * j;
-          v[q][j] = (id >= 0 && c < dw) ? src[c] : 0u;
+          const uint32_t x = src[c < dw ? c : dw - 1];
+          v[q][j] = (id >= 0 && c < dw) ? x : 0u;
         }
       }
 #pragma unroll
@@ -143,26 +178,35 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 struct WRegs { uint4 v[TG_WROWS * TG_SLAB / 8 / TG_TPB]; };      // 8 x 16 bytes per thread
 
-__device__ __forceinline__ void w_slab_load(WRegs& g, const bf16_t* __restrict__ w, long long w_stride, int N, int K, int slab, int tid) {
+// full slab (all 64 k inside K, rows 4-byte aligned): no branch, no mask -- rows beyond N are CLAMPED to a real row (their
+// columns are computed from it and never stored), so every lane issues its eight 16-byte loads unconditionally and the
+// compiler can count them (a load under a branch made it wait for ALL outstanding loads at every use)
+__device__ __forceinline__ void w_slab_load_full(WRegs& g, const bf16_t* __restrict__ w, long long w_stride, int N, int slab, int tid) {
   const int part = tid & 7, k = slab * TG_SLAB + 8 * part;
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(g.v) / sizeof(g.v[0])); ++i) {
-    const int n = i * (TG_TPB / 8) + (tid >> 3);
-    uint4 x = make_uint4(0, 0, 0, 0);
-    if (n < N && k < K) {
-      const bf16_t* p = w + (long long)n * w_stride + k;
-      if (k + 8 <= K && (((uintptr_t)p) & 3) == 0) {
-        const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(p);
-        x = make_uint4(q[0], q[1], q[2], q[3]);
-      } else {
-        union { uint4 u; bf16_t e[8]; } t;
-        t.u = make_uint4(0, 0, 0, 0);
-        for (int j = 0; j < 8; ++j) if (k + j < K) t.e[j] = p[j];
-        x = t.u;
-      }
-    }
-    g.v[i] = x;
+    int n = i * (TG_TPB / 8) + (tid >> 3);
+    n = n < N ? n : N - 1;
+    const u32x4_a4 q = *reinterpret_cast<const u32x4_a4*>(w + (long long)n * w_stride + k);
+    g.v[i] = make_uint4(q[0], q[1], q[2], q[3]);
   }
+}
+// the last, partial slab (or odd alignment): element-wise with masks
+__device__ __forceinline__ void w_slab_load_tail(WRegs& g, const bf16_t* __restrict__ w, long long w_stride, int N, int K, int slab, int tid) {
+  const int part = tid & 7, k = slab * TG_SLAB + 8 * part;
+  for (int i = 0; i < (int)(sizeof(g.v) / sizeof(g.v[0])); ++i) {
+    int n = i * (TG_TPB / 8) + (tid >> 3);
+    n = n < N ? n : N - 1;
+    const bf16_t* p = w + (long long)n * w_stride + k;
+    union { uint4 u; bf16_t e[8]; } t;
+    t.u = make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) if (k + j < K) t.e[j] = p[j];
+    g.v[i] = t.u;
+  }
+}
+// how many leading slabs of this W take the branch-free path
+__device__ __forceinline__ int w_full_slabs(const bf16_t* w, long long w_stride, int K) {
+  return ((w_stride % 2 == 0) && (((uintptr_t)w) % 4 == 0)) ? K / TG_SLAB : 0;
 }
 __device__ __forceinline__ void w_slab_store(const WRegs& g, bf16_t* wl, int tid) {
   const int part = tid & 7;
@@ -174,17 +218,11 @@ __device__ __forceinline__ void w_slab_store(const WRegs& g, bf16_t* wl, int tid
 }
 
 // acc += A_tile[32 x K] . W[N x K]^T for this wave's 64 columns (n0 ..); all four waves take part in the slab traffic
-__device__ __forceinline__ void mma_product(const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w, long long w_stride,
-                                            int n0, int N, bf16_t* wl, int tid, int lane, f32x16_t acc[2]) {
+__device__ __forceinline__ void mma_product(WRegs& ga, WRegs& gb, const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w,
+                                            long long w_stride, int n0, int N, bf16_t* wl, int tid, int lane, f32x16_t acc[2]) {
   const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
   const int nslab = (kp + TG_SLAB - 1) / TG_SLAB;
-  WRegs g;
-  w_slab_load(g, w, w_stride, N, k, 0, tid);
-  for (int sl = 0; sl < nslab; ++sl) {
-    __syncthreads();                                      // the previous slab has been consumed
-    w_slab_store(g, wl, tid);
-    if (sl + 1 < nslab) w_slab_load(g, w, w_stride, N, k, sl + 1, tid);
-    __syncthreads();
+  auto multiply = [&](int sl) {
     if (n0 < N) {
 #pragma unroll
       for (int st = 0; st < TG_SLAB / 16; ++st) {
@@ -198,10 +236,37 @@ __device__ __forceinline__ void mma_product(const bf16_t* tile, int stride, int 
         }
       }
     }
+  };
+  // Two register sets (ga: even slabs, gb: odd), two slabs in flight beside the one being multiplied; the caller has
+  // requested slabs 0 and 1.  Only full slabs run through this pipeline: their loads are unconditional, so the compiler's
+  // wait before a set's LDS store counts exactly that set's (older) loads.
+  const int nfull = w_full_slabs(w, w_stride, k);
+  for (int sl = 0; sl < nfull; sl += 2) {
+    __syncthreads();                                      // the previous slab has been consumed
+    w_slab_store(ga, wl, tid);
+    if (sl + 2 < nfull) w_slab_load_full(ga, w, w_stride, N, sl + 2, tid);
+    __syncthreads();
+    multiply(sl);
+    if (sl + 1 < nfull) {
+      __syncthreads();
+      w_slab_store(gb, wl, tid);
+      if (sl + 3 < nfull) w_slab_load_full(gb, w, w_stride, N, sl + 3, tid);
+      __syncthreads();
+      multiply(sl + 1);
+    }
+  }
+  // the partial last slab (K not a multiple of 64) or an oddly aligned W: one slab at a time, masked element loads
+  for (int sl = nfull; sl < nslab; ++sl) {
+    WRegs t;
+    w_slab_load_tail(t, w, w_stride, N, k, sl, tid);
+    __syncthreads();
+    w_slab_store(t, wl, tid);
+    __syncthreads();
+    multiply(sl);
   }
 }
 
-__device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, int* row_id) {
+__device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, int* row_id, int dbg) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int M = p.m_bound;
   if (p.m_dev) { const int t = *p.m_dev; M = t < M ? t : M; }
@@ -228,31 +293,35 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   float bias_v[2] = {0.f, 0.f};
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) { const int col = n0 + 32 * nb + (lane & 31); if (p.bias && col < N) bias_v[nb] = bf2f(p.bias[col]); }
+  // the first two W slabs depend on nothing: requested now, they arrive while the rows are gathered
+  WRegs ga, gb;
+  {
+    const int nf = w_full_slabs(p.w1, p.w1_stride, p.k1);
+    if (nf > 0) w_slab_load_full(ga, p.w1, p.w1_stride, N, 0, tid);
+    if (nf > 1) w_slab_load_full(gb, p.w1, p.w1_stride, N, 1, tid);
+  }
   if (tid < TG_M) {
     const int r = row0 + tid;
     row_id[tid] = r < M ? (p.ids ? p.ids[r] : r) : -1;
     row_id[TG_M + tid] = r < M ? r : -1;
   }
   __syncthreads();
-  stage_rows(p.a1, p.a1_stride, row_id, p.k1, row0, p.m_bound, t1, s1, p.a_copy, p.copy_stride, wave, lane);
+  if (!(dbg & 1)) stage_rows(p.a1, p.a1_stride, row_id, p.k1, row0, p.m_bound, t1, s1, p.a_copy, p.copy_stride, wave, lane);
   if (p.k2) stage_rows(p.a2, p.a2_stride, row_id + TG_M, p.k2, row0, p.m_bound, t2, s2, nullptr, 0, wave, lane);
   __syncthreads();
-  if (p.in_norm) {                                          // model.py:318-320 of THIS layer, in k_embed_norm's order
-    const int vec4 = (p.k1 % 4 == 0);
-    for (int lr = wave; lr < TG_M; lr += TG_WAVES) {
-      const int r = row0 + lr;
-      if (r >= p.m_bound) break;
-      const float ss = r < M ? row_sumsq(t1 + (size_t)lr * s1, p.k1, vec4, lane) : 0.f;
-      if (lane == 0) p.in_norm[r] = f2bf(sqrtf(ss));
-    }
-  }
+  if (p.in_norm && !(dbg & 4)) rows_norm(t1, s1, p.k1, row0, M, p.m_bound, p.in_norm, wave, lane);   // model.py:318-320 of THIS layer
   f32x16_t acc[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-  mma_product(t1, s1, p.k1, p.w1, p.w1_stride, n0, N, wl, tid, lane, acc);
-  if (p.k2) mma_product(t2, s2, p.k2, p.w2, p.w2_stride, n0, N, wl, tid, lane, acc);
+  if (!(dbg & 2)) mma_product(ga, gb, t1, s1, p.k1, p.w1, p.w1_stride, n0, N, wl, tid, lane, acc);
+  if (p.k2) {
+    const int nf = w_full_slabs(p.w2, p.w2_stride, p.k2);
+    if (nf > 0) w_slab_load_full(ga, p.w2, p.w2_stride, N, 0, tid);
+    if (nf > 1) w_slab_load_full(gb, p.w2, p.w2_stride, N, 1, tid);
+    mma_product(ga, gb, t2, s2, p.k2, p.w2, p.w2_stride, n0, N, wl, tid, lane, acc);
+  }
   __syncthreads();                                          // every wave is done reading the staged rows: reuse the LDS for the output tile
   const int so = ((N + 63) & ~63) + 8;
   bf16_t* ot = lds;
@@ -275,24 +344,23 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
     }
   }
   __syncthreads();
-  const int vec4 = (N % 4 == 0);
+  const bool pair_ok = (N % 2 == 0) && (p.out_stride % 2 == 0) && (((uintptr_t)p.out) % 4 == 0);
   for (int lr = wave; lr < TG_M; lr += TG_WAVES) {
     const int r = row0 + lr;
     if (r >= p.m_bound) break;
     const bf16_t* sh = ot + (size_t)lr * so;
     bf16_t* o = p.out + (long long)r * p.out_stride;
-    for (int c = lane; c < N; c += 64) o[c] = sh[c];
-    if (p.out_norm) {
-      const float ss = r < M ? row_sumsq(sh, N, vec4, lane) : 0.f;
-      if (lane == 0) p.out_norm[r] = f2bf(sqrtf(ss));
-    }
+    if (pair_ok) for (int c = lane * 2; c < N; c += 128) *reinterpret_cast<uint32_t*>(o + c) = *reinterpret_cast<const uint32_t*>(sh + c);
+    else for (int c = lane; c < N; c += 64) o[c] = sh[c];
   }
+  if (p.out_norm) rows_norm(ot, so, N, row0, M, p.m_bound, p.out_norm, wave, lane);
 }
 
-__global__ void __launch_bounds__(TG_TPB) k_tile_gemm(TileGemm p0, TileGemm p1, int n_sets) {
+__global__ void __launch_bounds__(TG_TPB) k_tile_gemm(TileGemm p0, TileGemm p1, int n_sets, int dbg) {
   extern __shared__ __attribute__((aligned(16))) bf16_t tg_lds[];
   __shared__ int row_id[2 * TG_M];
-  tile_gemm_body(blockIdx.y == 0 ? p0 : p1, tg_lds, row_id);
+  if (dbg & 8) return;
+  tile_gemm_body(blockIdx.y == 0 ? p0 : p1, tg_lds, row_id, dbg);
   // dropout stream: the last workgroup of the launch bumps the device-resident launch counter (everybody has read it)
   unsigned long long* ctr = p0.drop_thresh ? p0.ctr : (n_sets > 1 && p1.drop_thresh ? p1.ctr : nullptr);
   if (ctr) {
@@ -345,6 +413,7 @@ extern "C" int bliss_tile_gemm(const bliss_tile_gemm_t* first, const bliss_tile_
     lds_set = lds;
   }
   const dim3 grid(t0 > t1 ? t0 : t1, second ? 2 : 1);
-  k_tile_gemm<<<grid, TG_TPB, lds, (hipStream_t)stream>>>(p0, p1, second ? 2 : 1);
+  static const int dbg = []() { const char* e = getenv("BLISS_TG_DEBUG"); return e ? atoi(e) : 0; }();
+  k_tile_gemm<<<grid, TG_TPB, lds, (hipStream_t)stream>>>(p0, p1, second ? 2 : 1, dbg);
   return (int)hipGetLastError();
 }
