@@ -53,7 +53,13 @@ class SAGE(nn.Module):
     def _mfma_ok(self, x):
         """The fused matrix-core path (csrc/sage.hip) covers the reference's configuration: bf16 on the GPU, ReLU, every
         layer within the tile kernel's limits (in <= 1024, out <= 256)."""
+        import os
         from .nn import tile_gemm_ok
+        # opt-in: on the Reddit-like step the hand-written tiles are at parity with the tuned library GEMMs on the 602-wide
+        # input layer (45 vs 46 us, two launches fewer) and slower on the two small layers (31 vs 23, 19 vs 18 us; DESIGN.md
+        # section 5: PMC counters show waves waiting 57 % of their cycles, no unit saturated) -- the default stays the faster path
+        if os.environ.get("BLISS_SAGE_MFMA", "0") != "1":
+            return False
         act = self.activation
         relu = act in (torch.relu, torch.nn.functional.relu) or isinstance(act, nn.ReLU)
         dims = all(tile_gemm_ok(l._in_src_feats, l._out_feats) and l.fc_self.bias is not None and l.norm is None and l.activation is None

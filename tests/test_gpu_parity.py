@@ -1648,7 +1648,7 @@ def test_mfma_dual_product_and_pair_launch(cuda):
         assert torch.allclose(got.float(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
 
 
-def test_sage_mfma_path_matches_unfused_path(cuda):
+def test_sage_mfma_path_matches_unfused_path(cuda, monkeypatch):
     """SAGE.forward through the fused MFMA kernels == the round-1 path (library GEMMs + separate gather / epilogue) within
     bf16 rounding, same embed_norm bits on the input layer, and the lazy feature gather == the materialised one bit for bit."""
     from bliss_gnn_amd.model import SAGE
@@ -1662,11 +1662,13 @@ def test_sage_mfma_path_matches_unfused_path(cuda):
     _, _, blocks = bg.PoissonBanditLadiesSampler([400, 200, 100], eta=0.1).sample_blocks(g, torch.arange(64, dtype=torch.int32, device=cuda))
     torch.manual_seed(0)
     model = SAGE(602, 256, 41, 3, torch.relu, 0.0).to(cuda).bfloat16()
+    monkeypatch.setenv("BLISS_SAGE_MFMA", "1")
+    assert model._mfma_ok(feats)
     a = model(blocks, blocks[0].srcdata.lazy("features"))
     norms_a = [b.srcdata["embed_norm"].clone() for b in blocks]
     b_ = model(blocks, blocks[0].srcdata["features"])                      # materialised rows, still the MFMA path
     assert torch.equal(a, b_)
-    model._mfma_ok = lambda x: False                                       # the unfused path
+    monkeypatch.setenv("BLISS_SAGE_MFMA", "0")                            # the unfused path
     c = model(blocks, blocks[0].srcdata["features"])
     assert torch.equal(norms_a[0].view(torch.int16), blocks[0].srcdata["embed_norm"].view(torch.int16))
     scale = float(c.float().abs().max())
