@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: run the replica exchange path (gradient all-reduce, EXP3 all-gather + apply) on a world of "
                          "one rank -- what the multi-GPU step costs per GPU before any communication time")
+    ap.add_argument("--mode", default="train", choices=["train", "inference"],
+                    help="inference: time SAGE.inference -- layer-wise full-neighbour evaluation of ALL nodes (model.py:335-383), the one "
+                         "whole-graph SpMM of the reference -- with its own roofline")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only (gloo, no GPU, no kernels): what a CPU-only box can check of --gpus N")
     return ap.parse_args()
@@ -147,6 +150,8 @@ def main():
     t_setup = time.time() - t0
 
     fan, eta, hidden = cfg["fanouts"], 0.1, 256
+    if args.mode == "inference":
+        return bench_inference(args, g, cfg, hidden, dev, t_setup)
     if args.sampler == "poisson-ladies":
         sampler = bg.PoissonLadiesSampler(fan)
     else:
@@ -207,8 +212,9 @@ def main():
         sizes = []
         while n > 0:
             if pipelined and n >= 2 and not eager:
-                sizes += step.run(loader, n // 2, pair_events=pair_events)
-                n -= n // 2 * 2
+                got = step.run(loader, n // 2, pair_events=pair_events)
+                sizes += got
+                n -= max(len(got), n // 2 * 2)              # (a capacity regrow inside run() trains three batches more)
             elif pipelined and n >= 2:
                 step.eager_pair(loader)
                 sizes += step.sizes2()
@@ -235,6 +241,7 @@ def main():
     all_sizes = advance(args.steps, pair_events=pair_events)
     sync()
     dt = time.perf_counter() - t1
+    steps_done = len(all_sizes)                        # == args.steps unless a capacity regrow happened inside the window (+3)
     # per-step device time: differences of timing events recorded on the critical stream at every pair boundary (two steps)
     step_ms = []
     if pair_events:
@@ -272,14 +279,14 @@ def main():
         dom_timing = timer.read().get(dominant)
         timer.enable("off")
     sampler.check_errors()
-    steps_total = args.steps * world
-    mean_sizes = [{k: v / args.steps for k, v in s.items()} for s in sizes_acc]
+    steps_total = steps_done * world
+    mean_sizes = [{k: v / steps_done for k, v in s.items()} for s in sizes_acc]
     alg = algorithmic_bytes(mean_sizes, cfg["feat"], dims)
 
     out = {
         "metric": "steps/sec (train step: sample_blocks + gather + %s fwd/bwd + Adam + exp3), %s-like" % ("SAGE" if args.model == "sage" else "GATv2", args.config),
-        "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": steps_total / dt, "unit": "steps/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / steps_done, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer %s hidden %d, poisson-bandit eta %.1f, "
                                "fanouts %s, batch %d per GPU%s" % (args.config, g.num_nodes(), g.num_edges(), cfg["feat"],
@@ -292,11 +299,12 @@ def main():
                    "global_batch": cfg["batch"] * world},
         "sampled_edges_per_sec": n_edges / dt, "frontier_edges_per_sec": n_frontier / dt,
         "sizes_per_step": mean_sizes, "algorithmic_bytes_per_step": alg,
-        "algorithmic_GBps": alg["total"] * (args.steps / dt) / 1e9, "frac_of_8TBps": alg["total"] * (args.steps / dt) / 8e12,
+        "algorithmic_GBps": alg["total"] * (steps_done / dt) / 1e9, "frac_of_8TBps": alg["total"] * (steps_done / dt) / 8e12,
         "setup_s": t_setup,
         # `value` is the mean over the whole timed window (EXP3 renormalisation passes included when they fall into it);
         # the distribution of the per-step device time over the same window, from events at every two-step boundary:
-        "value_is": "mean over %d consecutive steps" % args.steps,
+        "value_is": "mean over %d consecutive steps" % steps_done,
+        "capacity_regrows": int(getattr(step, "regrows", 0)),
         "step_ms_percentiles": percentiles(step_ms),
     }
 
@@ -349,6 +357,52 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_inference(args, g, cfg, hidden, dev, t_setup):
+    """SAGE.inference over the whole graph (train_lightning.py:686-705 -> model.py:335-383): per layer one mean-SpMM over all
+    |E_g| edges + the two Linear layers.  A 'step' here = one full inference pass (3 layers, all nodes)."""
+    from bliss_gnn_amd import roofline
+    from bliss_gnn_amd.model import SAGE
+    torch.manual_seed(1234)
+    model = SAGE(cfg["feat"], hidden, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()
+    V, E = g.num_nodes(), g.num_edges()
+    timer = roofline.KernelTimer()
+    for _ in range(max(1, min(args.warmup, 2))):
+        model.inference(g)
+    torch.cuda.synchronize()
+    n = max(1, min(args.steps, 10))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record()
+    for i in range(n):
+        model.inference(g)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])]
+    timer.enable("k_spmm_fwd")
+    model.inference(g)
+    torch.cuda.synchronize()
+    spmm = timer.read().get("k_spmm_fwd")
+    timer.enable("off")
+    dims = [hidden, hidden, cfg["classes"]]                       # SpMM widths (in > out: the Linear runs first), SURVEY.md m2
+    # algorithmic HBM bytes of the aggregation per layer: CSC pointers + indices once, the feature rows in, the result out
+    layer_bytes = [4 * (V + 1) + 4 * E + 2 * V * d * 2 for d in dims]
+    total = float(sum(layer_bytes))
+    mean_ms = sum(ms) / len(ms)
+    out = {"metric": "full-neighbour inference passes/sec (SAGE.inference, all %d nodes, 3 layers), %s-like" % (V, args.config),
+           "value": 1e3 / mean_ms, "unit": "passes/s", "n_gpus": 1, "steps": n, "warmup": args.warmup, "ms_per_step": mean_ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "%s-like Chung-Lu graph |V|=%d |E|=%d F=%d, 3-layer SAGE hidden %d, layer-wise full-neighbour inference"
+                                  % (args.config, V, E, cfg["feat"], hidden)},
+           "pass_ms_percentiles": percentiles(ms), "edges_per_sec": 3.0 * E / (mean_ms * 1e-3), "setup_s": t_setup}
+    if spmm:
+        achieved = total / (spmm["total_ms"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_spmm_fwd (mean over ALL in-edges, %d launches per pass)" % spmm["launches"],
+                           "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / roofline.HBM_PEAK_GBPS,
+                           "traffic": None, "algorithmic_bytes_per_pass": total, "spmm_ms_per_pass": spmm["total_ms"],
+                           "note": "algorithmic bytes = 4(V+1) + 4|E| + 2 V D (in) + 2 V D (out) per layer; the gathered rows (|E| x 2D bytes) "
+                                   "are served by L2 / Infinity Cache and are not counted"}
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(g, feats, labels, train_nid, cfg, fan, eta, hidden, n_steps):

@@ -171,6 +171,7 @@ class GraphedTrainStep:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             mx = [dict(K=int(k), B=int(b), E=int(e)) for k, b, e in t.tolist()]
         fan = [self.sampler.nodes_per_layer[b] for b in reversed(range(L))]
+        self._margins, self._hw = (k_margin, b_margin), [dict(m) for m in mx]
         self.sampler._engine.set_static_caps(self.bs, fan, mx, k_margin, b_margin)
 
     def _body(self):
@@ -536,6 +537,50 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._finish_pair()
         return self.losses
 
+    # -- capacities that follow the run --------------------------------------------------------------------------------
+    # Static capacities come from a few steps taken while the bandit weights are uniform; as the weights move, the kept sets
+    # and blocks drift.  A step that exceeds a capacity is clamped and flagged only afterwards (its update is invalid), so
+    # the loop watches the sizes that come back with every pair and acts BEFORE that: once a size passes ``regrow_at`` of
+    # its capacity, the next run() first trains the batch in flight, recalibrates from the high-water marks, re-captures
+    # the graphs and carries on -- the batches, their order and the sampler's random stream are those of the plain loop.
+    regrow_at = 0.85
+
+    def _watch(self, sizes):
+        caps = self.sampler._engine.caps
+        L = len(caps)
+        for sz in sizes:                                   # per batch: blocks input-most first = sampling order reversed
+            for l, s_ in enumerate(sz):
+                n = L - 1 - l
+                hw = self._hw[n]
+                for k in ("K", "B", "E"):
+                    hw[k] = max(hw.get(k, 0), int(s_[k]))
+                if s_["K"] > self.regrow_at * caps[n]["K"] or s_["B"] > self.regrow_at * caps[n]["B"] or \
+                        (self.distributed and s_["B"] > self.regrow_at * caps[n].get("X", caps[n]["B"])):
+                    self._needs_regrow = True
+
+    def _regrow(self, loader):
+        """Train the batch in flight, enlarge the capacities to the high-water marks (x the calibration margins), re-capture.
+        Returns the sizes of the two batches the re-capture sampled (it replays one pair)."""
+        eng = self.sampler._engine
+        L = len(self.sampler.nodes_per_layer)
+        self.drain()
+        mx = [dict(h) for h in self._hw]
+        if self.distributed:                               # every rank must end up with the same capacities
+            import torch.distributed as dist
+            t = torch.tensor([[m["K"], m["B"], m["E"]] for m in mx], dtype=torch.int64, device=self.g.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mx = [dict(K=int(k), B=int(b), E=int(e)) for k, b, e in t.tolist()]
+        GraphedTrainStep.close(self)                       # quiesce, drop the graphs recorded for the old shapes
+        fan = [self.sampler.nodes_per_layer[b] for b in reversed(range(L))]
+        eng.set_static_caps(self.bs, fan, mx, *self._margins)
+        if self.use_flags:
+            eng.scratch_sets = max(eng.scratch_sets, L)
+        self._needs_regrow = False
+        self.regrows = getattr(self, "regrows", 0) + 1
+        self.prime(next(loader))
+        self._capture_graphs(loader)
+        return self.sizes2()
+
     def run(self, loader, n_pairs, ring=4, pair_events=None):
         """``n_pairs`` calls without a host round trip in between: the generator state is chained on the device from
         batch to batch (torch's CPU generator is brought up to date once, at the end), and sizes / error words come back
@@ -549,6 +594,8 @@ class PipelinedTrainStep(GraphedTrainStep):
             self._ring = [torch.empty(2 * L * 10, dtype=torch.int32).pin_memory() for _ in range(ring)]
             self._ring_ev = [torch.cuda.Event() for _ in range(ring)]
         sizes, pending, bad = [], [], 0
+        if getattr(self, "_needs_regrow", False):          # (the re-capture trains three batches itself: one drained, one pair)
+            sizes += self._regrow(loader)
 
         def collect(i):
             nonlocal bad
@@ -619,7 +666,9 @@ class PipelinedTrainStep(GraphedTrainStep):
             self._finish_pair()
         if bad:
             raise RuntimeError(f"static-shape step exceeded its capacities or hit a kernel error 0x{bad:x} "
-                               f"({_lib.err_string(bad)}); results are invalid -- raise the margins")
+                               f"({_lib.err_string(bad)}) before the early-warning regrow could act; results are invalid -- "
+                               f"raise the margins or lower regrow_at")
+        self._watch(sizes)
         return sizes
 
     def eager_pair(self, loader):

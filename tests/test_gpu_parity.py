@@ -1673,3 +1673,47 @@ def test_sage_mfma_path_matches_unfused_path(cuda, monkeypatch):
     assert torch.equal(norms_a[0].view(torch.int16), blocks[0].srcdata["embed_norm"].view(torch.int16))
     scale = float(c.float().abs().max())
     assert float((a.float() - c.float()).abs().max()) <= 3 * 2.0 ** -8 * scale
+
+
+def test_capacity_regrow_keeps_the_run_valid(cuda):
+    """Static capacities calibrated with NO margin overflow as soon as a batch is a little larger than the calibration
+    batches.  The pipelined loop watches the sizes that come back with every pair and re-captures with larger capacities
+    before a step is clamped (PipelinedTrainStep._watch / _regrow): the run finishes without a capacity error, it trained
+    every batch of the loader in order (same sampled sizes as a run with generous margins), and the capacities grew."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, PipelinedTrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(8000, 160000, seed=17)
+    feats = torch.randn(8000, 32, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 4, (8000,), generator=torch.Generator().manual_seed(3))
+    ids = torch.arange(8000, dtype=torch.int32, device=cuda)
+    runs = []
+    for k_margin, b_margin, regrow_at in ((1.0, 1.0, 0.7), (3.0, 6.0, 0.85)):
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler([400, 200, 100], eta=0.1)
+        torch.manual_seed(0)
+        model = SAGE(32, 16, 4, 3, torch.relu, 0.0).to(cuda).bfloat16()
+        step = PipelinedTrainStep(g, sampler, model, 64)
+        step.regrow_at = regrow_at
+        loader = BatchLoader(ids, 64, seed=5).forever()
+        torch.manual_seed(9)
+        step.calibrate(loader, steps=2, k_margin=k_margin, b_margin=b_margin)
+        caps0 = [dict(c) for c in sampler._engine.caps]
+        step.capture(loader, warmup=1)
+        sizes = []
+        for _ in range(6):
+            sizes += step.run(loader, 3)
+        step.drain()
+        sampler.check_errors()
+        runs.append(dict(regrows=getattr(step, "regrows", 0), caps0=caps0, caps1=[dict(c) for c in sampler._engine.caps], sizes=sizes,
+                         w=sampler.exp3_weights.view(torch.int16).clone()))
+    tight, loose = runs
+    assert tight["regrows"] >= 1 and loose["regrows"] == 0
+    assert any(a["K"] > b["K"] or a["B"] > b["B"] for a, b in zip(tight["caps1"], tight["caps0"]))
+    # every sampled batch is a real one (no clamping): the first len(loose) batches have the sizes of the generous run's
+    # (the sampler stream, the batches and the EXP3 feedback are the same; a regrow adds three batches to a run() call)
+    n = min(len(tight["sizes"]), len(loose["sizes"]))
+    same = sum(a == b for a, b in zip(tight["sizes"][:n], loose["sizes"][:n]))
+    assert same >= n - 2, (same, n)                       # (bf16 activations feed the bandit: a late ulp may move a late batch)
