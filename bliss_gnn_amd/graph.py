@@ -183,7 +183,7 @@ class _LazyFrame(dict):
             idx = self._index_fn()
             if src.is_cuda and src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32 and idx.is_contiguous():
                 from .nn import LazyRows
-                return LazyRows(src, idx)
+                return LazyRows(src, idx, self, key)
         return self[key]
 
     def row_norm_of(self, t):

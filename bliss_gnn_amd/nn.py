@@ -122,12 +122,16 @@ class LazyRows:
     """``table[ids]`` not gathered yet: ``block.srcdata.lazy('features')``.  SAGE.forward hands it to the fused transform,
     whose A-operand load IS the gather (train_lightning.py:138 + model.py:318-329 in one launch)."""
 
-    def __init__(self, table, ids):
-        self.table, self.ids = table, ids
+    def __init__(self, table, ids, frame=None, key=None):
+        self.table, self.ids, self._frame, self._key = table, ids, frame, key
         self.shape, self.dtype, self.device = (ids.numel(), table.shape[1]), table.dtype, table.device
         self.is_cuda = table.is_cuda
 
     def materialize(self):
+        """The rows as a tensor: through the owning frame when there is one (its gather kernel also leaves the row norms the
+        model asks for next, graph._LazyFrame), else a plain index_select."""
+        if self._frame is not None:
+            return self._frame[self._key]
         return torch.index_select(self.table, 0, self.ids)
 
 

@@ -4,12 +4,15 @@ set -o pipefail
 T=$1; O=gpurun_out/$T; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 echo "[1] bench default"; timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
-echo "[2] kernel stats"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 100 --warmup 20 --cpu-baseline-steps 0 --tune-gemm 0 > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
-python scratch/timeline2.py $O/prof > $O/pair_timeline.txt 2>&1
+echo "[1b] bench inference"; timeout -k 10 300 python bench.py --mode inference --steps 5 --warmup 1 > $O/bench_inference.json 2> $O/bench_inference.err || exit 1
+echo "[1c] bench force-dist"; timeout -k 10 300 python bench.py --steps 200 --warmup 40 --cpu-baseline-steps 0 --no-roofline --force-dist > $O/bench_force_dist.json 2> $O/bench_force_dist.err || exit 1
+echo "[2] kernel stats"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 100 --warmup 20 --cpu-baseline-steps 0 --tune-gemm 0 --no-roofline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
+python scratch/timeline3.py $O/prof > $O/step_timeline.txt 2>&1
 cp $O/prof/*/*_kernel_stats.csv $O/kernel_stats_pipelined.csv
 echo "[3] pmc fetch"; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 bench.py --steps 10 --warmup 4 --no-roofline --cpu-baseline-steps 0 --tune-gemm 0 > $O/pmc_f.log 2>&1 || exit 1
 echo "[4] pmc write"; timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 bench.py --steps 10 --warmup 4 --no-roofline --cpu-baseline-steps 0 --tune-gemm 0 > $O/pmc_w.log 2>&1 || exit 1
 python scratch/pmc_traffic.py $O/pmc_f $O/pmc_w $O/pmc_traffic.json > $O/pmc_summary.txt
-echo "[5] phases"; timeout -k 10 200 python scratch/phases2.py > $O/phase_times.txt 2>&1
+echo "[5] other configs"; for c in yelp pubmed cora; do timeout -k 10 200 python bench.py --config $c --steps 200 --warmup 20 --cpu-baseline-steps 0 --no-roofline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c', round(o['value'],1), 'steps/s', round(o['ms_per_step'],4), 'ms/step', o['step_ms_percentiles'])" >> $O/other_configs.txt; done
+timeout -k 10 300 python bench.py --model gat --steps 100 --warmup 20 --cpu-baseline-steps 0 --no-roofline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('reddit-gat', round(o['value'],1), 'steps/s', round(o['ms_per_step'],4), 'ms/step', o['step_ms_percentiles'])" >> $O/other_configs.txt
 rm -rf $O/prof $O/pmc_f $O/pmc_w
-ls -la $O
+ls -la $O; cat $O/other_configs.txt
