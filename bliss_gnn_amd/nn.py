@@ -14,69 +14,35 @@ from ._engine import _stream
 
 
 def embed_norm(h):
-    """``th.reshape(th.norm(h, dim=1, keepdim=True), (-1,))`` of model.py:318-320 -> bf16 [K]."""
+    """``th.reshape(th.norm(h, dim=1, keepdim=True), (-1,))`` of model.py:318-320 -> bf16 [K]  (``torch.ops.bliss.embed_norm``)."""
+    from . import ops
     h = h.detach()
     if h.dtype != torch.bfloat16:
         h = h.bfloat16()
     if h.stride(1) != 1:
         h = h.contiguous()
-    out = torch.empty(h.shape[0], dtype=torch.bfloat16, device=h.device)
-    _lib.check(_lib.lib.bliss_embed_norm(h.data_ptr(), h.shape[0], h.shape[1], h.stride(0), out.data_ptr(), _stream()),
-               "bliss_embed_norm")
-    return out
-
-
-class _WeightedAggregate(torch.autograd.Function):
-    """out[i] = (1/deg_i if mean) * sum_{e -> i} w_e h[src_e]; gradient w.r.t. h only (the sampler's
-    edge weights carry no grad)."""
-
-    @staticmethod
-    def forward(ctx, h, block, edge_weight, mean, out_fp32):
-        assert h.is_cuda and h.dtype == torch.bfloat16, "bf16 features on the GPU (load_graph.py:7)"
-        if h.stride(1) != 1:
-            h = h.contiguous()
-        S, D = block.num_dst_nodes(), h.shape[1]
-        out = torch.empty(S, D, dtype=torch.float32 if out_fp32 else torch.bfloat16, device=h.device)
-        w = None
-        if edge_weight is not None:
-            w = edge_weight.reshape(-1)
-            if w.dtype != torch.bfloat16:
-                w = w.bfloat16()
-            w = w.contiguous()
-            assert w.numel() == block.num_edges()
-        B = block.num_edges()
-        ec = _lib.lib.bliss_spmm_chunk_edges(B)
-        part = torch.empty(2 * ((B + ec - 1) // ec) * D, dtype=torch.float32, device=h.device) if B > 0 else None
-        _lib.check(_lib.lib.bliss_spmm_fwd(block.indptr.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
-                                           0 if w is None else w.data_ptr(), h.data_ptr(), h.stride(0), S, block._nnz_ptr, B, D,
-                                           int(mean),
-                                           out.data_ptr(), out.stride(0), int(out_fp32), 0 if part is None else part.data_ptr(),
-                                           _stream()), "bliss_spmm_fwd")
-        ctx.block, ctx.w, ctx.mean, ctx.n_src = block, w, mean, h.shape[0]
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        block, w = ctx.block, ctx.w
-        gout = gout.contiguous()
-        if gout.dtype != torch.bfloat16:
-            gout = gout.bfloat16()
-        D = gout.shape[1]
-        t_indptr, t_edge = block.transposed()
-        gh = torch.empty(ctx.n_src, D, dtype=torch.bfloat16, device=gout.device)
-        B = block.num_edges()
-        ec = _lib.lib.bliss_spmm_chunk_edges(B)
-        part = torch.empty(2 * ((B + ec - 1) // ec) * D, dtype=torch.float32, device=gout.device) if B > 0 else None
-        _lib.check(_lib.lib.bliss_spmm_bwd(t_indptr.data_ptr(), t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(),
-                                           block.indptr.data_ptr(), 0 if w is None else w.data_ptr(), gout.data_ptr(),
-                                           gout.stride(0), ctx.n_src, block._nnz_ptr, B, D, int(ctx.mean), gh.data_ptr(),
-                                           gh.stride(0), 0,
-                                           0 if part is None else part.data_ptr(), _stream()), "bliss_spmm_bwd")
-        return gh, None, None, None, None
+    return ops.embed_norm(h)
 
 
 def weighted_aggregate(block, h, edge_weight=None, mean=True, out_fp32=False):
-    return _WeightedAggregate.apply(h, block, edge_weight, mean, out_fp32)
+    """out[i] = (1/deg_i if mean) * sum_{e -> i} w_e h[src_e] over a Block -- ``torch.ops.bliss.spmm`` (bliss_gnn_amd/ops.py: a
+    torch.library custom op with a fake kernel and the transposed SpMM as its autograd formula); gradient w.r.t. h only
+    (the sampler's edge weights carry no grad)."""
+    from . import ops
+    assert h.is_cuda and h.dtype == torch.bfloat16, "bf16 features on the GPU (load_graph.py:7)"
+    if h.stride(1) != 1:
+        h = h.contiguous()
+    w = None
+    if edge_weight is not None:
+        w = edge_weight.reshape(-1)
+        if w.dtype != torch.bfloat16:
+            w = w.bfloat16()
+        w = w.contiguous()
+        assert w.numel() == block.num_edges()
+    counts = getattr(block, "_counts_dev", None) if block._nnz_ptr else None
+    need_t = h.requires_grad and torch.is_grad_enabled()
+    t_indptr, t_edge = block.transposed() if need_t else (None, None)
+    return ops.spmm(block.indptr, block.src, block.dst, w, h, block.num_dst_nodes(), counts, bool(mean), bool(out_fp32), t_indptr, t_edge)
 
 
 class _SageEpilogue(torch.autograd.Function):

@@ -108,3 +108,35 @@ def test_reference_gat_call_sequence_on_a_block(cuda):
     assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=6e-2, atol=6e-2)
     for a, b in zip(ga, gb):
         assert torch.allclose(a.float(), b.float(), rtol=8e-2, atol=8e-2 * float(b.float().abs().max()))
+
+
+def test_custom_ops_are_registered_and_traceable(cuda):
+    """torch.ops.bliss.spmm / embed_norm: schema, fake (meta) kernels and the registered autograd formula checked by
+    torch.library.opcheck; under FakeTensorMode the ops propagate shapes without touching the GPU library."""
+    import bliss_gnn_amd as bg
+    from bliss_gnn_amd import ops
+    from bliss_gnn_amd.synth import chung_lu_csc
+    ip, ix, ei = chung_lu_csc(2000, 30000, seed=4)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda))
+    g.edata["w"] = bg.normalized_edata(g)
+    torch.manual_seed(1)
+    _, _, (blk,) = bg.PoissonBanditLadiesSampler([150]).sample_blocks(g, torch.arange(30, dtype=torch.int32, device=cuda))
+    h = torch.randn(blk.num_src_nodes(), 64, device=cuda).bfloat16().requires_grad_()
+    t_indptr, t_edge = blk.transposed()
+    args = (blk.indptr, blk.src, blk.dst, blk.edata["edge_weights"], h, blk.num_dst_nodes(), None, True, False, t_indptr, t_edge)
+    torch.library.opcheck(torch.ops.bliss.spmm.default, args, test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.bliss.embed_norm.default, (h.detach(),), test_utils=("test_schema", "test_faketensor"))
+    out = torch.ops.bliss.spmm(*args)
+    out.float().sum().backward()
+    # reference: fp32 mean of weighted rows
+    w = blk.edata["edge_weights"].float()
+    ref = torch.zeros(blk.num_dst_nodes(), 64, device=cuda).index_add_(0, blk.dst.long(), h.detach().float()[blk.src.long()] * w[:, None])
+    ref = ref / blk.in_degrees().clamp(min=1).float()[:, None]
+    assert torch.allclose(out.float(), ref, rtol=2 ** -7, atol=2 ** -7 * float(ref.abs().max()))
+    assert h.grad is not None and bool(torch.isfinite(h.grad.float()).all())
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        fh = torch.empty(blk.num_src_nodes(), 64, dtype=torch.bfloat16, device=cuda)
+        fo = torch.ops.bliss.spmm(blk.indptr, blk.src, blk.dst, None, fh, blk.num_dst_nodes(), None, True, True, None, None)
+        assert fo.shape == (blk.num_dst_nodes(), 64) and fo.dtype == torch.float32
+        assert torch.ops.bliss.embed_norm(fh).shape == (blk.num_src_nodes(),)
