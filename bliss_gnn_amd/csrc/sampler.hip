@@ -91,8 +91,8 @@ __device__ __forceinline__ bf16_t edge_q_pre(bf16_t w, bf16_t wsum, float a, flo
 // ---------------------------------------------------------------- K_a: seed columns -> seg_ptr
 // also resets the counts record and zeroes the per-seed accumulators (a kernel, not hipMemsetAsync: memset nodes
 // of a captured HIP graph were observed to leave this buffer stale on replay -- ROCm 7.2)
-// (wg / n_wgs: this workgroup's index and the number of workgroups doing THIS job -- k_seg_col runs the column sums in the
-// same launch on further workgroups; keep_sums: those workgroups write the first two per-seed accumulators, leave them alone)
+// (wg / n_wgs: this workgroup's index among those of the launch; keep_sums: k_col_sums, launched right behind, WRITES the
+// first two per-seed accumulators -- leave them alone)
 __device__ __forceinline__ void seg_scan_body(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
                                               LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
                                               unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
@@ -181,11 +181,12 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
                                                    unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
                                                    int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
                                                    int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
-                                                   int* __restrict__ span_seg, long long frontier_cap, int* entry_flag) {
+                                                   int* __restrict__ span_seg, long long frontier_cap, int* entry_flag,
+                                                   int keep_sums) {
   __shared__ int sh[17];
   __shared__ int st_sh[1024];
   seg_scan_body(indptr, seeds, cnt, S_host, S_dev, cap_s, seed_acc, seg_ptr, local_id, num_nodes, src_cnt, cap_k, bin_cursor, n_bins,
-                col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, gridDim.x, false, sh, st_sh);
+                col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, gridDim.x, keep_sums != 0, sh, st_sh);
 }
 
 // ---------------------------------------------------------------- K_b: first appearance + sum_j w_ij
@@ -444,140 +445,103 @@ __device__ __forceinline__ void col_store(int k, long long ws_fixed, long long q
   seed_coef[k] = make_uint2((unsigned)wsum | ((unsigned)qsum << 16), __float_as_uint(rbf((1.0f / (float)n) * eta_f)));
 }
 
-// NT threads per workgroup.  DIRECT: take a column's start and length from seeds -> indptr instead of k_seg_scan's tables --
-// the column sums need no frontier positions, so they can run BESIDE the scan (k_seg_col); wg / n_wgs as in seg_scan_body.
-template <int NT, bool DIRECT>
-__device__ __forceinline__ void col_sums_body(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                              const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
-                                              const long long* __restrict__ col_base, int S, int num_nodes,
-                                              LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
-                                              unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                              uint2* __restrict__ seed_coef, int n_wave_wgs, int wg, int n_wgs, long long* sh) {
-  const int tid = threadIdx.x, lane = lane_id();
-  int bad = 0;
-  // the first n_wave_wgs workgroups take the short columns (one per wave), the others the long ones (one per workgroup):
-  // both kinds are latency chains, so they run side by side instead of one after the other
-  const int n_block_wgs = n_wgs - n_wave_wgs;
-  auto column = [&](int k, long long* p0, int* n) {
-    if (DIRECT) {
-      const int sd = seeds[k];
-      if (sd < 0 || sd >= num_nodes) { *n = 0; *p0 = 0; return; }
-      *p0 = indptr[sd];
-      *n = (int)(indptr[sd + 1] - *p0);
-    } else {
-      const int s0 = seg_ptr[k];
-      *n = seg_ptr[k + 1] - s0;
-      *p0 = col_base[k] + s0;
-    }
-  };
-  // ---- columns up to COL_BIG edges: one per wave
-  if (wg < n_wave_wgs)
-  for (int k = wg * (NT / 64) + (tid >> 6); k < S; k += n_wave_wgs * (NT / 64)) {
-    long long p0; int n;
-    column(k, &p0, &n);
-    if (n == 0 || n > COL_BIG) continue;              // wave-uniform
-    bf16_t wr[COL_R];
-    long long part = 0;
-    int emax = 1;
-#pragma unroll
-    for (int r = 0; r < COL_R; ++r) {
-      const int i = lane + r * 64;
-      wr[r] = 0;
-      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
-    }
-    const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
-#pragma unroll
-    for (int r = 0; r < COL_R; ++r)
-      if (lane + r * 64 < n) part += bf_to_fixed(wr[r], wfrac, &bad);                         // :129 copy_e_sum over exp3 weights
-    const long long ws_fixed = wave_total_i64(part);
-    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
-    const float a = rbf((1.0f / (float)n) * eta_f);
-    part = 0;
-#pragma unroll
-    for (int r = 0; r < COL_R; ++r) {
-      const int i = lane + r * 64;
-      if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);     // :67 copy_e_sum(insg, edge_prob)
-    }
-    const long long qs_fixed = wave_total_i64(part);
-    if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
-  }
-  // ---- the long columns: one per workgroup, the first COL_RB * NT edges held in registers between the two sums
-  if (wg >= n_wave_wgs)
-  for (int k = wg - n_wave_wgs; k < S; k += n_block_wgs) {
-    long long p0; int n;
-    column(k, &p0, &n);
-    if (n <= COL_BIG) continue;                       // block-uniform
-    bf16_t wr[COL_RB];
-    long long part = 0;
-    int emax = 1;
-#pragma unroll
-    for (int r = 0; r < COL_RB; ++r) {
-      const int i = tid + r * NT;
-      wr[r] = 0;
-      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
-    }
-#pragma unroll 8
-    for (int i = tid + COL_RB * NT; i < n; i += NT) emax = max(emax, bf_exp_field(w[p0 + i]));
-    const int wfrac = rel_frac(FRAC_DST, block_max_u31<NT>(emax, sh));
-#pragma unroll
-    for (int r = 0; r < COL_RB; ++r)
-      if (tid + r * NT < n) part += bf_to_fixed(wr[r], wfrac, &bad);
-#pragma unroll 8
-    for (int i = tid + COL_RB * NT; i < n; i += NT) part += bf_to_fixed(w[p0 + i], wfrac, &bad);
-    const long long ws_fixed = block_sum_i64<NT>(part, sh);
-    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
-    const float a = rbf((1.0f / (float)n) * eta_f);
-    part = 0;
-#pragma unroll
-    for (int r = 0; r < COL_RB; ++r) {
-      const int i = tid + r * NT;
-      if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
-    }
-#pragma unroll 8
-    for (int i = tid + COL_RB * NT; i < n; i += NT) part += bf_to_fixed(edge_q_pre(w[p0 + i], wsum, a, ome_f), FRAC_DST, &bad);
-    const long long qs_fixed = block_sum_i64<NT>(part, sh);
-    if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
-  }
-  if (bad) atomicOr(&cnt->err, bad);
-}
-
-__global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
-                                                      const long long* __restrict__ col_base, const int* __restrict__ span_seg,
-                                                      LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
-                                                      unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                                      uint2* __restrict__ seed_coef, int n_wave_wgs) {
-  __shared__ long long sh[COL_TPB / 64];
-  if (cnt->E == 0) return;
-  col_sums_body<COL_TPB, false>(indptr, w, seeds, seg_ptr, col_base, cnt->S, 0, cnt, acc_w, acc_q, eta_f, ome_f, seed_coef, n_wave_wgs,
-                                blockIdx.x, gridDim.x, sh);
-}
-
-// k_seg_scan and k_col_sums in ONE launch: the first 1 + SEG_ZERO_WGS workgroups scan / zero, the others take the column
-// sums straight from seeds -> indptr.  One launch (and one serial scan) less on the sampler's critical chain per layer.
-#define SEGCOL_TPB 1024
-__global__ void __launch_bounds__(SEGCOL_TPB) k_seg_col(const int64_t* __restrict__ indptr, const int* __restrict__ seeds,
-                                                        LayerCounts* cnt, int S_host, const int* __restrict__ S_dev, int cap_s,
-                                                        unsigned long long* __restrict__ seed_acc, int* __restrict__ seg_ptr,
-                                                        int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
-                                                        int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
-                                                        int* __restrict__ span_seg, long long frontier_cap, int* entry_flag,
-                                                        const bf16_t* __restrict__ w, float eta_f, float ome_f,
-                                                        uint2* __restrict__ seed_coef, int n_wave_wgs) {
-  __shared__ int sh[17];
-  __shared__ int st_sh[1024];
-  __shared__ long long shl[SEGCOL_TPB / 64];
-  const int n_seg = 1 + SEG_ZERO_WGS;
-  if ((int)blockIdx.x < n_seg) {
-    seg_scan_body(indptr, seeds, cnt, S_host, S_dev, cap_s, seed_acc, seg_ptr, local_id, num_nodes, src_cnt, cap_k, bin_cursor, n_bins,
-                  col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, n_seg, true, sh, st_sh);
-    return;
-  }
+// A workgroup (4 waves) owns FOUR consecutive seed columns.  Each wave first looks at "its" column (start and length straight
+// from seeds -> indptr: the sums need no frontier positions, so this kernel does not wait for k_seg_scan's tables): a
+// column of up to COL_BIG edges is summed by that wave alone, in registers, with DPP reductions and no barrier.  Longer
+// columns are then taken one after the other by the whole workgroup (their start / length are already in LDS).
+// Round 1 gave the long columns to SEPARATE workgroups that each re-chased seeds -> indptr for every candidate column
+// (3-4 dependent round trips per workgroup before any work): 55-69 us on the 3.3 K-seed layer of the Reddit-like step, the
+// largest kernel of the sampler, for 6 MB of weights.
+#define COL4_TPB 256
+#define COL4_COLS (COL4_TPB / 64)
+__global__ void __launch_bounds__(COL4_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
+                                                       const int* __restrict__ seeds, int S_host, const int* __restrict__ S_dev,
+                                                       int cap_s, int num_nodes, LayerCounts* cnt,
+                                                       unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
+                                                       float eta_f, float ome_f, uint2* __restrict__ seed_coef) {
+  __shared__ long long sh[COL4_TPB / 64];
+  __shared__ long long sh_p0[COL4_COLS];
+  __shared__ int sh_n[COL4_COLS];
+  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
   int S = S_host >= 0 ? S_host : *S_dev;
   if (S > cap_s) S = cap_s;
-  unsigned long long* acc_w = seed_acc;
-  col_sums_body<SEGCOL_TPB, true>(indptr, w, seeds, nullptr, nullptr, S, num_nodes, cnt, acc_w, acc_w + cap_s, eta_f, ome_f, seed_coef,
-                                  n_wave_wgs, (int)blockIdx.x - n_seg, (int)gridDim.x - n_seg, shl);
+  int bad = 0;
+  for (int base = blockIdx.x * COL4_COLS; base < S; base += gridDim.x * COL4_COLS) {
+    const int k = base + wave;
+    long long p0 = 0;
+    int n = 0;
+    if (k < S) {
+      const int sd = seeds[k];
+      if (sd >= 0 && sd < num_nodes) { p0 = indptr[sd]; n = (int)(indptr[sd + 1] - p0); }
+    }
+    if (lane == 0) { sh_p0[wave] = p0; sh_n[wave] = n; }
+    // ---- a column of up to COL_BIG edges: this wave alone
+    if (n > 0 && n <= COL_BIG) {
+      bf16_t wr[COL_R];
+      long long part = 0;
+      int emax = 1;
+#pragma unroll
+      for (int r = 0; r < COL_R; ++r) {
+        const int i = lane + r * 64;
+        wr[r] = 0;
+        if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
+      }
+      const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
+#pragma unroll
+      for (int r = 0; r < COL_R; ++r)
+        if (lane + r * 64 < n) part += bf_to_fixed(wr[r], wfrac, &bad);                         // :129 copy_e_sum over exp3 weights
+      const long long ws_fixed = wave_total_i64(part);
+      const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+      const float a = rbf((1.0f / (float)n) * eta_f);
+      part = 0;
+#pragma unroll
+      for (int r = 0; r < COL_R; ++r) {
+        const int i = lane + r * 64;
+        if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);     // :67 copy_e_sum(insg, edge_prob)
+      }
+      const long long qs_fixed = wave_total_i64(part);
+      if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
+    }
+    __syncthreads();
+    // ---- the long columns of this group of four: the whole workgroup, the first COL_RB * 256 edges held in registers
+    for (int c = 0; c < COL4_COLS; ++c) {
+      const int nc = sh_n[c];
+      if (nc <= COL_BIG) continue;                    // block-uniform
+      const long long pc = sh_p0[c];
+      bf16_t wr[COL_RB];
+      long long part = 0;
+      int emax = 1;
+#pragma unroll
+      for (int r = 0; r < COL_RB; ++r) {
+        const int i = tid + r * COL4_TPB;
+        wr[r] = 0;
+        if (i < nc) { wr[r] = w[pc + i]; emax = max(emax, bf_exp_field(wr[r])); }
+      }
+#pragma unroll 8
+      for (int i = tid + COL_RB * COL4_TPB; i < nc; i += COL4_TPB) emax = max(emax, bf_exp_field(w[pc + i]));
+      const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL4_TPB>(emax, sh));
+#pragma unroll
+      for (int r = 0; r < COL_RB; ++r)
+        if (tid + r * COL4_TPB < nc) part += bf_to_fixed(wr[r], wfrac, &bad);
+#pragma unroll 8
+      for (int i = tid + COL_RB * COL4_TPB; i < nc; i += COL4_TPB) part += bf_to_fixed(w[pc + i], wfrac, &bad);
+      const long long ws_fixed = block_sum_i64<COL4_TPB>(part, sh);
+      const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+      const float a = rbf((1.0f / (float)nc) * eta_f);
+      part = 0;
+#pragma unroll
+      for (int r = 0; r < COL_RB; ++r) {
+        const int i = tid + r * COL4_TPB;
+        if (i < nc) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
+      }
+#pragma unroll 8
+      for (int i = tid + COL_RB * COL4_TPB; i < nc; i += COL4_TPB) part += bf_to_fixed(edge_q_pre(w[pc + i], wsum, a, ome_f), FRAC_DST, &bad);
+      const long long qs_fixed = block_sum_i64<COL4_TPB>(part, sh);
+      if (tid == 0) col_store(base + c, ws_fixed, qs_fixed, wsum, nc, eta_f, acc_w, acc_q, seed_coef, &bad);
+    }
+    __syncthreads();                                  // sh_p0 / sh_n are rewritten by the next group
+  }
+  if (bad) atomicOr(&cnt->err, bad);
 }
 
 template <bool BANDIT>
@@ -1348,29 +1312,20 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
       return BLISS_EINVAL;
   }
   const long long fcap = (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll);
-  static const bool merged_ok = []() { const char* e = getenv("BLISS_SEG_COL"); return !(e && e[0] == '0'); }();
-  const bool merged = binned && mode == BLISS_MODE_BANDIT && merged_ok;
-  if (merged) {
-    // scan + zeroing and the column sums (sum_j w_ij, sum_k q_ik per seed) side by side in one launch
-    const int n_wave = grid_for(cap_s, SEGCOL_TPB / 64, 2048), n_long = cap_s < 1024 ? cap_s : 1024;
-    PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_col<<<1 + SEG_ZERO_WGS + n_wave + n_long, SEGCOL_TPB, 0, st>>>(
-        g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr, m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
-        ws->bin_cursor, ws->n_bins, (long long*)col_base, ws->span_seg, fcap, ws->entry_flag, w, eta_f, one_minus_eta_f,
-        (uint2*)(acc_w + 6 * (size_t)cap_s), n_wave));
-  } else {
-    PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
-                                                              m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
-                                                              binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
-                                                              fcap, ws->entry_flag));
-  }
+  // the bandit's column sums write the first two per-seed accumulators themselves: the scan's zeroing leaves them alone
+  const bool col_sums = binned && mode == BLISS_MODE_BANDIT;
+  PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
+                                                            m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
+                                                            binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
+                                                            fcap, ws->entry_flag, col_sums ? 1 : 0));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
-    const int n_wave_wgs = grid_for(cap_s, COL_TPB / 64, 2048);
-    if (mode == BLISS_MODE_BANDIT && !merged)            // the block passes need sum_j w_ij even when p_j does not
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs));
+    if (col_sums)                                        // (the block passes need sum_j w_ij even when p_j does not)
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<grid_for(cap_s, COL4_COLS, 8192), COL4_TPB, 0, st>>>(
+          g->indptr, w, seeds, n_seeds, n_seeds_dev, cap_s, g->num_nodes, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef));
     if (mode == BLISS_MODE_BANDIT)
       PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
     else

@@ -33,13 +33,13 @@ class MultiLayerFullNeighborSampler(BlockSampler):
     def __init__(self, num_layers):
         super().__init__()
         self.num_layers = int(num_layers)
+        self.nodes_per_layer = [-1] * self.num_layers          # (-1 = every in-neighbour, DGL's convention for "no fanout")
         self._inner = None
 
     def sample_blocks(self, g, seed_nodes, exclude_eids=None):
         g = as_graph(g, self.__dict__.setdefault("_graphs", {}))
         if self._inner is None:
             self._inner = PoissonLadiesSampler([g.num_nodes() + 1] * self.num_layers)
-            self.nodes_per_layer = self._inner.nodes_per_layer
         if "w" not in g.edata:
             from .bandit_sampler import normalized_edata
             g.edata["w"] = normalized_edata(g)
