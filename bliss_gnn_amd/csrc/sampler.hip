@@ -99,10 +99,11 @@ __device__ __forceinline__ void seg_scan_body(const int64_t* __restrict__ indptr
                                               int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
                                               int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
                                               int* __restrict__ span_seg, long long frontier_cap, int* entry_flag,
-                                              int wg, int n_wgs, bool keep_sums, int* sh, int* st_sh) {
+                                              int wg, int n_wgs, bool keep_sums, int* sh, int* st_sh, int* hub_count = nullptr) {
   // This kernel runs <=> everything enqueued before this layer has completed (stream / graph order): tell a consumer on
   // another stream (bliss_flag_wait) without an event, i.e. without cutting a captured graph in two.
   if (entry_flag && wg == 0 && threadIdx.x == 0) __hip_atomic_store(entry_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (hub_count && wg == n_wgs - 1 && threadIdx.x == 0) *hub_count = 0;      // k_col_sums' hub list starts empty
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
@@ -182,11 +183,11 @@ __global__ void __launch_bounds__(1024) k_seg_scan(const int64_t* __restrict__ i
                                                    int* __restrict__ local_id, int num_nodes, int* __restrict__ src_cnt, int cap_k,
                                                    int* __restrict__ bin_cursor, int n_bins, long long* __restrict__ col_base,
                                                    int* __restrict__ span_seg, long long frontier_cap, int* entry_flag,
-                                                   int keep_sums) {
+                                                   int keep_sums, int* hub_count) {
   __shared__ int sh[17];
   __shared__ int st_sh[1024];
   seg_scan_body(indptr, seeds, cnt, S_host, S_dev, cap_s, seed_acc, seg_ptr, local_id, num_nodes, src_cnt, cap_k, bin_cursor, n_bins,
-                col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, gridDim.x, keep_sums != 0, sh, st_sh);
+                col_base, span_seg, frontier_cap, entry_flag, blockIdx.x, gridDim.x, keep_sums != 0, sh, st_sh, hub_count);
 }
 
 // ---------------------------------------------------------------- K_b: first appearance + sum_j w_ij
@@ -454,11 +455,16 @@ __device__ __forceinline__ void col_store(int k, long long ws_fixed, long long q
 // largest kernel of the sampler, for 6 MB of weights.
 #define COL4_TPB 256
 #define COL4_COLS (COL4_TPB / 64)
+#define COL_HUB (COL_RB * COL4_TPB)       // 8192: what a 256-thread workgroup holds in registers; longer columns are "hubs"
+#define HUB_TPB 1024
+// hubs[0] = number of hub columns (zeroed by k_seg_scan), hubs[1 + i] = seed index of the i-th: a hub's three passes (largest
+// exponent, exact sum of the weights, exact sum of q) by a 256-thread workgroup are a ~60 us latency chain on a 30 K-edge
+// column and set the duration of the whole launch; k_col_hubs gives each hub 1024 threads with the column in registers.
 __global__ void __launch_bounds__(COL4_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
                                                        const int* __restrict__ seeds, int S_host, const int* __restrict__ S_dev,
                                                        int cap_s, int num_nodes, LayerCounts* cnt,
                                                        unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
-                                                       float eta_f, float ome_f, uint2* __restrict__ seed_coef) {
+                                                       float eta_f, float ome_f, uint2* __restrict__ seed_coef, int* __restrict__ hubs) {
   __shared__ long long sh[COL4_TPB / 64];
   __shared__ long long sh_p0[COL4_COLS];
   __shared__ int sh_n[COL4_COLS];
@@ -473,6 +479,10 @@ __global__ void __launch_bounds__(COL4_TPB) k_col_sums(const int64_t* __restrict
     if (k < S) {
       const int sd = seeds[k];
       if (sd >= 0 && sd < num_nodes) { p0 = indptr[sd]; n = (int)(indptr[sd + 1] - p0); }
+    }
+    if (n > COL_HUB) {                                  // a hub: listed for k_col_hubs, nothing to do here
+      if (lane == 0) hubs[1 + atomicAdd(hubs, 1)] = k;
+      n = 0;
     }
     if (lane == 0) { sh_p0[wave] = p0; sh_n[wave] = n; }
     // ---- a column of up to COL_BIG edges: this wave alone
@@ -540,6 +550,52 @@ __global__ void __launch_bounds__(COL4_TPB) k_col_sums(const int64_t* __restrict
       if (tid == 0) col_store(base + c, ws_fixed, qs_fixed, wsum, nc, eta_f, acc_w, acc_q, seed_coef, &bad);
     }
     __syncthreads();                                  // sh_p0 / sh_n are rewritten by the next group
+  }
+  if (bad) atomicOr(&cnt->err, bad);
+}
+
+// one 1024-thread workgroup per hub column: up to COL_RB * 1024 = 32 K edges held in registers between the three passes
+__global__ void __launch_bounds__(HUB_TPB) k_col_hubs(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
+                                                      const int* __restrict__ seeds, LayerCounts* cnt,
+                                                      unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
+                                                      float eta_f, float ome_f, uint2* __restrict__ seed_coef, const int* __restrict__ hubs) {
+  __shared__ long long sh[HUB_TPB / 64];
+  const int tid = threadIdx.x, n_hubs = hubs[0];
+  int bad = 0;
+  for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+    const int k = hubs[1 + h], sd = seeds[k];
+    const long long pc = indptr[sd];
+    const int nc = (int)(indptr[sd + 1] - pc);
+    bf16_t wr[COL_RB];
+    long long part = 0;
+    int emax = 1;
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r) {
+      const int i = tid + r * HUB_TPB;
+      wr[r] = 0;
+      if (i < nc) { wr[r] = w[pc + i]; emax = max(emax, bf_exp_field(wr[r])); }
+    }
+#pragma unroll 8
+    for (int i = tid + COL_RB * HUB_TPB; i < nc; i += HUB_TPB) emax = max(emax, bf_exp_field(w[pc + i]));
+    const int wfrac = rel_frac(FRAC_DST, block_max_u31<HUB_TPB>(emax, sh));
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r)
+      if (tid + r * HUB_TPB < nc) part += bf_to_fixed(wr[r], wfrac, &bad);
+#pragma unroll 8
+    for (int i = tid + COL_RB * HUB_TPB; i < nc; i += HUB_TPB) part += bf_to_fixed(w[pc + i], wfrac, &bad);
+    const long long ws_fixed = block_sum_i64<HUB_TPB>(part, sh);
+    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+    const float a = rbf((1.0f / (float)nc) * eta_f);
+    part = 0;
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r) {
+      const int i = tid + r * HUB_TPB;
+      if (i < nc) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
+    }
+#pragma unroll 8
+    for (int i = tid + COL_RB * HUB_TPB; i < nc; i += HUB_TPB) part += bf_to_fixed(edge_q_pre(w[pc + i], wsum, a, ome_f), FRAC_DST, &bad);
+    const long long qs_fixed = block_sum_i64<HUB_TPB>(part, sh);
+    if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, nc, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -1317,15 +1373,20 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
                                                             binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
-                                                            fcap, ws->entry_flag, col_sums ? 1 : 0));
+                                                            fcap, ws->entry_flag, col_sums ? 1 : 0, col_sums ? ws->chunk_cnt : nullptr));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
     if (col_sums)                                        // (the block passes need sum_j w_ij even when p_j does not)
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<grid_for(cap_s, COL4_COLS, 8192), COL4_TPB, 0, st>>>(
-          g->indptr, w, seeds, n_seeds, n_seeds_dev, cap_s, g->num_nodes, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef));
+      PROF_LAUNCH(BK_COL_SUMS, st, {
+        k_col_sums<<<grid_for(cap_s, COL4_COLS, 8192), COL4_TPB, 0, st>>>(
+            g->indptr, w, seeds, n_seeds, n_seeds_dev, cap_s, g->num_nodes, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, ws->chunk_cnt);
+        // hubs (> 8192 edges: at most |E| / 8192 of them, the list sits at the front of the chunk scratch): one fat workgroup each
+        k_col_hubs<<<grid_for(g->num_edges / COL_HUB + 1, 1, 128), HUB_TPB, 0, st>>>(
+            g->indptr, w, seeds, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, ws->chunk_cnt);
+      });
     if (mode == BLISS_MODE_BANDIT)
       PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
     else

@@ -578,8 +578,9 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._needs_regrow = False
         self.regrows = getattr(self, "regrows", 0) + 1
         self.prime(next(loader))
+        primed = [dict(S=b._counts.S, E=b._counts.E, C=b._counts.C, K=b._counts.K, B=b._counts.B) for b in reversed(eng._static[0][0])]
         self._capture_graphs(loader)
-        return self.sizes2()
+        return [primed] + self.sizes2()                   # every batch sampled here, in sampling order
 
     def run(self, loader, n_pairs, ring=4, pair_events=None):
         """``n_pairs`` calls without a host round trip in between: the generator state is chained on the device from
@@ -596,6 +597,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         sizes, pending, bad = [], [], 0
         if getattr(self, "_needs_regrow", False):          # (the re-capture trains three batches itself: one drained, one pair)
             sizes += self._regrow(loader)
+            self._watch(sizes)
 
         def collect(i):
             nonlocal bad
