@@ -446,156 +446,91 @@ __device__ __forceinline__ void col_store(int k, long long ws_fixed, long long q
   seed_coef[k] = make_uint2((unsigned)wsum | ((unsigned)qsum << 16), __float_as_uint(rbf((1.0f / (float)n) * eta_f)));
 }
 
-// A workgroup (4 waves) owns FOUR consecutive seed columns.  Each wave first looks at "its" column (start and length straight
-// from seeds -> indptr: the sums need no frontier positions, so this kernel does not wait for k_seg_scan's tables): a
-// column of up to COL_BIG edges is summed by that wave alone, in registers, with DPP reductions and no barrier.  Longer
-// columns are then taken one after the other by the whole workgroup (their start / length are already in LDS).
-// Round 1 gave the long columns to SEPARATE workgroups that each re-chased seeds -> indptr for every candidate column
-// (3-4 dependent round trips per workgroup before any work): 55-69 us on the 3.3 K-seed layer of the Reddit-like step, the
-// largest kernel of the sampler, for 6 MB of weights.
-#define COL4_TPB 256
-#define COL4_COLS (COL4_TPB / 64)
-#define COL_HUB (COL_RB * COL4_TPB)       // 8192: what a 256-thread workgroup holds in registers; longer columns are "hubs"
-#define HUB_TPB 1024
-// hubs[0] = number of hub columns (zeroed by k_seg_scan), hubs[1 + i] = seed index of the i-th: a hub's three passes (largest
-// exponent, exact sum of the weights, exact sum of q) by a 256-thread workgroup are a ~60 us latency chain on a 30 K-edge
-// column and set the duration of the whole launch; k_col_hubs gives each hub 1024 threads with the column in registers.
-__global__ void __launch_bounds__(COL4_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                                       const int* __restrict__ seeds, int S_host, const int* __restrict__ S_dev,
-                                                       int cap_s, int num_nodes, LayerCounts* cnt,
-                                                       unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
-                                                       float eta_f, float ome_f, uint2* __restrict__ seed_coef, int* __restrict__ hubs) {
-  __shared__ long long sh[COL4_TPB / 64];
-  __shared__ long long sh_p0[COL4_COLS];
-  __shared__ int sh_n[COL4_COLS];
-  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-  int S = S_host >= 0 ? S_host : *S_dev;
-  if (S > cap_s) S = cap_s;
+// (Round 2 tried three other shapes for this kernel -- scan and column sums in one 1024-thread launch; four columns per
+// 256-thread workgroup with the long ones taken by the same workgroup; the latter plus one fat workgroup per hub column --
+// and measured all of them SLOWER on the Reddit-like step (34 / 78 / 73 us per layer against 16 / 27 / 55 for this one,
+// profiles/r02_e and r02_f step timelines): every dependent global access costs microseconds here, and this shape has the
+// fewest per workgroup -- one column per wave, one long column per workgroup, all of them side by side.)
+__global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
+                                                      const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
+                                                      const long long* __restrict__ col_base, const int* __restrict__ span_seg,
+                                                      LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
+                                                      unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
+                                                      uint2* __restrict__ seed_coef, int n_wave_wgs) {
+  __shared__ long long sh[COL_TPB / 64];
+  const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
+  if (cnt->E == 0) return;
   int bad = 0;
-  for (int base = blockIdx.x * COL4_COLS; base < S; base += gridDim.x * COL4_COLS) {
-    const int k = base + wave;
-    long long p0 = 0;
-    int n = 0;
-    if (k < S) {
-      const int sd = seeds[k];
-      if (sd >= 0 && sd < num_nodes) { p0 = indptr[sd]; n = (int)(indptr[sd + 1] - p0); }
+  // the first n_wave_wgs workgroups take the short columns (one per wave), the others the long ones (one per workgroup):
+  // both kinds are latency chains, so they run side by side instead of one after the other
+  const int n_block_wgs = (int)gridDim.x - n_wave_wgs;
+  // ---- columns up to COL_BIG edges: one per wave
+  if ((int)blockIdx.x < n_wave_wgs)
+  for (int k = blockIdx.x * (COL_TPB / 64) + (tid >> 6); k < S; k += n_wave_wgs * (COL_TPB / 64)) {
+    const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
+    if (n == 0 || n > COL_BIG) continue;              // wave-uniform
+    const long long p0 = col_base[k] + s0;
+    bf16_t wr[COL_R];
+    long long part = 0;
+    int emax = 1;
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r) {
+      const int i = lane + r * 64;
+      wr[r] = 0;
+      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
     }
-    if (n > COL_HUB) {                                  // a hub: listed for k_col_hubs, nothing to do here
-      if (lane == 0) hubs[1 + atomicAdd(hubs, 1)] = k;
-      n = 0;
+    const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r)
+      if (lane + r * 64 < n) part += bf_to_fixed(wr[r], wfrac, &bad);                         // :129 copy_e_sum over exp3 weights
+    const long long ws_fixed = wave_total_i64(part);
+    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+    const float a = rbf((1.0f / (float)n) * eta_f);
+    part = 0;
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r) {
+      const int i = lane + r * 64;
+      if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);     // :67 copy_e_sum(insg, edge_prob)
     }
-    if (lane == 0) { sh_p0[wave] = p0; sh_n[wave] = n; }
-    // ---- a column of up to COL_BIG edges: this wave alone
-    if (n > 0 && n <= COL_BIG) {
-      bf16_t wr[COL_R];
-      long long part = 0;
-      int emax = 1;
-#pragma unroll
-      for (int r = 0; r < COL_R; ++r) {
-        const int i = lane + r * 64;
-        wr[r] = 0;
-        if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
-      }
-      const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
-#pragma unroll
-      for (int r = 0; r < COL_R; ++r)
-        if (lane + r * 64 < n) part += bf_to_fixed(wr[r], wfrac, &bad);                         // :129 copy_e_sum over exp3 weights
-      const long long ws_fixed = wave_total_i64(part);
-      const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
-      const float a = rbf((1.0f / (float)n) * eta_f);
-      part = 0;
-#pragma unroll
-      for (int r = 0; r < COL_R; ++r) {
-        const int i = lane + r * 64;
-        if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);     // :67 copy_e_sum(insg, edge_prob)
-      }
-      const long long qs_fixed = wave_total_i64(part);
-      if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
-    }
-    __syncthreads();
-    // ---- the long columns of this group of four: the whole workgroup, the first COL_RB * 256 edges held in registers
-    for (int c = 0; c < COL4_COLS; ++c) {
-      const int nc = sh_n[c];
-      if (nc <= COL_BIG) continue;                    // block-uniform
-      const long long pc = sh_p0[c];
-      bf16_t wr[COL_RB];
-      long long part = 0;
-      int emax = 1;
-#pragma unroll
-      for (int r = 0; r < COL_RB; ++r) {
-        const int i = tid + r * COL4_TPB;
-        wr[r] = 0;
-        if (i < nc) { wr[r] = w[pc + i]; emax = max(emax, bf_exp_field(wr[r])); }
-      }
-#pragma unroll 8
-      for (int i = tid + COL_RB * COL4_TPB; i < nc; i += COL4_TPB) emax = max(emax, bf_exp_field(w[pc + i]));
-      const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL4_TPB>(emax, sh));
-#pragma unroll
-      for (int r = 0; r < COL_RB; ++r)
-        if (tid + r * COL4_TPB < nc) part += bf_to_fixed(wr[r], wfrac, &bad);
-#pragma unroll 8
-      for (int i = tid + COL_RB * COL4_TPB; i < nc; i += COL4_TPB) part += bf_to_fixed(w[pc + i], wfrac, &bad);
-      const long long ws_fixed = block_sum_i64<COL4_TPB>(part, sh);
-      const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
-      const float a = rbf((1.0f / (float)nc) * eta_f);
-      part = 0;
-#pragma unroll
-      for (int r = 0; r < COL_RB; ++r) {
-        const int i = tid + r * COL4_TPB;
-        if (i < nc) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
-      }
-#pragma unroll 8
-      for (int i = tid + COL_RB * COL4_TPB; i < nc; i += COL4_TPB) part += bf_to_fixed(edge_q_pre(w[pc + i], wsum, a, ome_f), FRAC_DST, &bad);
-      const long long qs_fixed = block_sum_i64<COL4_TPB>(part, sh);
-      if (tid == 0) col_store(base + c, ws_fixed, qs_fixed, wsum, nc, eta_f, acc_w, acc_q, seed_coef, &bad);
-    }
-    __syncthreads();                                  // sh_p0 / sh_n are rewritten by the next group
+    const long long qs_fixed = wave_total_i64(part);
+    if (lane == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
-  if (bad) atomicOr(&cnt->err, bad);
-}
-
-// one 1024-thread workgroup per hub column: up to COL_RB * 1024 = 32 K edges held in registers between the three passes
-__global__ void __launch_bounds__(HUB_TPB) k_col_hubs(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
-                                                      const int* __restrict__ seeds, LayerCounts* cnt,
-                                                      unsigned long long* __restrict__ acc_w, unsigned long long* __restrict__ acc_q,
-                                                      float eta_f, float ome_f, uint2* __restrict__ seed_coef, const int* __restrict__ hubs) {
-  __shared__ long long sh[HUB_TPB / 64];
-  const int tid = threadIdx.x, n_hubs = hubs[0];
-  int bad = 0;
-  for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
-    const int k = hubs[1 + h], sd = seeds[k];
-    const long long pc = indptr[sd];
-    const int nc = (int)(indptr[sd + 1] - pc);
+  // ---- the long columns: one per workgroup, the first COL_RB * COL_TPB edges held in registers between the two sums
+  if ((int)blockIdx.x >= n_wave_wgs)
+  for (int k = (int)blockIdx.x - n_wave_wgs; k < S; k += n_block_wgs) {
+    const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
+    if (n <= COL_BIG) continue;                       // block-uniform
+    const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_RB];
     long long part = 0;
     int emax = 1;
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r) {
-      const int i = tid + r * HUB_TPB;
+      const int i = tid + r * COL_TPB;
       wr[r] = 0;
-      if (i < nc) { wr[r] = w[pc + i]; emax = max(emax, bf_exp_field(wr[r])); }
+      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * HUB_TPB; i < nc; i += HUB_TPB) emax = max(emax, bf_exp_field(w[pc + i]));
-    const int wfrac = rel_frac(FRAC_DST, block_max_u31<HUB_TPB>(emax, sh));
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(w[p0 + i]));
+    const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL_TPB>(emax, sh));
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r)
-      if (tid + r * HUB_TPB < nc) part += bf_to_fixed(wr[r], wfrac, &bad);
+      if (tid + r * COL_TPB < n) part += bf_to_fixed(wr[r], wfrac, &bad);
 #pragma unroll 8
-    for (int i = tid + COL_RB * HUB_TPB; i < nc; i += HUB_TPB) part += bf_to_fixed(w[pc + i], wfrac, &bad);
-    const long long ws_fixed = block_sum_i64<HUB_TPB>(part, sh);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], wfrac, &bad);
+    const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
     const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
-    const float a = rbf((1.0f / (float)nc) * eta_f);
+    const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r) {
-      const int i = tid + r * HUB_TPB;
-      if (i < nc) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
+      const int i = tid + r * COL_TPB;
+      if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * HUB_TPB; i < nc; i += HUB_TPB) part += bf_to_fixed(edge_q_pre(w[pc + i], wsum, a, ome_f), FRAC_DST, &bad);
-    const long long qs_fixed = block_sum_i64<HUB_TPB>(part, sh);
-    if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, nc, eta_f, acc_w, acc_q, seed_coef, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(w[p0 + i], wsum, a, ome_f), FRAC_DST, &bad);
+    const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
+    if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -1373,20 +1308,15 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
                                                             binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
-                                                            fcap, ws->entry_flag, col_sums ? 1 : 0, col_sums ? ws->chunk_cnt : nullptr));
+                                                            fcap, ws->entry_flag, col_sums ? 1 : 0, nullptr));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
     unsigned long long* bin_rec = (unsigned long long*)ws->bin_rec;
     const int gb = grid_for(frontier_bound, BIN_BATCH);
+    const int n_wave_wgs = grid_for(cap_s, COL_TPB / 64, 2048);
     if (col_sums)                                        // (the block passes need sum_j w_ij even when p_j does not)
-      PROF_LAUNCH(BK_COL_SUMS, st, {
-        k_col_sums<<<grid_for(cap_s, COL4_COLS, 8192), COL4_TPB, 0, st>>>(
-            g->indptr, w, seeds, n_seeds, n_seeds_dev, cap_s, g->num_nodes, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, ws->chunk_cnt);
-        // hubs (> 8192 edges: at most |E| / 8192 of them, the list sits at the front of the chunk scratch): one fat workgroup each
-        k_col_hubs<<<grid_for(g->num_edges / COL_HUB + 1, 1, 128), HUB_TPB, 0, st>>>(
-            g->indptr, w, seeds, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, ws->chunk_cnt);
-      });
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs));
     if (mode == BLISS_MODE_BANDIT)
       PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
     else
