@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: run the replica exchange path (gradient all-reduce, EXP3 all-gather + apply) on a world of "
                          "one rank -- what the multi-GPU step costs per GPU before any communication time")
+    ap.add_argument("--dist", default="replicas", choices=["replicas", "shards"],
+                    help="multi-GPU layout: replicas (whole graph per rank, graph-captured step; the default) or destination-range "
+                         "shards (bliss_gnn_amd/shard.py: the north star's split; eager launches); with one GPU, shards = a world of one rank")
     ap.add_argument("--mode", default="train", choices=["train", "inference"],
                     help="inference: time SAGE.inference -- layer-wise full-neighbour evaluation of ALL nodes (model.py:335-383), the one "
                          "whole-graph SpMM of the reference -- with its own roofline")
@@ -120,7 +123,7 @@ def main():
                          "launcher)" % (args.gpus, world))
     if args.dry_run:
         return dry_run(args, rank, world)
-    force_dist = args.force_dist and world == 1
+    force_dist = (args.force_dist or args.dist == "shards") and world == 1
     if world > 1 or force_dist:
         from bliss_gnn_amd.dist import want_hw_queues
         want_hw_queues()                                  # before the first GPU call of this process
@@ -152,6 +155,8 @@ def main():
     fan, eta, hidden = cfg["fanouts"], 0.1, 256
     if args.mode == "inference":
         return bench_inference(args, g, cfg, hidden, dev, t_setup)
+    if args.dist == "shards":
+        return bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, rank, max(world, 1), t_setup)
     if args.sampler == "poisson-ladies":
         sampler = bg.PoissonLadiesSampler(fan)
     else:
@@ -355,6 +360,58 @@ def main():
     del step
     torch.cuda.synchronize()
     if world > 1 or force_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, rank, world, t_setup):
+    """The destination-range-sharded step (bliss_gnn_amd/shard.py): every rank owns a node range, draws its batch from the
+    train ids it owns (weak scaling: global batch = world x batch) and takes part in one global step at a time.  Eager
+    launches with a host sync per exchange -- this measures the path as built, not a graph-replayed loop."""
+    from bliss_gnn_amd import shard as sh
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.train import BatchLoader
+    bounds = sh.partition_by_in_edges(ip, world)
+    g = sh.GraphShard.from_global(ip, ix, ei, bounds, rank, device=dev, ndata={"features": feats, "labels": labels})
+    sampler = sh.ShardedPoissonBanditSampler(g, cfg["fanouts"], eta=0.1, seed=7)
+    torch.manual_seed(1234)
+    model = SAGE(cfg["feat"], hidden, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()
+    step = sh.ShardedTrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"])
+    mine = train_nid[(train_nid >= g.lo) & (train_nid < g.hi)]
+    loader = BatchLoader(mine, cfg["batch"], shuffle=True, drop_last=True, seed=2 + rank).forever()
+    for _ in range(args.warmup):
+        step(next(loader))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    edges = 0
+    for _ in range(args.steps):
+        step(next(loader))
+        edges += sum(b.num_edges() for b in step.last["mfgs"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    t = torch.tensor([dt, float(edges)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, edges = float(tmax[0]), float(tsum[1])
+    sampler.check_errors()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "steps/sec (train step over destination-range shards, batch-%d equivalents), %s-like" % (cfg["batch"], args.config),
+            "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "%s-like Chung-Lu graph |V|=%d, 3-layer SAGE hidden %d, sharded poisson-bandit (keyed draws) fanouts %s, "
+                                   "batch %d per GPU" % (args.config, ip.numel() - 1, hidden, "/".join(map(str, cfg["fanouts"])), cfg["batch"]),
+                       "parallelism": "destination-range shards x%d (partials all-to-all, histogram all-reduce, kept-list all-gather, halo "
+                                      "gathers, gradient all-reduce)" % world,
+                       "launch": "eager (one host sync per exchange)", "global_batch": cfg["batch"] * world},
+            "sampled_edges_per_sec": edges / dt, "setup_s": t_setup}), flush=True)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

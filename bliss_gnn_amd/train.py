@@ -671,6 +671,10 @@ class PipelinedTrainStep(GraphedTrainStep):
                                f"({_lib.err_string(bad)}) before the early-warning regrow could act; results are invalid -- "
                                f"raise the margins or lower regrow_at")
         self._watch(sizes)
+        if self.distributed and hasattr(self.sampler, "check_errors"):
+            # the exchange truncates an update list that outgrew its capacity and only flags it on the sampler: surface
+            # it with the call that produced it, not at the end of training (one tiny read-back per run(), not per step)
+            self.sampler.check_errors()
         return sizes
 
     def eager_pair(self, loader):
