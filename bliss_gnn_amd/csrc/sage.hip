@@ -12,10 +12,10 @@
 // (embed_norm of the next layer).  Two argument sets can share a launch (blockIdx.y): fc_neigh over all source rows and
 // fc_self over the destination rows of a W-first layer.
 //
-// Shape of the work: a workgroup (4 waves) owns 32 rows and all N <= 256 output columns.  The 32 input rows are staged
+// Shape of the work: a workgroup (8 waves) owns 32 rows and all N <= 256 output columns.  The 32 input rows are staged
 // ONCE in LDS (32 x K bf16 <= 66 KB for K <= 1024, 39 KB for the 602-wide features: four workgroups per CU overlap each
 // other's latency chains), which is also where the input norms are taken in exactly k_embed_norm's order (same bits as the
-// unfused path).  Wave w computes columns 64 w .. 64 w + 63 as two 32 x 32 tiles of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
+// unfused path).  Wave w computes columns 32 w .. 32 w + 31 as one 32 x 32 tile of v_mfma_f32_32x32x16_bf16: A fragments are 16-byte LDS reads (row = lane & 31, k = 8 (lane >> 5) ..+7), B fragments
 // 16-byte global (L2) reads of W[n][k..k+7] -- nn.Linear keeps W as [out, in], i.e. K-contiguous, exactly the B layout
 // the instruction wants, so no operand is ever transposed.  fp32 accumulation over all of K (and both products), one
 // rounding to bf16 at the store.  A row's result depends on nothing but that row: capacity-padded and exact-size blocks
@@ -29,9 +29,10 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-#define TG_TPB 256
+#define TG_TPB 512
 #define TG_M 32
 #define TG_WAVES (TG_TPB / 64)
+#define TG_NB (256 / 32 / TG_WAVES)          // 32-column blocks per wave: 8 waves x 1 block cover the 256 columns
 
 struct TileGemm {
   const bf16_t* a1; long long a1_stride; const int* ids;
@@ -219,7 +220,7 @@ __device__ __forceinline__ void w_slab_store(const WRegs& g, bf16_t* wl, int tid
 
 // acc += A_tile[32 x K] . W[N x K]^T for this wave's 64 columns (n0 ..); all four waves take part in the slab traffic
 __device__ __forceinline__ void mma_product(WRegs& ga, WRegs& gb, const bf16_t* tile, int stride, int k, const bf16_t* __restrict__ w,
-                                            long long w_stride, int n0, int N, bf16_t* wl, int tid, int lane, f32x16_t acc[2]) {
+                                            long long w_stride, int n0, int N, bf16_t* wl, int tid, int lane, f32x16_t acc[TG_NB]) {
   const int kp = k_pad16(k), r = lane & 31, h = lane >> 5;
   const int nslab = (kp + TG_SLAB - 1) / TG_SLAB;
   auto multiply = [&](int sl) {
@@ -229,10 +230,11 @@ __device__ __forceinline__ void mma_product(WRegs& ga, WRegs& gb, const bf16_t* 
         const int ks = sl * TG_SLAB + 16 * st;
         if (ks < kp) {
           const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(tile + (size_t)r * stride + ks + 8 * h);
-          const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(wl + (size_t)(n0 + r) * TG_WSTRIDE + 16 * st + 8 * h);
-          const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(wl + (size_t)(n0 + 32 + r) * TG_WSTRIDE + 16 * st + 8 * h);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < TG_NB; ++nb) {
+            const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wl + (size_t)(n0 + 32 * nb + r) * TG_WSTRIDE + 16 * st + 8 * h);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+          }
         }
       }
     }
@@ -288,11 +290,13 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   const int s1 = lds_stride(p.k1), s2 = p.k2 ? lds_stride(p.k2) : 0;
   bf16_t* t1 = lds;
   bf16_t* t2 = lds + (size_t)TG_M * s1;
-  const int n0 = wave * 64;
+  const int n0 = wave * 32 * TG_NB;
   bf16_t* wl = lds + (size_t)TG_M * (s1 + s2);              // the W slab behind the staged rows
-  float bias_v[2] = {0.f, 0.f};
+  float bias_v[TG_NB];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) { const int col = n0 + 32 * nb + (lane & 31); if (p.bias && col < N) bias_v[nb] = bf2f(p.bias[col]); }
+  for (int nb = 0; nb < TG_NB; ++nb) bias_v[nb] = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < TG_NB; ++nb) { const int col = n0 + 32 * nb + (lane & 31); if (p.bias && col < N) bias_v[nb] = bf2f(p.bias[col]); }
   // the first two W slabs depend on nothing: requested now, they arrive while the rows are gathered
   WRegs ga, gb;
   {
@@ -310,9 +314,9 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   if (p.k2) stage_rows(p.a2, p.a2_stride, row_id + TG_M, p.k2, row0, p.m_bound, t2, s2, nullptr, 0, wave, lane);
   __syncthreads();
   if (p.in_norm && !(dbg & 4)) rows_norm(t1, s1, p.k1, row0, M, p.m_bound, p.in_norm, wave, lane);   // model.py:318-320 of THIS layer
-  f32x16_t acc[2];
+  f32x16_t acc[TG_NB];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < TG_NB; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   if (!(dbg & 2)) mma_product(ga, gb, t1, s1, p.k1, p.w1, p.w1_stride, n0, N, wl, tid, lane, acc);
@@ -327,7 +331,7 @@ __device__ __forceinline__ void tile_gemm_body(const TileGemm& p, bf16_t* lds, i
   bf16_t* ot = lds;
   if (n0 < N) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {                            // (m = the wave's two column blocks)
+    for (int m = 0; m < TG_NB; ++m) {                        // (m = the wave's column blocks)
       const int col = n0 + 32 * m + (lane & 31);
       const float bv = bias_v[m];
 #pragma unroll

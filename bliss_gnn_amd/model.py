@@ -55,10 +55,10 @@ class SAGE(nn.Module):
         layer within the tile kernel's limits (in <= 1024, out <= 256)."""
         import os
         from .nn import tile_gemm_ok
-        # opt-in: on the Reddit-like step the hand-written tiles are at parity with the tuned library GEMMs on the 602-wide
-        # input layer (45 vs 46 us, two launches fewer) and slower on the two small layers (31 vs 23, 19 vs 18 us; DESIGN.md
-        # section 5: PMC counters show waves waiting 57 % of their cycles, no unit saturated) -- the default stays the faster path
-        if os.environ.get("BLISS_SAGE_MFMA", "0") != "1":
+        # BLISS_SAGE_MFMA=0 falls back to library GEMMs + separate gather / epilogue kernels (the round-1 path).  Device time per
+        # launch on the Reddit-like step (scratch/tgbench.py, graph replay): 602 -> 256 pair with the gather 32-37 us (gather +
+        # two tuned library GEMMs: 46), 256 + 256 dual with epilogue 20 (23), 256 -> 41 pair 13 (18), and five launches fewer
+        if os.environ.get("BLISS_SAGE_MFMA", "1") == "0":
             return False
         act = self.activation
         relu = act in (torch.relu, torch.nn.functional.relu) or isinstance(act, nn.ReLU)
