@@ -80,6 +80,40 @@ def sage_epilogue(self_out, neigh, p, ctr, seed):
     return _SageEpilogue.apply(self_out, neigh, p, ctr, seed)
 
 
+# ------------------------------------------------------------------------------------------------ loss (csrc/loss.hip)
+class _CrossEntropy(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) on bf16 logits, forward and gradient in one launch (train_lightning.py:77-79, :142)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, state):
+        x = logits if logits.stride(1) == 1 else logits.contiguous()
+        n, c = x.shape
+        dx = torch.empty(n, c, dtype=torch.bfloat16, device=x.device)
+        rows = torch.empty(n, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib.bliss_cross_entropy(x.data_ptr(), x.stride(0), labels.data_ptr(), n, c, rows.data_ptr(), dx.data_ptr(), dx.stride(0),
+                                                loss.data_ptr(), state.data_ptr(), state.data_ptr() + 4, _stream()), "bliss_cross_entropy")
+        ctx.save_for_backward(dx)
+        return loss.to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g.to(dx.dtype), None, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """``nn.CrossEntropyLoss()`` as the reference builds it (train_lightning.py:77-79): mean over the batch, class-index
+    targets.  bf16 logits on the GPU take the one-launch kernel; anything else goes to torch's functional form."""
+
+    def forward(self, logits, target):
+        if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2 and target.dtype == torch.int64 and target.dim() == 1:
+            if getattr(self, "_state", None) is None or self._state.device != logits.device:
+                self._state = torch.zeros(2, dtype=torch.int32, device=logits.device)       # [0] ticket, [1] error word
+            return _CrossEntropy.apply(logits, target.contiguous(), self._state)
+        return torch.nn.functional.cross_entropy(logits, target)
+
+
 # ------------------------------------------------------------------------------------------------ MFMA tile GEMM (csrc/sage.hip)
 TILE_GEMM_MAX_K, TILE_GEMM_MAX_N = 1024, 256
 

@@ -53,6 +53,11 @@ def _inputs(model, mfgs):
     return mfgs[0].srcdata["features"]
 
 
+def _ce_loss():
+    from .nn import CrossEntropyLoss
+    return CrossEntropyLoss()
+
+
 def make_adam(model, lr, capturable=False):
     """th.optim.Adam(self.parameters(), lr) (train_lightning.py:206).  For the reference's precision (bf16 module on the GPU,
     :596-618) this is the one-launch gfx950 Adam of csrc/optim.hip; anything else gets torch's own."""
@@ -70,7 +75,7 @@ class TrainStep:
 
     def __init__(self, g, sampler, model, lr=0.002, multilabel=False, bandit=True, grad_sync=None, exp3_sync=None):
         self.g, self.sampler, self.model = g, sampler, model
-        self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()   # :77-79
+        self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else _ce_loss()             # :77-79
         self.opt = make_adam(model, lr)                                                  # :206
         self.bandit = bandit and hasattr(sampler, "exp3")          # train_lightning.py:469: only for the bandit samplers
         self.grad_sync, self.exp3_sync = grad_sync, exp3_sync
@@ -145,7 +150,7 @@ class GraphedTrainStep:
     def __init__(self, g, sampler, model, batch_size, lr=0.002, multilabel=False, distributed=False):
         self.g, self.sampler, self.model, self.bs = g, sampler, model, int(batch_size)
         self.distributed = distributed          # replicas: gradient all-reduce + EXP3 exchange recorded in the graph too
-        self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else nn.CrossEntropyLoss()
+        self.loss_fn = nn.BCEWithLogitsLoss() if multilabel else _ce_loss()
         # ONE launch for all parameter tensors (csrc/optim.hip; torch's foreach path is ~40 launches of >= 5 us inside a graph,
         # its fused multi-tensor kernel ~50 us)
         self.opt = make_adam(model, lr, capturable=True)

@@ -248,6 +248,13 @@ typedef struct {
 } bliss_tile_gemm_t;
 int bliss_tile_gemm(const bliss_tile_gemm_t* first, const bliss_tile_gemm_t* second_or_null, void* stream);
 
+/* nn.CrossEntropyLoss() (mean) on bf16 logits [n_rows, n_cls] and int64 labels (train_lightning.py:77-79, :142), forward and
+ * gradient in one launch: *loss_out = mean_r (logsumexp(x_r) - x_r[y_r]) in fp32, dlogits = (softmax(x) - onehot(y)) / n_rows in
+ * bf16.  row_loss: float[n_rows] scratch; ticket: zero-initialised uint32 (left zero); a label outside [0, n_cls) sets bit 2 in *err. */
+int bliss_cross_entropy(const void* logits, int64_t stride, const int64_t* labels, int32_t n_rows, int32_t n_cls,
+                        float* row_loss, void* dlogits, int64_t d_stride, float* loss_out, uint32_t* ticket, int32_t* err,
+                        void* stream);
+
 /* th.optim.Adam(self.parameters(), lr) (train_lightning.py:205-206) for a bf16 module: parameters, gradients and both moment
  * buffers bf16, one launch over all tensors, math in fp32, one rounding per stored value.  state: float[4] on the device --
  * [0] step count (incremented by the launch), [1] learning rate (the caller rewrites it when its scheduler does,

@@ -1717,3 +1717,24 @@ def test_capacity_regrow_keeps_the_run_valid(cuda):
     n = min(len(tight["sizes"]), len(loose["sizes"]))
     same = sum(a == b for a, b in zip(tight["sizes"][:n], loose["sizes"][:n]))
     assert same >= n - 2, (same, n)                       # (bf16 activations feed the bandit: a late ulp may move a late batch)
+
+
+@pytest.mark.parametrize("n,c", [(256, 41), (32, 3), (1000, 100), (7, 1000)])
+def test_one_launch_cross_entropy_vs_torch(cuda, n, c):
+    """csrc/loss.hip: nn.CrossEntropyLoss() (mean; train_lightning.py:77-79, :142) and its gradient in one launch, against
+    torch's fp32 cross_entropy on the same bf16 logits: loss to fp32 accuracy (then stored in bf16 like torch's), gradient
+    within one bf16 rounding of (softmax - onehot) / n."""
+    from bliss_gnn_amd.nn import CrossEntropyLoss
+    gen = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=gen) * 3).bfloat16().to(cuda).requires_grad_()
+    y = torch.randint(0, c, (n,), generator=gen).to(cuda)
+    loss = CrossEntropyLoss()(x, y)
+    loss.backward()
+    xr = x.detach().float().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(xr, y)
+    ref.backward()
+    assert loss.dtype == torch.bfloat16 and abs(float(loss) - float(ref)) <= 2.0 ** -8 * abs(float(ref)) + 1e-6
+    assert torch.allclose(x.grad.float(), xr.grad, rtol=2.0 ** -7, atol=2e-6)
+    x2 = x.detach().clone().requires_grad_()
+    (CrossEntropyLoss()(x2, y) * 0.5).backward()                          # a non-unit incoming gradient
+    assert torch.allclose(x2.grad.float(), 0.5 * xr.grad, rtol=2.0 ** -6, atol=2e-6)
