@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(SP_TPB) k_gather_rows_norm(const bf16_t* __res
 // ReLU, dropout (keep with probability 1-p, scale 1/(1-p), one rounding) and the fp32 sum of squares of what it stores
 // (the same accumulation order as k_embed_norm).  The dropout bits come from a counter-based hash of (seed, launch
 // counter, element index): the same Bernoulli(1-p) law as torch's fused_dropout, a different (device-resident,
-// graph-replayable) random stream.  ctr[0] = launch counter, ctr[1] = ticket: the last workgroup to finish bumps the
+// graph-replayable) random stream.  ctr[0] = launch counter, ctr[1] (and ctr[2..65]) = tickets: the last workgroup to finish bumps the
 // counter, so every workgroup of a launch has read the same value.
 __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t ctr, uint32_t idx) {
   uint32_t x = idx * 0x9e3779b1u + seed;
@@ -297,12 +297,18 @@ __global__ void __launch_bounds__(SP_TPB) k_sage_epilogue(const bf16_t* __restri
     if (lane == 0 && norm_out) norm_out[row] = f2bf(sqrtf(s));
   }
   if (drop_thresh) {                                          // launch counter: bumped once, by the last workgroup
+    // two-level ticket (ctr[2 + g], g = workgroup % 64, then ctr[1]): a same-address atomic costs ~10 ns, and the 1200
+    // workgroups of the input layer's launch spent 12 of its 20 us queueing on ONE ticket word
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned long long t = atomicAdd(ctr + 1, 1ull);
-      if (t == (unsigned long long)gridDim.x - 1) {
-        __hip_atomic_store(ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(ctr, 1ull);
+      const unsigned G = gridDim.x < 64u ? gridDim.x : 64u, g = blockIdx.x % G;
+      const unsigned long long members = (gridDim.x - g + G - 1) / G;
+      if (atomicAdd(ctr + 2 + g, 1ull) == members - 1) {
+        __hip_atomic_store(ctr + 2 + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicAdd(ctr + 1, 1ull) == (unsigned long long)G - 1) {
+          __hip_atomic_store(ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(ctr, 1ull);
+        }
       }
     }
   }

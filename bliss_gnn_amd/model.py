@@ -45,7 +45,7 @@ class SAGE(nn.Module):
             self._drop_ctr = {}
         key = (l, str(device))
         if key not in self._drop_ctr:
-            self._drop_ctr[key] = torch.zeros(2, dtype=torch.int64, device=device)
+            self._drop_ctr[key] = torch.zeros(2 + 64, dtype=torch.int64, device=device)      # launch counter, ticket, 64 sub-tickets
         return self._drop_ctr[key], (torch.cuda.initial_seed() ^ (0x9E3779B1 * (l + 1))) & 0xFFFFFFFF
 
     accepts_lazy_rows = True        # forward() takes blocks[0].srcdata.lazy('features'): the gather becomes an operand load

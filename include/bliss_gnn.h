@@ -306,8 +306,8 @@ int bliss_spmm_bwd(const int32_t* t_indptr, const int32_t* t_edge, const int32_t
 
 /* The element-wise tail of a hidden SAGE layer in one pass (model.py:321-333 and :318-320 of the next layer):
  * out = dropout_p(relu(a + b)) row by row, norm_out[row] = ||out[row,:]||_2 (bf16, may be NULL).  a, b, out: bf16
- * [n_rows, dim].  p_drop = 0 (evaluation) makes it deterministic.  ctr: device uint64[2], zero-initialised once: the
- * dropout stream's launch counter (bumped by every call with p_drop > 0) -- counter-based bits, not torch's generator.
+ * [n_rows, dim].  p_drop = 0 (evaluation) makes it deterministic.  ctr: device uint64[66], zero-initialised once: the
+ * dropout stream's launch counter + tickets (bumped by every call with p_drop > 0) -- counter-based bits, not torch's generator.
  * _bwd: din = dout / (1 - p) where out > 0, else 0 (the gradient w.r.t. both a and b). */
 int bliss_sage_epilogue_fwd(const void* a, int64_t a_stride, const void* b, int64_t b_stride, int32_t n_rows, int32_t dim,
                             float p_drop, uint32_t seed, uint64_t* ctr, void* out, int64_t out_stride, void* norm_out, void* stream);

@@ -1332,7 +1332,7 @@ def test_sage_epilogue_kernel(cuda):
     assert torch.equal(out2.view(torch.int16), torch.relu(a2 + b2).view(torch.int16))
     assert torch.equal(norm2.view(torch.int16), embed_norm(torch.relu(a2 + b2)).view(torch.int16))
     # dropout
-    ctr = torch.zeros(2, dtype=torch.int64, device=cuda)
+    ctr = torch.zeros(66, dtype=torch.int64, device=cuda)      # launch counter, ticket, 64 sub-tickets
     p = 0.25
     ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     o1, n1 = sage_epilogue(ar, br, p, ctr, 123)
