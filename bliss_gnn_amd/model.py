@@ -66,20 +66,22 @@ class SAGE(nn.Module):
                    and l.feat_drop.p == 0 for l in self.layers)
         return relu and dims and x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.dropout, nn.Dropout)
 
-    def _forward_mfma(self, blocks, x):
-        """model.py:312-333 with the Linear layers on hand-written MFMA tiles: per W-first layer ONE launch for fc_neigh +
-        fc_self (+ the feature gather and the input norms), per aggregate-first layer ONE launch for both Linears, the
-        bias, ReLU, dropout and the next layer's norms.  The aggregation stays the merge-style SpMM of csrc/spmm.hip."""
+    def _layers_mfma(self, blocks, h, norm, lo, hi):
+        """model.py:312-333, layers lo..hi-1, with the Linear layers on hand-written MFMA tiles: per W-first layer ONE launch
+        for fc_neigh + fc_self (+ the feature gather and the input norms), per aggregate-first layer ONE launch for both
+        Linears, the bias, ReLU, dropout and the next layer's norms.  The aggregation stays the merge-style SpMM of
+        csrc/spmm.hip."""
         from .nn import LazyRows, _SageDualLinear, _SageLinearPair, weighted_aggregate
-        h, norm, n_layers = x, None, len(self.layers)
-        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+        n_layers = len(self.layers)
+        for l in range(lo, hi):
+            layer, block = self.layers[l], blocks[l]
             last = l == n_layers - 1
             S_b, K_b = block.num_dst_nodes(), block.num_src_nodes()
             cd = block._counts_dev.data_ptr() if block._nnz_ptr else 0           # capacity-padded block: true S, K on the device
             src_dev, dst_dev = (cd + 12, cd) if cd else (0, 0)
             ew = block.edata["edge_weights"] if "edge_weights" in block.edata else None
             p = self.dropout.p if (self.training and not last) else 0.0
-            ctr, seed = self._dropout_state(l, x.device) if p > 0 else (None, 0)
+            ctr, seed = self._dropout_state(l, h.device) if p > 0 else (None, 0)
             fc_n, fc_s = layer.fc_neigh, layer.fc_self
             if layer._in_src_feats > layer._out_feats:                           # fc_neigh before the aggregation
                 table, ids = (h.table, h.ids) if isinstance(h, LazyRows) else (h, None)
@@ -98,16 +100,12 @@ class SAGE(nn.Module):
                 h, norm = _SageDualLinear.apply(agg, h[:S_b], fc_n.weight, fc_s.weight, fc_s.bias, not last, p, ctr, seed, S_b, dst_dev)
                 if last:
                     norm = None
-        return h
+        return h, norm
 
-    def forward(self, blocks, x):
-        from .nn import LazyRows
-        if self._mfma_ok(x):
-            return self._forward_mfma(blocks, x)
-        if isinstance(x, LazyRows):
-            x = x.materialize()
-        h, norm = x, _gathered_norm(blocks, x)
-        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+    def _layers_plain(self, blocks, h, norm, lo, hi):
+        """model.py:312-333, layers lo..hi-1, on library GEMMs (+ the fused epilogue where it applies)."""
+        for l in range(lo, hi):
+            layer, block = self.layers[l], blocks[l]
             block.srcdata["embed_norm"] = embed_norm(h) if norm is None else norm          # model.py:318-320
             norm = None
             ew = block.edata["edge_weights"] if "edge_weights" in block.edata else None
@@ -125,7 +123,41 @@ class SAGE(nn.Module):
             if l < len(self.layers) - 1:
                 h = self.activation(h)
                 h = self.dropout(h)
-        return h
+        return h, norm
+
+    def _layers(self, blocks, x, norm, lo, hi, mfma):
+        from .nn import LazyRows
+        if mfma:
+            return self._layers_mfma(blocks, x, norm, lo, hi)
+        if isinstance(x, LazyRows):
+            x = x.materialize()
+        if lo == 0 and norm is None:
+            norm = _gathered_norm(blocks, x)
+        return self._layers_plain(blocks, x, norm, lo, hi)
+
+    def forward(self, blocks, x):
+        return self._layers(blocks, x, None, 0, len(self.layers), self._mfma_ok(x))[0]
+
+    # The bandit update (sampler.exp3) reads every block's INPUT row norms (model.py:318-320) and nothing the output layer
+    # computes, so a training loop may run forward_hidden -> exp3 -> next batch's sampler and leave forward_last + loss +
+    # backward to a second stream (train.PipelinedTrainStep).  forward(blocks, x) == forward_last(blocks, forward_hidden(...)).
+    def forward_hidden(self, blocks, x):
+        """Layers 0..L-2 and the output layer's input norms: every block's srcdata['embed_norm'] is set on return."""
+        n = len(self.layers)
+        if n < 2:
+            raise ValueError("forward_hidden needs at least one hidden layer")
+        mfma = self._mfma_ok(x)
+        h, norm = self._layers(blocks, x, None, 0, n - 1, mfma)
+        if norm is None:
+            norm = embed_norm(h)
+        blocks[n - 1].srcdata["embed_norm"] = norm
+        return h, norm, mfma
+
+    def forward_last(self, blocks, hidden):
+        """The output layer on forward_hidden's result."""
+        h, norm, mfma = hidden
+        n = len(self.layers)
+        return self._layers(blocks, h, norm, n - 1, n, mfma)[0]
 
     @torch.no_grad()
     def inference(self, g, device=None, batch_size=128, use_uva=False, num_workers=0, node_chunk=16384):

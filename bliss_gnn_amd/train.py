@@ -323,25 +323,43 @@ class PipelinedTrainStep(GraphedTrainStep):
         return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng,
                                                  part=part)[2]
 
+    def _split_forward(self):
+        # BLISS_SPLIT_FORWARD=0 keeps the whole forward pass ahead of the bandit update (the round-1 order)
+        return (hasattr(self.model, "forward_hidden") and len(getattr(self.model, "layers", ())) > 1 and hasattr(self.sampler, "exp3")
+                and os.environ.get("BLISS_SPLIT_FORWARD", "1") != "0")
+
     def _forward(self, mfgs):
-        pred = self.model(mfgs, _inputs(self.model, mfgs))
-        loss = self.loss_fn(pred, mfgs[-1].dstdata["labels"])
+        """The part of the step the NEXT batch's sampler waits for: the forward pass up to the output layer's input (every
+        block's row norms exist from there on, train_lightning.py:232-238 reads nothing else) and the bandit update.  Returns
+        what _backward needs to finish the step."""
+        if self._split_forward():
+            pending = ("hidden", self.model.forward_hidden(mfgs, _inputs(self.model, mfgs)), mfgs)
+        else:
+            pred = self.model(mfgs, _inputs(self.model, mfgs))
+            pending = ("loss", self.loss_fn(pred, mfgs[-1].dstdata["labels"]), mfgs)
         if not hasattr(self.sampler, "exp3"):                      # LADIES samplers keep no bandit state
-            return loss
+            return pending
         if self.distributed:
             from . import dist as bdist
             bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
         else:
             self.sampler.exp3(mfgs, self.g)
-        return loss
+        return pending
 
-    def _backward(self, loss):
+    def _backward(self, pending):
+        """Output layer + loss (when _forward left them), backward, optimizer.  Returns the detached loss."""
+        kind, val, mfgs = pending
+        if kind == "hidden":
+            loss = self.loss_fn(self.model.forward_last(mfgs, val), mfgs[-1].dstdata["labels"])
+        else:
+            loss = val
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         if self.distributed:
             from . import dist as bdist
             bdist.allreduce_gradients(self.model)
         self.opt.step()
+        return loss.detach()
 
     def _pair(self):
         # Eager version (warm-up, kernel-by-kernel timing).  The sampler stays on the origin stream (its random-number
@@ -352,13 +370,12 @@ class PipelinedTrainStep(GraphedTrainStep):
         losses = []
         for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
             with torch.cuda.stream(side):
-                loss = self._forward(self.mfgs[cur])         # F + X
+                pending = self._forward(self.mfgs[cur])      # F + X
             main.wait_stream(side)                           # the sampler needs the EXP3 weights X just wrote
             self.mfgs[nxt] = self._sample(nxt, chain)        # S, beside ...
             with torch.cuda.stream(side):
-                self._backward(loss)                         # ... B
+                losses.append(self._backward(pending))       # ... B
                 side.wait_stream(main)                       # the next forward needs the blocks S built
-            losses.append(loss.detach())
         main.wait_stream(side)
         return tuple(losses)
 
@@ -465,7 +482,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         pool = torch.cuda.graph_pool_handle()
         self.graph = None
         self.g_main, self.g_fwd, self.g_bwd, self.g_smp, self.g_blk = ([None, None] for _ in range(5))
-        held = [None, None]
+        held, out = [None, None], [None, None]
         for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
             # (the sampler is recorded without its generator: that one is launched ahead of time, see _replay / run)
             self.g_bwd[cur] = torch.cuda.CUDAGraph()
@@ -482,7 +499,7 @@ class PipelinedTrainStep(GraphedTrainStep):
                     # B may start once S has (flag 0 is raised by the sampler's first kernel: F and X have completed)
                     _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr(), eng.flag_err.data_ptr(),
                                                         torch.cuda.current_stream().cuda_stream), "bliss_flag_wait")
-                    self._backward(held[cur])
+                    out[cur] = self._backward(held[cur])
             else:
                 self.g_fwd[cur], self.g_smp[nxt] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side):
@@ -490,8 +507,8 @@ class PipelinedTrainStep(GraphedTrainStep):
                 with torch.cuda.graph(self.g_smp[nxt]):
                     self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True)
                 with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
-                    self._backward(held[cur])
-        self.losses = tuple(h.detach() for h in held)
+                    out[cur] = self._backward(held[cur])
+        self.losses = tuple(out)
         self.graph = True
         self._replay()                                   # the captures themselves executed nothing
         self._finish_pair(check_flags=False)             # (capture() looks at the flags itself)
@@ -696,12 +713,11 @@ class PipelinedTrainStep(GraphedTrainStep):
         main, side = torch.cuda.current_stream(), self.side
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            loss = self._forward(self.mfgs[0])
-            self._backward(loss)
+            loss = self._backward(self._forward(self.mfgs[0]))
         main.wait_stream(side)
         main.synchronize()
         self.num_steps += 1
-        return loss.detach()
+        return loss
 
     def _graph_attrs(self):
         return ("graph", "g_main", "g_fwd", "g_bwd", "g_smp", "g_blk")
