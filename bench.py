@@ -251,6 +251,18 @@ def main():
     step_ms = []
     if pair_events:
         step_ms = [0.5 * a.elapsed_time(b) for a, b in zip(pair_events[:-1], pair_events[1:])]
+        if os.environ.get("BLISS_BENCH_DUMP"):          # the per-pair series with the sampled sizes beside it (tail hunting)
+            with open(os.environ["BLISS_BENCH_DUMP"], "w") as f:
+                json.dump({"step_ms": step_ms, "sizes": all_sizes, "host": getattr(step, "_host_trace", None)}, f)
+    if pipelined and os.environ.get("BLISS_BENCH_NORMS") and hasattr(sampler, "_scratch"):
+        # what F.normalize saw on every second step of 600 more: bf16 norm bits per layer (0x3f80 = 1.0 = pass skipped)
+        rec = []
+        for _ in range(300):
+            step.run(loader, 1)
+            rec.append([int(v) & 0x1ffff for v in sampler._scratch[:, 0].tolist()]
+                       + [float(w.float().sum(dtype=torch.float64)) for w in sampler._w_pos])
+        with open(os.environ["BLISS_BENCH_NORMS"], "w") as f:
+            json.dump(rec, f)
     n_edges = sum(x["B"] for sz in all_sizes for x in sz)
     n_frontier = sum(x["E"] for sz in all_sizes for x in sz)
     sizes_acc = [{k: sum(sz[l][k] for sz in all_sizes) for k in all_sizes[0][l]} for l in range(len(all_sizes[0]))]

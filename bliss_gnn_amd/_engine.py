@@ -416,7 +416,8 @@ class LayerEngine:
     def static_rng_ready(self):
         _lib.check(_lib.lib.bliss_rng_stream_ready(_stream()), "bliss_rng_stream_ready")
 
-    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False, part=None):
+    def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False, part=None,
+                       w_pend=None):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
         blocks (sampling order); sizes, errors and the generator state are read back by finish().
 
@@ -425,12 +426,13 @@ class LayerEngine:
         ``part``: None = the whole call.  "main" = everything except the blocks of all but the last-sampled layer, and layer
         n raises ``flags[n]`` when it starts; "early_blocks" = only those blocks, each behind a bliss_flag_wait on
         ``flags[n + 1]`` -- to be enqueued on ANOTHER stream, with ``scratch_sets`` >= the number of layers (block n then shares
-        no scratch with any later layer) and external_rng.  The caller orders the next "main" after both parts."""
+        no scratch with any later layer) and external_rng.  The caller orders the next "main" after both parts.
+        ``w_pend``: per layer (sampling order) the address of the row's pending-norm word (bliss_exp3_step_deferred)."""
         if part is not None and (self.scratch_sets < len(fanouts) or not external_rng):
             raise ValueError("split enqueue needs one scratch set per layer and an external generator")
         L = len(fanouts)
         out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng,
-                            external_rng=external_rng, part=part)
+                            external_rng=external_rng, part=part, w_pend=w_pend)
         counts_dev, layers = out
         if slot not in self._slot_counts_host:
             self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
@@ -471,7 +473,7 @@ class LayerEngine:
         return cnts
 
     def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False, external_rng=False,
-                 part=None):
+                 part=None, w_pend=None):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
         if snapshot is not None and not chain_rng and not external_rng:
@@ -498,6 +500,8 @@ class LayerEngine:
             c_ws, c_out, lay, cnt_ptr, kept_nid = self._layer_buffers(n, counts, slot)
             w_pos = w_rows[n]
             last = n == L - 1
+            if w_pend is not None:
+                c_ws.w_pend = int(w_pend[n])
             if part == "main":                  # layer n raises flag n when it starts (= everything before it has completed)
                 c_ws.entry_flag = self.flags.data_ptr() + 4 * n
             if part in (None, "main"):          # candidates, probabilities, draw: all the next layer needs (its seeds = kept_nid)

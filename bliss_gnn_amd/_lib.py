@@ -46,14 +46,15 @@ class LayerWs(C.Structure):
                 ("n_bins", C.c_int32), ("bin_cap", C.c_int64), ("bin_cursor", C.c_void_p), ("bin_rec", C.c_void_p),
                 ("bitmap", C.c_void_p), ("word_prefix", C.c_void_p), ("touched_key", C.c_void_p), ("touched_sum", C.c_void_p),
                 ("span_seg", C.c_void_p), ("kept_rec", C.c_void_p), ("span_cnt", C.c_void_p), ("kept_rec_positions", C.c_int64),
-                ("kept_map", C.c_void_p), ("entry_flag", C.c_void_p)]
+                ("kept_map", C.c_void_p), ("entry_flag", C.c_void_p), ("w_pend", C.c_void_p)]
 
 
 class Exp3Block(C.Structure):
     _fields_ = [("w_pos", C.c_void_p), ("row_sum", C.c_void_p), ("scratch", C.c_void_p), ("norm_out", C.c_void_p),
                 ("blk_indptr", C.c_void_p), ("blk_src", C.c_void_p), ("blk_dst", C.c_void_p), ("blk_pos", C.c_void_p),
                 ("q_ij", C.c_void_p), ("node_prob", C.c_void_p), ("embed_norm", C.c_void_p), ("alpha_or_null", C.c_void_p),
-                ("dst_nid", C.c_void_p), ("n_edges_dev", C.c_void_p), ("rewards_out", C.c_void_p), ("edges_bound", C.c_int32)]
+                ("dst_nid", C.c_void_p), ("n_edges_dev", C.c_void_p), ("rewards_out", C.c_void_p), ("edges_bound", C.c_int32),
+                ("norm_pend", C.c_void_p)]
 
 
 EXP3_MAX_BLOCKS = 8
@@ -138,6 +139,8 @@ SIGNATURES = {
     "bliss_graph_prepare": [_P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
     "bliss_exp3_step": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
+    "bliss_exp3_step_deferred": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
+    "bliss_exp3_normalize_pending": [C.POINTER(Exp3Block), _I32, _I64, _P],
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],

@@ -105,12 +105,41 @@ class BanditLadiesSampler(BlockSampler):
             self._scratch = torch.zeros(L, 98, dtype=torch.int64, device=g.device)
             self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
             self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
+            self._pend = torch.zeros(L, dtype=torch.int32, device=g.device)
+
+    # -- F.normalize off the critical path ----------------------------------------------------
+    # bandit_sampler.py:249 renormalises every row after every update.  Here the pass over a row (4 bytes of HBM traffic per
+    # edge of the GRAPH) only runs when the row's bf16 norm is not exactly 1.0 -- which still happens in stretches of hundreds
+    # of steps (the bf16 quotients over- and undershoot: norm 1.0078, 0.9961, 1.0078 ... until the drift of the sum ends the
+    # cycle), and the next batch's sampler waits for exp3().  With ``defer_normalize`` set (train.PipelinedTrainStep does)
+    # exp3() only decides which rows need the pass; sample_blocks_static divides what it reads on the fly, and
+    # ``normalize_pending`` rewrites the rows -- beside the next forward pass.  Same bits as the immediate pass.
+    defer_normalize = False
+    _pend_maybe = False
+
+    def normalize_pending(self, g=None):
+        """Rewrite the rows a deferred exp3() left pending (one launch; a no-op on the device when there are none)."""
+        if self._w_pos is None or getattr(self, "_pend", None) is None:
+            return
+        L = self._w_pos.shape[0]
+        rows = (_lib.Exp3Block * L)()
+        for idx in range(L):
+            rows[idx].w_pos, rows[idx].row_sum = self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr()
+            rows[idx].scratch, rows[idx].norm_pend = self._scratch[idx].data_ptr(), self._pend[idx:].data_ptr()
+        _lib.check(_lib.lib.bliss_exp3_normalize_pending(rows, L, self._w_pos.shape[1], _stream()), "bliss_exp3_normalize_pending")
+        self._pend_maybe = False
+
+    def _settle(self):
+        # anything that reads or writes the rows outside the deferred protocol sees them rewritten
+        if self._pend_maybe:
+            self.normalize_pending()
 
     @property
     def exp3_weights(self):
         """[L, |E|] bf16 indexed by EDGE ID like the reference's attribute (bandit_sampler.py:43)."""
         if self._w_pos is None:
             return None
+        self._settle()
         return self._engine.g.by_edge_id(self._w_pos)
 
     @exp3_weights.setter
@@ -125,6 +154,8 @@ class BanditLadiesSampler(BlockSampler):
         self._scratch = torch.zeros(L, 98, dtype=torch.int64, device=g.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
         self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
+        self._pend = torch.zeros(L, dtype=torch.int32, device=g.device)
+        self._pend_maybe = False
         for l in range(L):
             _lib.check(_lib.lib.bliss_row_sum(self._w_pos[l].data_ptr(), g.num_edges(), self._row_sum[l].data_ptr(),
                                               _stream()), "bliss_row_sum")
@@ -136,6 +167,7 @@ class BanditLadiesSampler(BlockSampler):
         g = self._graph(g)
         eng = self._bind(g)
         self._ensure_weights(g)
+        self._settle()
         output_nodes = seed_nodes
         order = list(reversed(range(len(self.nodes_per_layer))))          # :350
         rows, fan = [self._w_pos[b] for b in order], [self.nodes_per_layer[b] for b in order]
@@ -161,8 +193,12 @@ class BanditLadiesSampler(BlockSampler):
         eng = self._bind(g)
         self._ensure_weights(g)
         order = list(reversed(range(len(self.nodes_per_layer))))
+        pend = [self._pend[b:].data_ptr() for b in order] if self.defer_normalize else None
+        if pend is None:
+            self._settle()
         blks = eng.enqueue_static([self._w_pos[b] for b in order], seed_nodes, [self.nodes_per_layer[b] for b in order],
-                                  self._mode(), self.eta, self.eps, slot=slot, chain_rng=chain_rng, external_rng=external_rng, part=part)
+                                  self._mode(), self.eta, self.eps, slot=slot, chain_rng=chain_rng, external_rng=external_rng, part=part,
+                                  w_pend=pend)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights
@@ -188,6 +224,8 @@ class BanditLadiesSampler(BlockSampler):
         edge_w_pos = g.edata_by_position(self.edge_weight)
         cg = self._engine.c_graph
         fused = apply and factors is None and len(mfgs) <= 8         # all blocks in two launches (bliss_exp3_step)
+        defer = fused and self.defer_normalize
+        self._settle()                                               # (a caller that overlaps the pass has launched it already)
         keep = []                                                    # (tensors the launch reads must outlive the loop)
         recs = (_lib.Exp3Block * len(mfgs))() if fused else None
         for idx, mfg in enumerate(mfgs):
@@ -211,7 +249,7 @@ class BanditLadiesSampler(BlockSampler):
                                            self._norms[idx:].data_ptr(), mfg.indptr.data_ptr(), mfg.src.data_ptr(), mfg.dst.data_ptr(),
                                            mfg.pos.data_ptr(), mfg.edata["q_ij"].data_ptr(), mfg.srcdata[self.node_prob].data_ptr(),
                                            en.data_ptr(), 0 if alpha is None else alpha.data_ptr(), mfg.dstdata[NID].data_ptr(),
-                                           n_edges_ptr, rewards.data_ptr(), B)
+                                           n_edges_ptr, rewards.data_ptr(), B, self._pend[idx:].data_ptr())
                 mfg.edata["rewards"] = rewards                          # :193
                 continue
             _lib.check(_lib.lib.bliss_exp3_update(
@@ -228,8 +266,9 @@ class BanditLadiesSampler(BlockSampler):
                                                      self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
                                                      self._norms[idx:].data_ptr(), st), "bliss_exp3_normalize")
         if fused and len(mfgs):
-            _lib.check(_lib.lib.bliss_exp3_step(C.byref(cg), edge_w_pos.data_ptr(), recs, len(mfgs), self._delta_f,
-                                                self._err.data_ptr(), st), "bliss_exp3_step")
+            fn = _lib.lib.bliss_exp3_step_deferred if defer else _lib.lib.bliss_exp3_step
+            _lib.check(fn(C.byref(cg), edge_w_pos.data_ptr(), recs, len(mfgs), self._delta_f, self._err.data_ptr(), st), "bliss_exp3_step")
+            self._pend_maybe = self._pend_maybe or defer
 
     def apply_updates(self, idx, pos, factor, g, n_dev=None):
         """w[pos] *= factor on layer ``idx`` (positions unique within one call), bandit_sampler.py:248.  ``n_dev``: optional
@@ -237,6 +276,7 @@ class BanditLadiesSampler(BlockSampler):
         bound = int(pos.numel())
         if bound == 0:
             return
+        self._settle()
         if n_dev is None:
             n_dev = torch.tensor([bound], dtype=torch.int32, device=pos.device)
         _lib.check(_lib.lib.bliss_exp3_apply(self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr(), pos.data_ptr(),
@@ -247,6 +287,7 @@ class BanditLadiesSampler(BlockSampler):
         """apply_updates for the packed (position, factor, count) lists of ``n_ranks`` ranks and several blocks in ONE launch,
         rank after rank (bliss_exp3_apply_ranks; ``gathered`` int32 = the all-gathered buffers, offsets per block inside one
         rank's buffer).  Same bits as the corresponding apply_updates calls in rank order."""
+        self._settle()
         m = _lib.Exp3RankLists()
         for j, idx in enumerate(block_ids):
             m.w_pos[j], m.row_sum[j] = self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr()
@@ -260,6 +301,7 @@ class BanditLadiesSampler(BlockSampler):
     def normalize(self, idx, g):
         """F.normalize(self.exp3_weights[idx], p=1, dim=0), bandit_sampler.py:249 (bit-exact, skipped on the
         device when the bf16 norm is 1.0)."""
+        self._settle()
         _lib.check(_lib.lib.bliss_exp3_normalize(self._w_pos[idx].data_ptr(), g.num_edges(), self._row_sum[idx].data_ptr(),
                                                  self._scratch[idx].data_ptr(), self._norms[idx:].data_ptr(), _stream()),
                    "bliss_exp3_normalize")

@@ -45,6 +45,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round-trip through bf16
 
+// F.normalize(row, p=1) element by element (bandit_sampler.py:249): x / max(norm, eps), rounded to bf16.  ONE definition
+// for the pass that rewrites a row (exp3.hip) and for the readers that apply a pending pass on the fly (sampler.hip:
+// BLISS_NORM_DEFER), so both produce the same bits.  pend = 0x10000 | bf16 bits of the norm, 0 = nothing pending.
+__device__ __forceinline__ float renorm_denom(int pend) { return rbf(fmaxf(bf2f((bf16_t)(pend & 0xffff)), 1e-12f)); }
+__device__ __forceinline__ bf16_t renorm_bf16(bf16_t x, float denom) { return f2bf(bf2f(x) / denom); }
+__device__ __forceinline__ bf16_t renorm_pending(bf16_t x, int pend, float denom) { return pend ? renorm_bf16(x, denom) : x; }
+
 // bf16 -> signed 64-bit fixed point with `frac` fractional bits; truncates below 2^-frac.
 // Sets *bad on a non-finite input or a magnitude that does not fit.
 __device__ __forceinline__ int64_t bf_to_fixed(bf16_t b, int frac, int* bad) {

@@ -13,10 +13,19 @@
 #include "common.cuh"
 #include "bliss_gnn.h"
 #include "prof.h"
+#include <cstdlib>
 
 namespace {
 
 #define E3_TPB 256
+// the row is streamed once: non-temporal accesses keep it from evicting what the sampler works on (A/B on the Reddit-like
+// loop: steps with a pass 0.92 -> 0.89 ms; alone on the chip the pass is a little slower this way, 85 -> 90 us)
+#ifndef NORM_NT
+#define NORM_NT 1
+#endif
+#ifndef NORM_UNROLL
+#define NORM_UNROLL 4
+#endif
 
 // digits of (bf16 value * 2^64), truncated below 2^-64; non-negative finite input required
 __device__ __forceinline__ void row_digits(bf16_t b, int64_t d[3], int* bad) {
@@ -306,40 +315,83 @@ __global__ void k_zero_i64(int64_t* p, int n) { if ((int)threadIdx.x < n) p[thre
 // norm_src (optional): take the norm from THESE limbs instead of row_sum -- a destination-range shard normalises its part
 // of the row by the exact sum over ALL shards (an all-reduce of the limb arrays; integer sums commute), and row_sum still
 // receives the exact sum of this shard's renormalised part.
+// two elements of the pass the slow way (by division; sum through the general three-digit path)
+struct PairSlow { uint32_t word; int bad; int64_t d0, d1, d2; };
+__device__ __attribute__((noinline)) PairSlow renorm_pair_slow(uint32_t word, float denom) {
+  PairSlow r;
+  r.bad = 0;
+  const bf16_t lo = renorm_bf16((bf16_t)(word & 0xffffu), denom), hi = renorm_bf16((bf16_t)(word >> 16), denom);
+  int64_t a[3], b[3];
+  row_digits(lo, a, &r.bad);
+  row_digits(hi, b, &r.bad);
+  r.d0 = a[0] + b[0]; r.d1 = a[1] + b[1]; r.d2 = a[2] + b[2];
+  r.word = (uint32_t)lo | ((uint32_t)hi << 16);
+  return r;
+}
+
+// mode NORM_NOW: decide and rewrite in this launch.  NORM_DECIDE (one workgroup per row): only derive the norm and leave
+// 0x10000 | norm bits in *pend when the row needs the pass (0 otherwise) -- the readers of the row apply the division on
+// the fly (renorm_pending, common.cuh) until NORM_APPLY (any number of workgroups, any later launch) rewrites the row from
+// *pend, installs the new exact sum and clears *pend.  DECIDE + APPLY leave the bits of NOW.
+enum { NORM_NOW = 0, NORM_DECIDE = 1, NORM_APPLY = 2 };
 __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out, int wg, int nwg,
-                                                   const int64_t* norm_src = nullptr) {
+                                                   const int64_t* norm_src = nullptr, int mode = NORM_NOW, int* pend = nullptr) {
   __shared__ int sh_norm, sh_last;
   if (threadIdx.x == 0) {
-    int bad = 0;
-    const bf16_t nb = limbs_to_bf16(norm_src ? norm_src : row_sum, &bad);
-    sh_norm = (int)nb | (bad << 20);
-    if (wg == 0) {
-      scratch[0] = (int64_t)nb | ((int64_t)(nb == 0x3f80) << 16) | ((int64_t)bad << 20);
-      if (norm_out) *norm_out = nb;
+    if (mode == NORM_APPLY) {
+      const int pd = __hip_atomic_load(pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh_norm = pd ? (pd & 0xffff) : 0x3f80;       // nothing pending: leave like a row whose norm is 1.0
+    } else {
+      int bad = 0;
+      const bf16_t nb = limbs_to_bf16(norm_src ? norm_src : row_sum, &bad);
+      sh_norm = (int)nb | (bad << 20);
+      if (wg == 0) {
+        scratch[0] = (int64_t)nb | ((int64_t)(nb == 0x3f80) << 16) | ((int64_t)bad << 20);
+        if (norm_out) *norm_out = nb;
+        if (mode == NORM_DECIDE) *pend = (nb == 0x3f80) ? 0 : (0x10000 | (int)nb);
+      }
     }
   }
   __syncthreads();
   const bf16_t nb = (bf16_t)(sh_norm & 0xffff);
-  if (nb == 0x3f80) return;                        // x / 1.0 == x : the row is already normalised, bit for bit
-  const float denom = rbf(fmaxf(bf2f(nb), 1e-12f));  // F.normalize: norm.clamp_min(eps)
+  if (nb == 0x3f80 || mode == NORM_DECIDE) return;   // x / 1.0 == x : the row is already normalised, bit for bit
+  const float denom = renorm_denom((int)nb);       // F.normalize: norm.clamp_min(eps)
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
-  // exact sum of the new values, cheaply: value * 2^64 = m << shift with an 8-bit m; shifts below 32 go to accA (units of
-  // 2^-64), shifts 32..55 to accB (units of 2^-32) -- a thread adds < 2^20 terms of < 2^40 to each, no overflow -- and only
-  // the rare large values take the general three-digit path
-  uint64_t accA = 0, accB = 0;
+  // The quotient without dividing.  Division by a fixed denominator commutes with powers of two as long as nothing leaves
+  // the normal range, and so does the rounding to bf16: the quotient's BITS are x's bits plus a constant that depends only on
+  // x's 7 mantissa bits -- 128 constants per pass, taken from renorm_bf16 itself on [1, 2).  (The pass was bound by its
+  // arithmetic, not by HBM: 8 IEEE divisions per 16 bytes.)  Valid for a positive normal x whose quotient is normal too, with a
+  // binade to spare on either side; everything else -- zero, subnormal, negative, non-finite, the edges of the range --
+  // takes the division.
+  __shared__ int sh_tbl[128];
+  if (threadIdx.x < 128) {
+    const bf16_t x0 = (bf16_t)(0x3f80u | threadIdx.x);
+    sh_tbl[threadIdx.x] = ((int)renorm_bf16(x0, denom) - (int)x0) & 0xffff;      // (added mod 2^16)
+  }
+  const int de_lo = (int)(renorm_bf16((bf16_t)0x3f80u, denom) >> 7) - 127;      // exponent change of the smallest mantissa ...
+  const int de_hi = (int)(renorm_bf16((bf16_t)0x3fffu, denom) >> 7) - 127;      // ... and of the largest (monotonic in between)
+  // x's sign|exponent field must lie in [e_lo, e_hi]; both quotients above normal and finite, else no x qualifies
+  const bool tbl_ok = de_lo > -126 && de_hi < 126 && de_lo <= de_hi;
+  const uint32_t e_lo = (uint32_t)max(2, 2 - de_lo), e_hi = (uint32_t)min(253, 253 - de_hi);
+  // ... and for the two-at-a-time path below also the QUOTIENT's exponent field in [70, 125]: its value * 2^64 is then
+  // m << s with s = field - 70 in [0, 56), which that path adds up in seven per-thread LDS counters, one per 8 bits of s
+  // (term = m << (s & 7) < 2^15, a thread adds far fewer than 2^17 of them: no overflow, no 64-bit shifts, no conflicts: bank = lane)
+  const int f_lo = max((int)e_lo, 70 - de_lo), f_hi = min((int)e_hi, 125 - de_hi);
+  const bool pair_ok = tbl_ok && e_hi >= e_lo && f_hi >= f_lo;
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const unsigned short f_base = pair_ok ? (unsigned short)f_lo : (unsigned short)0xffffu, f_span = pair_ok ? (unsigned short)(f_hi - f_lo) : (unsigned short)0;
+  const u16x2 FLO2 = {f_base, f_base}, SPAN2 = {f_span, f_span};
+  __shared__ unsigned sh_bins[7][E3_TPB];
+#pragma unroll
+  for (int a = 0; a < 7; ++a) sh_bins[a][threadIdx.x] = 0;
+  __syncthreads();
+  // (everything else: one at a time, by division, sum through the general three-digit path)
   auto one = [&](bf16_t x) {
-    const bf16_t v = f2bf(bf2f(x) / denom);        // :249 input / denom
-    uint32_t e = (v >> 7) & 0xff, m = v & 0x7f;
-    if (e == 0) e = 1; else m |= 0x80;
-    const int shift = (int)e - 70;                 // e - 134 + 64
-    if ((v & 0x8000u) == 0 && e != 255 && shift >= 0 && shift < 56) {
-      if (shift < 32) accA += (uint64_t)m << shift; else accB += (uint64_t)m << (shift - 32);
-    } else {
-      int64_t a[3];
-      row_digits(v, a, &bad);
-      dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
-    }
+    const bf16_t v = renorm_bf16(x, denom);        // :249 input / denom
+    int64_t a[3];
+    row_digits(v, a, &bad);
+    dg[0] += a[0]; dg[1] += a[1]; dg[2] += a[2];
     return v;
   };
   // When the pass does run it is a pure stream over the row (2 x 2 bytes per edge, 0.46 GB on the Reddit-like graph):
@@ -349,20 +401,53 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
   const int64_t gtid = (int64_t)wg * E3_TPB + threadIdx.x, gsz = (int64_t)nwg * E3_TPB;
   if (gtid < head) w[gtid] = one(w[gtid]);
   for (int64_t i = head + nvec * 8 + gtid; i < n; i += gsz) w[i] = one(w[i]);
-  uint4* wv = reinterpret_cast<uint4*>(w + head);
-#pragma unroll 4
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* wv = reinterpret_cast<u32x4*>(w + head);
+#pragma unroll NORM_UNROLL
   for (int64_t i = gtid; i < nvec; i += gsz) {
-    uint4 x = wv[i];
-    uint32_t* q = reinterpret_cast<uint32_t*>(&x);
+#if NORM_NT
+    u32x4 x = __builtin_nontemporal_load(wv + i);
+#else
+    u32x4 x = wv[i];
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const bf16_t lo = one((bf16_t)(q[k] & 0xffffu)), hi = one((bf16_t)(q[k] >> 16));
-      q[k] = (uint32_t)lo | ((uint32_t)hi << 16);
+      const uint32_t word = x[k];
+      const u16x2 W = __builtin_bit_cast(u16x2, word);
+      const u16x2 D = (W >> 7) - FLO2;               // sign|exponent fields relative to the range (wrapping)
+      if (__builtin_bit_cast(uint32_t, __builtin_elementwise_max(D, SPAN2)) == __builtin_bit_cast(uint32_t, SPAN2)) {
+        // both in range: quotient bits = bits + constant(mantissa), two at a time
+        const uint32_t t = (uint32_t)sh_tbl[word & 0x7fu] | ((uint32_t)sh_tbl[(word >> 16) & 0x7fu] << 16);
+        const u16x2 V = W + __builtin_bit_cast(u16x2, t);
+        const uint32_t v2 = __builtin_bit_cast(uint32_t, V);
+        const u16x2 S = (V >> 7) - (u16x2){70, 70};
+        const u16x2 M = __builtin_bit_cast(u16x2, (v2 & 0x007f007fu) | 0x00800080u);
+        const u16x2 T = M << (S & (u16x2){7, 7});
+        const u16x2 A = S >> 3;
+        __hip_atomic_fetch_add(&sh_bins[A.x][threadIdx.x], (unsigned)T.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sh_bins[A.y][threadIdx.x], (unsigned)T.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        x[k] = v2;
+      } else {                                     // rare: a call, so that the loop body stays small
+        const PairSlow r = renorm_pair_slow(word, denom);
+        x[k] = r.word; bad |= r.bad;
+        dg[0] += r.d0; dg[1] += r.d1; dg[2] += r.d2;
+      }
     }
+#if NORM_NT
+    __builtin_nontemporal_store(x, wv + i);
+#else
     wv[i] = x;
+#endif
   }
-  dg[0] += (int64_t)(accA & 0xffffffffull); dg[1] += (int64_t)(accA >> 32);
-  dg[1] += (int64_t)(accB & 0xffffffffull); dg[2] += (int64_t)(accB >> 32);
+  {                                                // the thread's seven counters -> digits
+    uint64_t a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a += (uint64_t)sh_bins[k][threadIdx.x] << (8 * k);           // units of 2^-64
+#pragma unroll
+    for (int k = 4; k < 7; ++k) b += (uint64_t)sh_bins[k][threadIdx.x] << (8 * (k - 4));     // units of 2^-32
+    dg[0] += (int64_t)(a & 0xffffffffull); dg[1] += (int64_t)(a >> 32);
+    dg[1] += (int64_t)(b & 0xffffffffull); dg[2] += (int64_t)(b >> 32);
+  }
   flush_digits(dg, scratch + 2);
   if (bad) atomicOr((unsigned long long*)scratch, (unsigned long long)bad << 20);
   // The last workgroup installs the new exact sum.  Everything it needs from the others went through memory-side
@@ -377,7 +462,10 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
       row_sum[k] = (int64_t)__hip_atomic_load((unsigned long long*)(scratch + 2 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store((unsigned long long*)(scratch + 2 + k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(scratch + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store((unsigned long long*)(scratch + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mode == NORM_APPLY) __hip_atomic_store(pend, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -386,10 +474,11 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
   normalize_row_body(w, n, row_sum, scratch, norm_out, blockIdx.x, gridDim.x, norm_src);
 }
 // the rows of all layers in one launch: gridDim.x / n_rows workgroups per row
-__global__ void __launch_bounds__(E3_TPB) k_normalize_rows(const Exp3Multi m, int64_t n, int per_row) {
+__global__ void __launch_bounds__(E3_TPB) k_normalize_rows(const Exp3Multi m, int64_t n, int per_row, int mode) {
   const int r = blockIdx.x / per_row;
   const bliss_exp3_block_t& k = m.blk[r];
-  normalize_row_body((bf16_t*)k.w_pos, n, k.row_sum, k.scratch, (bf16_t*)k.norm_out, (int)blockIdx.x - r * per_row, per_row);
+  normalize_row_body((bf16_t*)k.w_pos, n, k.row_sum, k.scratch, (bf16_t*)k.norm_out, (int)blockIdx.x - r * per_row, per_row, nullptr, mode,
+                     k.norm_pend);
 }
 
 // w_pos[p] = bf16(1 / bf16(indeg(dst(p))))          bandit_sampler.py:20-27
@@ -404,6 +493,12 @@ __global__ void __launch_bounds__(E3_TPB) k_normalized_edata(const int64_t* __re
 }
 
 }  // namespace
+
+// workgroups per row of the F.normalize pass (BLISS_NORM_WGS overrides, for measurements)
+static int norm_wgs() {
+  static const int v = [] { const char* e = getenv("BLISS_NORM_WGS"); int x = e ? atoi(e) : 0; return x > 0 ? x : 1024; }();
+  return v;
+}
 
 extern "C" {
 
@@ -428,8 +523,8 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
   return (int)hipGetLastError();
 }
 
-int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
-                    float delta_f, int32_t* err, void* stream) {
+static int exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                     float delta_f, int32_t* err, void* stream, bool defer) {
   if (!g || !blocks || n_blocks <= 0 || n_blocks > BLISS_EXP3_MAX_BLOCKS || !err) return BLISS_EINVAL;
   Exp3Multi m;
   m.n = n_blocks;
@@ -437,7 +532,7 @@ int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_
   for (int i = 0; i < n_blocks; ++i) {
     const bliss_exp3_block_t& k = blocks[i];
     if (!k.w_pos || !k.row_sum || !k.scratch || !k.blk_indptr || !k.blk_src || !k.blk_dst || !k.blk_pos || !k.q_ij || !k.node_prob ||
-        !k.embed_norm || !k.dst_nid || !k.n_edges_dev || (!edge_w_pos && !k.alpha_or_null) || k.edges_bound < 0)
+        !k.embed_norm || !k.dst_nid || !k.n_edges_dev || (!edge_w_pos && !k.alpha_or_null) || k.edges_bound < 0 || (defer && !k.norm_pend))
       return BLISS_EINVAL;
     m.blk[i] = k;
     m.grid_begin[i] = total;
@@ -452,9 +547,37 @@ int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_
   int64_t per_row = (g->num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   // usually every workgroup returns at once (norm == 1.0), but a row that does need the pass streams 4 bytes per edge and
   // wants the whole chip: 1024 workgroups per row
-  if (per_row > 1024) per_row = 1024;
+  if (per_row > norm_wgs()) per_row = norm_wgs();
   if (per_row < 1) per_row = 1;
-  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows<<<(int)(per_row * n_blocks), E3_TPB, 0, st>>>(m, g->num_edges, (int)per_row));
+  if (defer) per_row = 1;                              // only the decision: one workgroup per row
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows<<<(int)(per_row * n_blocks), E3_TPB, 0, st>>>(m, g->num_edges, (int)per_row, defer ? NORM_DECIDE : NORM_NOW));
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                    float delta_f, int32_t* err, void* stream) {
+  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, false);
+}
+
+int bliss_exp3_step_deferred(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                             float delta_f, int32_t* err, void* stream) {
+  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, true);
+}
+
+int bliss_exp3_normalize_pending(const bliss_exp3_block_t* rows, int32_t n_rows, int64_t num_edges, void* stream) {
+  if (!rows || n_rows <= 0 || n_rows > BLISS_EXP3_MAX_BLOCKS || num_edges < 0) return BLISS_EINVAL;
+  Exp3Multi m;
+  m.n = n_rows;
+  for (int i = 0; i < n_rows; ++i) {
+    if (!rows[i].w_pos || !rows[i].row_sum || !rows[i].scratch || !rows[i].norm_pend) return BLISS_EINVAL;
+    m.blk[i] = rows[i];
+    m.grid_begin[i] = 0;
+  }
+  int64_t per_row = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
+  if (per_row > norm_wgs()) per_row = norm_wgs();
+  if (per_row < 1) per_row = 1;
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows<<<(int)(per_row * n_rows), E3_TPB, 0, st>>>(m, num_edges, (int)per_row, NORM_APPLY));
   return (int)hipGetLastError();
 }
 
@@ -524,7 +647,7 @@ int bliss_exp3_normalize(void* w_pos, int64_t num_edges, int64_t* row_sum, int64
   if (!w_pos || !row_sum || !scratch || num_edges <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
-  if (grid > 1024) grid = 1024;                      // usually every workgroup returns at once (norm == 1.0): keep the launch small
+  if (grid > norm_wgs()) grid = norm_wgs();          // usually every workgroup returns at once (norm == 1.0): keep the launch small
   if (grid < 1) grid = 1;
   PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16, nullptr));
   return (int)hipGetLastError();
@@ -535,7 +658,7 @@ int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum
   if (!w_pos || !row_sum || !norm_limbs || !scratch || num_edges <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int64_t grid = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
-  if (grid > 1024) grid = 1024;
+  if (grid > norm_wgs()) grid = norm_wgs();
   if (grid < 1) grid = 1;
   PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16, norm_limbs));
   return (int)hipGetLastError();

@@ -197,7 +197,9 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restric
                                                         const int* __restrict__ seg_ptr, const long long* __restrict__ col_base,
     const int* __restrict__ span_seg, LayerCounts* cnt,
                                                         const int* __restrict__ local_id, unsigned* first_pos,
-                                                        unsigned long long* acc_w) {
+                                                        unsigned long long* acc_w, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   const int S = cnt->S, E = cnt->E;
   const int nspans = (E + SPAN - 1) / SPAN;
   int bad = 0;
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restric
           if (__hip_atomic_load(first_pos + a.src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)e)
             atomicMin(first_pos + a.src, (unsigned)e);
         }
-        if (BANDIT) term = bf_to_fixed(w[a.pos], FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
+        if (BANDIT) term = bf_to_fixed(renorm_pending(w[a.pos], pend, pdenom), FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
       }
       if (BANDIT) wave_segsum_atomic_i64(a.k, term, acc_w);
     }
@@ -234,7 +236,9 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restric
                                                         const unsigned* __restrict__ first_pos,
                                                         const unsigned long long* __restrict__ acc_w,
                                                         unsigned long long* acc_q, int* __restrict__ chunk_cnt,
-                                                        float eta_f, float ome_f) {
+                                                        float eta_f, float ome_f, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restric
         first = first_pos[a.src] == (unsigned)e;
         if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
+          bf16_t q = edge_q(renorm_pending(w[a.pos], pend, pdenom), wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           term = bf_to_fixed(q, FRAC_DST, &bad);       // :67 copy_e_sum(insg, edge_prob)
         }
       }
@@ -300,7 +304,9 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
                                                         const unsigned long long* __restrict__ acc_q,
                                                         const int* __restrict__ chunk_off, int* local_id,
                                                         int* __restrict__ cand_nid, unsigned long long* acc_p2,
-                                                        float eta_f, float ome_f, int cap_c, int uniform_nodes) {
+                                                        float eta_f, float ome_f, int cap_c, int uniform_nodes, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
   const int nchunks = (E + CHUNK - 1) / CHUNK;
@@ -325,12 +331,12 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
           acc_p2[a.src] = 1ull;
         } else if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(w[a.pos], wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
+          bf16_t q = edge_q(renorm_pending(w[a.pos], pend, pdenom), wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           bf16_t qsum = fixed_to_bf((int64_t)acc_q[a.k], FRAC_DST, &bad);
           float r = rbf(bf2f(q) / bf2f(qsum));          // :71 e_div_u on the reversed frontier
           t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
         } else {
-          float x = bf2f(w[a.pos]);                     // ladies_sampler.py:46-47  weight ** 2
+          float x = bf2f(renorm_pending(w[a.pos], pend, pdenom));                     // ladies_sampler.py:46-47  weight ** 2
           t = f2bf(x * x);
         }
         int64_t fx = uniform_nodes ? 0 : bf_to_fixed(t, FRAC_SRC, &bad);
@@ -456,7 +462,9 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
                                                       const long long* __restrict__ col_base, const int* __restrict__ span_seg,
                                                       LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
                                                       unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                                      uint2* __restrict__ seed_coef, int n_wave_wgs) {
+                                                      uint2* __restrict__ seed_coef, int n_wave_wgs, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ long long sh[COL_TPB / 64];
   const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
   if (cnt->E == 0) return;
@@ -477,8 +485,15 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int r = 0; r < COL_R; ++r) {
       const int i = lane + r * 64;
       wr[r] = 0;
-      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
+      if (i < n) wr[r] = w[p0 + i];
     }
+    if (pend) {                                       // (uniform; after ALL the loads have been issued)
+#pragma unroll
+      for (int r = 0; r < COL_R; ++r) wr[r] = renorm_bf16(wr[r], pdenom);
+    }
+#pragma unroll
+    for (int r = 0; r < COL_R; ++r)
+      if (lane + r * 64 < n) emax = max(emax, bf_exp_field(wr[r]));
     const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
 #pragma unroll
     for (int r = 0; r < COL_R; ++r)
@@ -508,16 +523,23 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int r = 0; r < COL_RB; ++r) {
       const int i = tid + r * COL_TPB;
       wr[r] = 0;
-      if (i < n) { wr[r] = w[p0 + i]; emax = max(emax, bf_exp_field(wr[r])); }
+      if (i < n) wr[r] = w[p0 + i];
     }
+    if (pend) {
+#pragma unroll
+      for (int r = 0; r < COL_RB; ++r) wr[r] = renorm_bf16(wr[r], pdenom);
+    }
+#pragma unroll
+    for (int r = 0; r < COL_RB; ++r)
+      if (tid + r * COL_TPB < n) emax = max(emax, bf_exp_field(wr[r]));
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(w[p0 + i]));
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(renorm_pending(w[p0 + i], pend, pdenom)));
     const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL_TPB>(emax, sh));
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r)
       if (tid + r * COL_TPB < n) part += bf_to_fixed(wr[r], wfrac, &bad);
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(w[p0 + i], wfrac, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(renorm_pending(w[p0 + i], pend, pdenom), wfrac, &bad);
     const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
     const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
     const float a = rbf((1.0f / (float)n) * eta_f);
@@ -528,7 +550,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
       if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(w[p0 + i], wsum, a, ome_f), FRAC_DST, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(renorm_pending(w[p0 + i], pend, pdenom), wsum, a, ome_f), FRAC_DST, &bad);
     const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
     if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
@@ -544,7 +566,9 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
                                                      const unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
                                                      int uniform_nodes, int n_bins, int log2_bins, long long bin_cap, int* bin_cursor,
                                                      unsigned long long* __restrict__ bin_rec, unsigned* __restrict__ bitmap,
-                                                     const uint2* __restrict__ seed_coef) {
+                                                     const uint2* __restrict__ seed_coef, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int hist[MAX_BINS];
   __shared__ int gbase[MAX_BINS];
   const int S = cnt->S, E = cnt->E, tid = threadIdx.x;
@@ -571,11 +595,11 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
           t = (bf16_t)0x3f80;                           // importance_sampling=False (:77-81): only "has an out-edge" matters
         } else if (BANDIT) {
           const uint2 cf = seed_coef[a.k];              // per-seed: bf16 sum_j w_ij | bf16 sum_k q_ik, eta / n_i
-          bf16_t q = edge_q_pre(w[a.pos], (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f);
+          bf16_t q = edge_q_pre(renorm_pending(w[a.pos], pend, pdenom), (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f);
           float r = rbf(bf2f(q) / bf2f((bf16_t)(cf.x >> 16)));   // :71 e_div_u on the reversed frontier
           t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
         } else {
-          float x = bf2f(w[a.pos]);                     // ladies_sampler.py:46-47  weight ** 2
+          float x = bf2f(renorm_pending(w[a.pos], pend, pdenom));                     // ladies_sampler.py:46-47  weight ** 2
           t = f2bf(x * x);
         }
         srcs[j] = a.src; ts[j] = t;
@@ -1005,7 +1029,9 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      int* __restrict__ chunk_cnt, int* src_cnt, float eta_f, float ome_f,
                                                      const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob,
                                                      const uint2* __restrict__ seed_coef, KeptRec* __restrict__ kept_rec,
-                                                     int* __restrict__ span_cnt, long long kept_rec_positions) {
+                                                     int* __restrict__ span_cnt, long long kept_rec_positions, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
@@ -1030,8 +1056,9 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
         if (src_cnt) atomicAdd(src_cnt + r.nid, 1);     // out-degree inside the block: sizes the by-source index
         if (BANDIT) {
           bf16_t q;
-          if (seed_coef) { const uint2 cf = seed_coef[r.k]; q = edge_q_pre(w[r.pos], (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
-          else q = edge_q(w[r.pos], fixed_to_bf((int64_t)acc_w[r.k], FRAC_DST, &bad), seg_ptr[r.k + 1] - seg_ptr[r.k], eta_f, ome_f);
+          const bf16_t wv = renorm_pending(w[r.pos], pend, pdenom);
+          if (seed_coef) { const uint2 cf = seed_coef[r.k]; q = edge_q_pre(wv, (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
+          else q = edge_q(wv, fixed_to_bf((int64_t)acc_w[r.k], FRAC_DST, &bad), seg_ptr[r.k + 1] - seg_ptr[r.k], eta_f, ome_f);
           bf16_t wt = f2bf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));    // :314 e_div_u(sg, W, P)
           term = bf_to_fixed(wt, FRAC_BLK, &bad);      // :316 copy_e_sum
         }
@@ -1108,7 +1135,9 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      float eta_f, float ome_f, int cap_b, const int* __restrict__ kept_map,
                                                      const bf16_t* __restrict__ node_prob, const uint2* __restrict__ seed_coef,
                                                      const KeptRec* __restrict__ kept_rec, const int* __restrict__ span_cnt,
-                                                     long long kept_rec_positions) {
+                                                     long long kept_rec_positions, const int* __restrict__ w_pend) {
+  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
   const int S = cnt->S, E = cnt->E;
@@ -1132,10 +1161,11 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
       const KeptRec r = list[j];
       const int k = r.k;
       bf16_t q;
+      const bf16_t wv = renorm_pending(w[r.pos], pend, pdenom);
       if (BANDIT) {
-        if (seed_coef) { const uint2 cf = seed_coef[k]; q = edge_q_pre(w[r.pos], (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
-        else q = edge_q(w[r.pos], fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad), seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
-      } else q = w[r.pos];
+        if (seed_coef) { const uint2 cf = seed_coef[k]; q = edge_q_pre(wv, (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
+        else q = edge_q(wv, fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad), seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);
+      } else q = wv;
       float wt = rbf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));   // :314
       float d = rbf((float)deg_blk[k]);                              // int -> bf16 promotion of `d`
       float out;
@@ -1316,11 +1346,11 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     const int gb = grid_for(frontier_bound, BIN_BATCH);
     const int n_wave_wgs = grid_for(cap_s, COL_TPB / 64, 2048);
     if (col_sums)                                        // (the block passes need sum_j w_ij even when p_j does not)
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs));
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs, ws->w_pend));
     if (mode == BLISS_MODE_BANDIT)
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef, ws->w_pend));
     else
-      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef));
+      PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<false><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef, ws->w_pend));
     PROF_LAUNCH(BK_BIN_REDUCE, st, k_bin_reduce<<<ws->n_bins, BINRED_TPB, (size_t)slots * 12, st>>>(
         cnt, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, g->num_nodes, slots, m->local_id, seed_p2,
         (unsigned long long*)ws->touched_key, (unsigned long long*)ws->touched_sum, ws->bitmap, ws->cap_c));
@@ -1337,17 +1367,17 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     return (int)hipGetLastError();
   }
   if (mode == BLISS_MODE_BANDIT) {
-    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->local_id, m->first_pos, acc_w));
-    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<true><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->local_id, m->first_pos, acc_w, ws->w_pend));
+    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f, ws->w_pend));
   } else {
-    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->local_id, m->first_pos, acc_w));
-    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f));
+    PROF_LAUNCH(BK_PASS1, st, k_frontier_pass1<false><<<ge, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->local_id, m->first_pos, acc_w, ws->w_pend));
+    PROF_LAUNCH(BK_PASS2, st, k_frontier_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, eta_f, one_minus_eta_f, ws->w_pend));
   }
   PROF_LAUNCH(BK_CHUNK_SCAN, st, k_chunk_scan<<<1, 1024, 0, st>>>(ws->chunk_cnt, cnt, 0, ws->cap_c));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes, ws->w_pend));
   else
-    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes));
+    PROF_LAUNCH(BK_PASS3, st, k_frontier_pass3<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, m->first_pos, acc_w, acc_q, ws->chunk_cnt, m->local_id, ws->cand_nid, (unsigned long long*)m->acc_p2, eta_f, one_minus_eta_f, ws->cap_c, uniform_nodes, ws->w_pend));
   {
     int gf = (ws->cap_c + FIN_TPB * 8 - 1) / (FIN_TPB * 8);          // ~8 candidates per thread: amortise the 128 KiB LDS zero/flush
     if (gf < 1) gf = 1;
@@ -1417,14 +1447,14 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
   if (want_t && cap_s > TSORT_MAX_S) return BLISS_EINVAL;                    // caller falls back to bliss_block_transpose
   int* sc = want_t ? src_cnt : nullptr;
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions, ws->w_pend));
   else
-    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions));
+    PROF_LAUNCH(BK_BLOCK1, st, k_block_pass1<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, sc, eta_f, one_minus_eta_f, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions, ws->w_pend));
   PROF_LAUNCH(BK_INDPTR_SCAN, st, k_block_scans<<<want_t ? 3 : 2, 1024, 0, st>>>(ws->chunk_cnt, deg_blk, cnt, out->indptr, cap_s, out->cap_b, src_cnt, out->t_indptr, ws->cap_k));
   if (mode == BLISS_MODE_BANDIT)
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions, ws->w_pend));
   else
-    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions));
+    PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions, ws->w_pend));
   if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
     const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
     PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map));

@@ -12,6 +12,7 @@ replays, in order, exactly what they do to the sampler and the model each step
 """
 import contextlib
 import os
+import time
 
 import torch
 import torch.nn as nn
@@ -318,6 +319,15 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.use_flags = os.environ.get("BLISS_PIPELINE_FLAGS", "1") != "0"
         self.losses = None
         self.last_counts2 = None
+        # F.normalize's pass over the bandit rows beside the next forward pass instead of in front of the next sampler
+        # (bandit_sampler.normalize_pending; flag mode only, switched on by capture()).  BLISS_NORM_DEFER=0: inside exp3(),
+        # as the reference orders it.  Replicas keep the immediate pass: their update lists are applied after an exchange,
+        # outside the fused exp3 step.
+        self._defer_wanted = (not distributed and hasattr(sampler, "normalize_pending")
+                              and os.environ.get("BLISS_NORM_DEFER", "1") != "0")
+        self._defer = False
+        self._norm_done = torch.cuda.Event()
+        self.g_norm = None
 
     def _sample(self, slot, chain, external_rng=False, part=None):
         return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng,
@@ -328,15 +338,20 @@ class PipelinedTrainStep(GraphedTrainStep):
         return (hasattr(self.model, "forward_hidden") and len(getattr(self.model, "layers", ())) > 1 and hasattr(self.sampler, "exp3")
                 and os.environ.get("BLISS_SPLIT_FORWARD", "1") != "0")
 
-    def _forward(self, mfgs):
+    FLAG_SAMPLED, FLAG_NORM_DONE = 12, 13         # engine.flags slots (0..L-1: the sampler's layers; 14: the probe)
+
+    def _forward(self, mfgs, flagged=False):
         """The part of the step the NEXT batch's sampler waits for: the forward pass up to the output layer's input (every
         block's row norms exist from there on, train_lightning.py:232-238 reads nothing else) and the bandit update.  Returns
         what _backward needs to finish the step."""
-        if self._split_forward():
-            pending = ("hidden", self.model.forward_hidden(mfgs, _inputs(self.model, mfgs)), mfgs)
-        else:
-            pred = self.model(mfgs, _inputs(self.model, mfgs))
-            pending = ("loss", self.loss_fn(pred, mfgs[-1].dstdata["labels"]), mfgs)
+        if self._defer and not flagged:                            # eager: the rows the previous update left pending, inline
+            self.sampler.normalize_pending()
+        pending = self._forward_model(mfgs)
+        if self._defer and flagged:                                # the pass runs on the third stream (g_norm): X waits for it
+            eng = self.sampler._engine
+            _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_NORM_DONE, eng.flag_err.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "bliss_flag_wait")
+            self.sampler._pend_maybe = False                       # (exp3() need not launch the pass itself)
         if not hasattr(self.sampler, "exp3"):                      # LADIES samplers keep no bandit state
             return pending
         if self.distributed:
@@ -344,6 +359,14 @@ class PipelinedTrainStep(GraphedTrainStep):
             bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
         else:
             self.sampler.exp3(mfgs, self.g)
+        return pending
+
+    def _forward_model(self, mfgs):
+        if self._split_forward():
+            pending = ("hidden", self.model.forward_hidden(mfgs, _inputs(self.model, mfgs)), mfgs)
+        else:
+            pred = self.model(mfgs, _inputs(self.model, mfgs))
+            pending = ("loss", self.loss_fn(pred, mfgs[-1].dstdata["labels"]), mfgs)
         return pending
 
     def _backward(self, pending):
@@ -388,6 +411,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.sampler.finish_static(0, commit=True)
 
     def _finish_pair(self, check_flags=True):
+        if self._defer:                                  # whoever looks at the rows between two calls sees them rewritten
+            self.sampler.normalize_pending()
         torch.cuda.current_stream().synchronize()
         c1 = self.sampler.finish_static(1, commit=False)
         c0 = self.sampler.finish_static(0, commit=True)
@@ -412,6 +437,8 @@ class PipelinedTrainStep(GraphedTrainStep):
             self.use_flags = False
         if self.use_flags:
             eng.scratch_sets = max(eng.scratch_sets, L)      # block n then shares no scratch with any later layer
+        self._defer = self._defer_wanted and self.use_flags
+        self.sampler.defer_normalize = self._defer
         tune_gemm = tune_gemm and _enable_gemm_tuning()
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
@@ -482,15 +509,27 @@ class PipelinedTrainStep(GraphedTrainStep):
         pool = torch.cuda.graph_pool_handle()
         self.graph = None
         self.g_main, self.g_fwd, self.g_bwd, self.g_smp, self.g_blk = ([None, None] for _ in range(5))
+        self.g_norm = None
         held, out = [None, None], [None, None]
+        st_ = lambda: torch.cuda.current_stream().cuda_stream
+        if self._defer:
+            # F.normalize's pass, for the third stream: once the sampler that reads the rows (dividing on the fly) has finished,
+            # rewrite them in place -- beside the next forward pass -- and tell the next bandit update
+            self.g_norm = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_norm, pool=pool):
+                _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_SAMPLED, eng.flag_err.data_ptr(), st_()), "bliss_flag_wait")
+                self.sampler.normalize_pending()
+                _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_NORM_DONE, st_()), "bliss_flag_raise")
         for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
             # (the sampler is recorded without its generator: that one is launched ahead of time, see _replay / run)
             self.g_bwd[cur] = torch.cuda.CUDAGraph()
             if self.use_flags:
                 self.g_main[cur] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_main[cur], pool=pool, stream=side):
-                    held[cur] = self._forward(self.mfgs[cur])                                   # F + X
+                    held[cur] = self._forward(self.mfgs[cur], flagged=True)                     # F + X
                     self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True, part="main")   # S without the early blocks
+                    if self._defer:
+                        _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_SAMPLED, st_()), "bliss_flag_raise")
                 if L > 1:
                     self.g_blk[nxt] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.g_blk[nxt]):
@@ -524,6 +563,10 @@ class PipelinedTrainStep(GraphedTrainStep):
                 with torch.cuda.stream(self.third):
                     self.g_blk[nxt].replay()             # early blocks of S: each waits for the flag of the next layer
                     self._blk_done.record(self.third)
+            if self.g_norm is not None:
+                with torch.cuda.stream(self.third):
+                    self.g_norm.replay()                 # F.normalize's pass: waits for the end of S, runs beside the next F
+                    self._norm_done.record(self.third)
             with torch.cuda.stream(side):
                 self.g_bwd[cur].replay()                 # B: waits for the flag S raises when it starts
                 if on_side is not None:
@@ -545,9 +588,19 @@ class PipelinedTrainStep(GraphedTrainStep):
 
     def _join(self):
         torch.cuda.current_stream().wait_event(self._bwd_done)     # (flag mode: implies the early blocks, see _half)
+        if self.g_norm is not None:
+            torch.cuda.current_stream().wait_event(self._norm_done)
+
+    def _prime_norm_flag(self):
+        # the first bandit update of a run of replays waits for a pass nobody launched: the rows are settled (_finish_pair)
+        if self.g_norm is not None:
+            eng = self.sampler._engine
+            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_NORM_DONE, torch.cuda.current_stream().cuda_stream),
+                       "bliss_flag_raise")
 
     def _replay(self, first_chain=False):
         eng = self.sampler._engine
+        self._prime_norm_flag()
         for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
             eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
             self._half(cur, nxt)
@@ -638,16 +691,20 @@ class PipelinedTrainStep(GraphedTrainStep):
         # between two samplers (state commit, counts to the host, control block of the next generator) is one kernel on the
         # generator's stream (static_rng_chain); the seed ids of later batches are copied on the backward pass's stream.
         main = torch.cuda.current_stream()
+        self._prime_norm_flag()
         if n_pairs:
             self.seeds2[1].copy_(next(loader))           # S(b) runs first, then S(a')
             self.seeds2[0].copy_(next(loader))
+        trace = self._host_trace = [] if pair_events is not None else None   # (host clock per pair: enqueue start, time blocked)
         for k in range(n_pairs):
+            t_in = time.perf_counter() if trace is not None else 0.0
             while pending and pending[0] <= k - ring:    # this pair reuses that pair's record
                 collect(pending.pop(0) % ring)
             if pair_events is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
                 pair_events.append(ev)
+                trace.append((t_in, time.perf_counter() - t_in))
             last = k == n_pairs - 1
             r = self._ring[k % ring]
             for cur, nxt in ((0, 1), (1, 0)):
@@ -715,12 +772,14 @@ class PipelinedTrainStep(GraphedTrainStep):
         with torch.cuda.stream(side):
             loss = self._backward(self._forward(self.mfgs[0]))
         main.wait_stream(side)
+        if self._defer:
+            self.sampler.normalize_pending()
         main.synchronize()
         self.num_steps += 1
         return loss
 
     def _graph_attrs(self):
-        return ("graph", "g_main", "g_fwd", "g_bwd", "g_smp", "g_blk")
+        return ("graph", "g_main", "g_fwd", "g_bwd", "g_smp", "g_blk", "g_norm")
 
     def close(self):
         """Train the batch still in flight (``drain``), wait for every stream of the loop, then destroy the graphs."""
@@ -730,6 +789,8 @@ class PipelinedTrainStep(GraphedTrainStep):
             st.synchronize()
         super().close()
         self.mfgs = [None, None]
+        if self._defer:
+            self.sampler.defer_normalize = False
 
     def sizes2(self):
         """sizes() for each of the two batches sampled by the last call."""

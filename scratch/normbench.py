@@ -1,23 +1,29 @@
-"""Time bliss_exp3_normalize on a row that needs the pass (norm != 1) and on one that does not."""
-import sys, torch
-sys.path.insert(0, '.')
-from bliss_gnn_amd import _lib
-dev = torch.device('cuda:0')
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 113988362
-for off in (0, 1):                                     # aligned and misaligned row start
-    base = torch.full((n + 8,), 1.0 / n, dtype=torch.bfloat16, device=dev)
-    w = base[off:off + n]
-    rs = torch.zeros(96, dtype=torch.int64, device=dev); sc = torch.zeros(98, dtype=torch.int64, device=dev)
-    nrm = torch.zeros(1, dtype=torch.bfloat16, device=dev)
-    for rep in range(4):
-        w.mul_(1.3 if rep % 2 == 0 else 1.0)           # odd reps: already normalised -> skipped
-        _lib.check(_lib.lib.bliss_row_sum(w.data_ptr(), n, rs.data_ptr(), 0), "row_sum")
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        _lib.check(_lib.lib.bliss_exp3_normalize(w.data_ptr(), n, rs.data_ptr(), sc.data_ptr(), nrm.data_ptr(), 0), "normalize")
-        b.record(); torch.cuda.synchronize()
-        fresh = torch.zeros(96, dtype=torch.int64, device=dev)
-        _lib.check(_lib.lib.bliss_row_sum(w.data_ptr(), n, fresh.data_ptr(), 0), "row_sum")
-        tot = lambda r: sum(int(r[3 * s]) + (int(r[3 * s + 1]) << 32) + (int(r[3 * s + 2]) << 64) for s in range(32))
-        print("offset %d rep %d: %.1f us  norm before %.6f  sum after %.6f  incremental == fresh: %s" % (
-            off, rep, 1e3 * a.elapsed_time(b), float(nrm), w.float().sum().item(), tot(rs.cpu()) == tot(fresh.cpu())))
+"""Device time of F.normalize's pass over one Reddit-sized row (114 M bf16), alone on the chip.
+usage: normbench.py <lib.so>   (BLISS_NORM_WGS = workgroups per row)"""
+import ctypes as C, os, sys, torch
+lib = C.CDLL(os.path.abspath(sys.argv[1]))
+P, I64 = C.c_void_p, C.c_int64
+lib.bliss_exp3_normalize_global.argtypes = [P, I64, P, P, P, P, P]
+dev = torch.device("cuda:0")
+E = 113988365
+w = (torch.rand(E, device=dev) * 1e-8 + 4e-9).bfloat16()
+row_sum = torch.zeros(96, dtype=torch.int64, device=dev)
+scratch = torch.zeros(98, dtype=torch.int64, device=dev)
+out_norm = torch.zeros(1, dtype=torch.bfloat16, device=dev)
+def limbs_for(norm):
+    v = int(norm * 2.0 ** 64); l = torch.zeros(96, dtype=torch.int64)
+    l[0], l[1], l[2] = v & 0xffffffff, (v >> 32) & 0xffffffff, v >> 64
+    return l.to(dev)
+la, lb = limbs_for(1.0078125), limbs_for(0.99609375)
+st = torch.cuda.current_stream().cuda_stream
+def run(l):
+    assert lib.bliss_exp3_normalize_global(w.data_ptr(), E, row_sum.data_ptr(), l.data_ptr(), scratch.data_ptr(), out_norm.data_ptr(), st) == 0
+for _ in range(3): run(la); run(lb)
+torch.cuda.synchronize()
+evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+for i in range(20):
+    evs[i].record(); run(la if i % 2 == 0 else lb)
+evs[20].record(); torch.cuda.synchronize()
+ts = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(20))
+print("%s wgs=%s pass us: min %.1f median %.1f max %.1f  -> %.2f TB/s at the median (4 B per edge)" % (
+    os.path.basename(sys.argv[1]), os.environ.get("BLISS_NORM_WGS", "1024"), ts[0], ts[10], ts[-1], 4 * E / ts[10] / 1e6))

@@ -970,6 +970,102 @@ def test_pipelined_two_step_graph_matches_sequential(cuda):
             assert torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize("norm", [1.0078125, 0.99609375, 113988365.0, 2.0 ** -20, 3.0, 2.0 ** -60, 2.0 ** 59, 0.0, 1.0])
+def test_normalize_pass_all_bit_patterns(cuda, norm):
+    """F.normalize's pass over a row (bandit_sampler.py:249: x / max(norm, 1e-12), bf16) computes its quotients from a table
+    of 128 constants instead of dividing; against torch's own bf16 division on EVERY non-negative finite bf16 pattern (zero
+    and subnormals included), a few negative ones, rows that start off 16-byte alignment, and norms that push the quotients
+    out of the normal range either way (those fall back to the division)."""
+    bg = _bg()
+    lib, check = bg._lib.lib, bg._lib.check
+    pats = torch.arange(0, 0x7f80, dtype=torch.int32)
+    extra = torch.tensor([0x8000, 0xbf80, 0x8001, 0xc2f7, 0xff7f], dtype=torch.int32)
+    bits = torch.cat([pats, extra, pats.flip(0)]).to(torch.int16)
+    for off in (0, 1, 5):
+        buf = torch.zeros(bits.numel() + 8, dtype=torch.int16)
+        buf[off:off + bits.numel()] = bits
+        w = buf.view(torch.bfloat16).to(cuda)
+        row = w[off:off + bits.numel()]
+        nb = torch.tensor([norm], dtype=torch.float32).bfloat16()
+        # the norm as limbs of value * 2^64 (three 32-bit digits in int64, first replica of 32); only its bf16 rounding matters
+        v = int(float(nb) * 2.0 ** 64)
+        limbs = torch.zeros(96, dtype=torch.int64)
+        limbs[0], limbs[1], limbs[2] = v & 0xffffffff, (v >> 32) & 0xffffffff, v >> 64
+        limbs = limbs.to(cuda)
+        row_sum = torch.zeros(96, dtype=torch.int64, device=cuda)
+        scratch = torch.zeros(98, dtype=torch.int64, device=cuda)
+        out_norm = torch.zeros(1, dtype=torch.bfloat16, device=cuda)
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib.bliss_exp3_normalize_global(row.data_ptr(), row.numel(), row_sum.data_ptr(), limbs.data_ptr(), scratch.data_ptr(),
+                                              out_norm.data_ptr(), st), "bliss_exp3_normalize_global")
+        torch.cuda.synchronize()
+        assert out_norm.cpu().view(torch.int16).item() == nb.view(torch.int16).item()
+        x = bits.view(torch.bfloat16)
+        want = x if float(nb) == 1.0 else x / nb.clamp_min(1e-12)       # F.normalize: input / norm.clamp_min(eps), bf16 tensors
+        got = row.cpu()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (norm, off)
+        assert torch.equal(w.cpu().view(torch.int16)[:off], buf[:off]) and torch.equal(w.cpu().view(torch.int16)[off + bits.numel():],
+                                                                                        buf[off + bits.numel():])
+
+
+def test_deferred_normalize_matches_immediate(cuda, monkeypatch):
+    """F.normalize's pass over the bandit rows taken off the critical path (bliss_exp3_step_deferred: exp3() only decides,
+    the next sampler divides what it reads on the fly, bliss_exp3_normalize_pending rewrites the rows beside the next forward
+    pass) leaves the bits of the immediate pass: blocks sizes, losses, rows, parameters, generator -- over a stretch in
+    which the rows do need the pass on most steps (the bf16 quotients over- and undershoot 1.0 in turn)."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    from bliss_gnn_amd.train import BatchLoader, PipelinedTrainStep
+    bg = _bg()
+    ip, ix, ei = chung_lu_csc(6000, 150001, seed=21)
+    feats = torch.randn(6000, 48, generator=torch.Generator().manual_seed(2)).bfloat16()
+    labels = torch.randint(0, 5, (6000,), generator=torch.Generator().manual_seed(3))
+    fan, bs = [300, 200, 100], 64
+    ids = torch.arange(6000, dtype=torch.int32, device=cuda)
+    outs = []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("BLISS_NORM_DEFER", defer)
+        g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats.to(cuda), "labels": labels.to(cuda)})
+        g.edata["w"] = bg.normalized_edata(g)
+        sampler = bg.PoissonBanditLadiesSampler(fan, eta=0.1)
+        torch.manual_seed(0)
+        model = SAGE(48, 32, 5, 3, torch.relu, 0.0).to(cuda).bfloat16()
+        step = PipelinedTrainStep(g, sampler, model, bs)
+        loader = BatchLoader(ids, bs, seed=5).forever()
+        torch.manual_seed(9)
+        step.calibrate(loader, steps=3)
+        step.capture(loader, warmup=1)
+        assert step._defer == (defer == "1" and step.use_flags) and sampler.defer_normalize == step._defer
+        assert (step.g_norm is not None) == step._defer
+        sizes, losses, passes = [], [], 0
+        for it in range(6):
+            # push the rows off norm 1.0 (in place: the graphs hold their addresses) so that the passes keep coming
+            sampler._w_pos.mul_(1.006 if it % 2 == 0 else 0.9955)
+            for l in range(3):
+                bg._lib.check(bg._lib.lib.bliss_row_sum(sampler._w_pos[l].data_ptr(), g.num_edges(), sampler._row_sum[l].data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream), "bliss_row_sum")
+            la, lb = step(loader)                               # one pair per call: the rows are settled in between
+            losses += [float(la), float(lb)]
+            sizes += step.sizes2()
+            passes += int(((sampler._scratch[:, 0] >> 16) & 1).eq(0).sum())     # rows whose last norm was not 1.0
+            assert int(sampler._pend.abs().sum()) == 0          # nothing pending between calls
+        sizes += step.run(loader, 6)                            # and free-running
+        losses += [float(x) for x in step.losses]
+        losses.append(float(step.drain()))
+        sampler.check_errors()
+        outs.append(dict(w=sampler._w_pos.cpu().view(torch.int16).clone(), rs=sampler._row_sum.cpu().clone(), sizes=sizes, losses=losses,
+                         rng=torch.get_rng_state(), params=[p.detach().cpu().clone() for p in model.parameters()], passes=passes))
+        step.close()
+        assert sampler.defer_normalize is False
+    a, b = outs
+    assert a["passes"] == b["passes"] and a["passes"] >= 6, a["passes"]
+    assert a["sizes"] == b["sizes"] and a["losses"] == b["losses"]
+    assert torch.equal(a["w"], b["w"]) and torch.equal(a["rng"], b["rng"])
+    assert torch.equal(a["rs"].view(-1, 32, 3).sum(1), b["rs"].view(-1, 32, 3).sum(1))      # (replica placement may differ)
+    for pa, pb in zip(a["params"], b["params"]):
+        assert torch.equal(pa, pb)
+
+
 @pytest.mark.parametrize("V,n_edges,R,bounds", [(2000, 30001, 4, [20000, 9000]),
                                                 # lists longer than the grid cap (256 workgroups x 256 threads): every workgroup
                                                 # strides, the grid barrier runs with the full resident grid, 8 ranks
