@@ -78,7 +78,7 @@ class LayerEngine:
         # binned candidate pipeline (csrc/sampler.hip): LDS-resident per-source reductions when |V| / n_bins slots fit in
         # 64 KiB; otherwise (or with BLISS_BINS=0) the memory-side atomic passes.  Scratch shared by all layers.
         self.n_bins = 0
-        for nb in (256, 1024):
+        for nb in ((int(os.environ["BLISS_NBINS"]),) if os.environ.get("BLISS_NBINS") else (256, 1024)):
             if -(-V // nb) * 12 <= 64 * 1024:
                 self.n_bins = nb
                 break

@@ -25,7 +25,9 @@
 #include "prof.h"
 #include <cstdlib>
 
+#ifndef TPB
 #define TPB 256
+#endif
 #define ITEMS 4
 #define CHUNK (TPB * ITEMS)
 
@@ -364,7 +366,9 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
 // reference evaluates sum_j min(c p_j, 1) up to 50 times over all C candidates with a host sync each
 // (bandit_sampler.py:396-401); with counts per distinct p the same sum costs 32 bins per thread.
 #define HIST_BINS 32768
-#define FIN_TPB 512
+#ifndef FIN_TPB
+#define FIN_TPB 1024             // (512: step 0.790 ms, 1024: 0.772, 256: 0.828 -- same box, Reddit-like loop)
+#endif
 __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
                                                            unsigned long long* acc_p2, unsigned* first_pos,
                                                            bf16_t* __restrict__ p, int* hist, int cap_c, int uniform_nodes) {
@@ -372,7 +376,10 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
   const int S = cnt->S;
   const int C = min(cnt->C, cap_c);
   if ((int)blockIdx.x * FIN_TPB >= C) return;         // surplus workgroups: nothing to zero, nothing to flush
-  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) lh[b] = 0;
+  {                                                   // (16 bytes per LDS access: the 128 KiB are most of this kernel's work)
+    int4* lh4 = reinterpret_cast<int4*>(lh);
+    for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) lh4[b] = make_int4(0, 0, 0, 0);
+  }
   __syncthreads();
   int bad = 0;
   for (int id = blockIdx.x * FIN_TPB + threadIdx.x; id < C; id += gridDim.x * FIN_TPB) {
@@ -388,9 +395,17 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
     if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;   // sign bit set = negative / -0 cannot occur
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) {
-    int v = lh[b];
-    if (v) atomicAdd(hist + b, v);
+  {
+    const int4* lh4 = reinterpret_cast<const int4*>(lh);
+    for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) {
+      const int4 v = lh4[b];
+      if (v.x | v.y | v.z | v.w) {
+        if (v.x) atomicAdd(hist + 4 * b, v.x);
+        if (v.y) atomicAdd(hist + 4 * b + 1, v.y);
+        if (v.z) atomicAdd(hist + 4 * b + 2, v.z);
+        if (v.w) atomicAdd(hist + 4 * b + 3, v.w);
+      }
+    }
   }
   if (bad) atomicOr(&cnt->err, bad);
 }
@@ -411,11 +426,17 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 #define BIN_ITEMS 4
 #define BIN_BATCH (BIN_TPB * BIN_ITEMS)      // frontier positions per workgroup step: 4096 (16 waves keep the loads in flight)
 #define MAX_BINS 1024
-#define COL_TPB 512
+#ifndef COL_TPB
+#define COL_TPB 1024
+#endif
 #define COL_R 16
-#define COL_RB 32
+#ifndef COL_RB
+#define COL_RB 8
+#endif
 #define COL_BIG (COL_R * 64)              // a wave keeps a whole column of up to 1024 edges in registers
-#define BINRED_TPB 512
+#ifndef BINRED_TPB
+#define BINRED_TPB 1024          // one workgroup per bin, 256 bins: 16 waves per CU (512: 23.1 us per launch, 1024: 21.0, 256: 28.1)
+#endif
 
 template <int NT>
 __device__ __forceinline__ int block_max_u31(int v, long long* sh) {
@@ -456,7 +477,10 @@ __device__ __forceinline__ void col_store(int k, long long ws_fixed, long long q
 // 256-thread workgroup with the long ones taken by the same workgroup; the latter plus one fat workgroup per hub column --
 // and measured all of them SLOWER on the Reddit-like step (34 / 78 / 73 us per layer against 16 / 27 / 55 for this one,
 // profiles/r02_e and r02_f step timelines): every dependent global access costs microseconds here, and this shape has the
-// fewest per workgroup -- one column per wave, one long column per workgroup, all of them side by side.)
+// fewest per workgroup -- one column per wave, one long column per workgroup, all of them side by side.  What does help the
+// long columns is MORE threads each: 1024-thread workgroups holding 8 edges per thread in registers took the launch from
+// 47 to 34 us on average over the three layers (512 x 32: 47, 256 x 32: 56, 1024 x 16: 35, 1024 x 32: 43), the step from
+// 0.816 to 0.789 ms, same box.)
 __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict__ indptr, const bf16_t* __restrict__ w,
                                                       const int* __restrict__ seeds, const int* __restrict__ seg_ptr,
                                                       const long long* __restrict__ col_base, const int* __restrict__ span_seg,
@@ -733,7 +757,10 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
   if (C > cap_c) { C = cap_c; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, BLISS_ERR_CAP_CAND); }
   if (blockIdx.x == 0 && threadIdx.x == 0) cnt->C = C;
   if ((int)blockIdx.x * FIN_TPB >= C) return;
-  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) lh[b] = 0;
+  {                                                   // (16 bytes per LDS access: the 128 KiB are most of this kernel's work)
+    int4* lh4 = reinterpret_cast<int4*>(lh);
+    for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) lh4[b] = make_int4(0, 0, 0, 0);
+  }
   __syncthreads();
   int bad = 0;
   for (int i = blockIdx.x * FIN_TPB + threadIdx.x; i < C; i += gridDim.x * FIN_TPB) {
@@ -757,9 +784,17 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
     if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < HIST_BINS; b += FIN_TPB) {
-    int v = lh[b];
-    if (v) atomicAdd(hist + b, v);
+  {
+    const int4* lh4 = reinterpret_cast<const int4*>(lh);
+    for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) {
+      const int4 v = lh4[b];
+      if (v.x | v.y | v.z | v.w) {
+        if (v.x) atomicAdd(hist + 4 * b, v.x);
+        if (v.y) atomicAdd(hist + 4 * b + 1, v.y);
+        if (v.z) atomicAdd(hist + 4 * b + 2, v.z);
+        if (v.w) atomicAdd(hist + 4 * b + 3, v.w);
+      }
+    }
   }
   if (bad) atomicOr(&cnt->err, bad);
 }

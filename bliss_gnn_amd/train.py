@@ -319,12 +319,14 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.use_flags = os.environ.get("BLISS_PIPELINE_FLAGS", "1") != "0"
         self.losses = None
         self.last_counts2 = None
-        # F.normalize's pass over the bandit rows beside the next forward pass instead of in front of the next sampler
-        # (bandit_sampler.normalize_pending; flag mode only, switched on by capture()).  BLISS_NORM_DEFER=0: inside exp3(),
-        # as the reference orders it.  Replicas keep the immediate pass: their update lists are applied after an exchange,
-        # outside the fused exp3 step.
+        # BLISS_NORM_DEFER=1: F.normalize's pass over the bandit rows beside the next forward pass instead of in front of the
+        # next sampler (bandit_sampler.normalize_pending; flag mode only, switched on by capture()).  Off by default: same bits,
+        # but measured no faster on the Reddit-like loop once the pass itself took 85 us instead of 129 (0.820 / 0.824 against
+        # 0.823 / 0.836 ms per step, run-to-run noise +-0.008) -- beside the forward pass it still competes for HBM, and the
+        # hand-off adds two small kernels to every step.  Replicas always keep the immediate pass: their update lists are applied
+        # after an exchange, outside the fused exp3 step.
         self._defer_wanted = (not distributed and hasattr(sampler, "normalize_pending")
-                              and os.environ.get("BLISS_NORM_DEFER", "1") != "0")
+                              and os.environ.get("BLISS_NORM_DEFER", "0") != "0")
         self._defer = False
         self._norm_done = torch.cuda.Event()
         self.g_norm = None
