@@ -258,9 +258,16 @@ def main():
         # what F.normalize saw on every second step of 600 more: bf16 norm bits per layer (0x3f80 = 1.0 = pass skipped)
         rec = []
         for _ in range(300):
-            step.run(loader, 1)
-            rec.append([int(v) & 0x1ffff for v in sampler._scratch[:, 0].tolist()]
-                       + [float(w.float().sum(dtype=torch.float64)) for w in sampler._w_pos])
+            try:
+                step.run(loader, 1)
+            except RuntimeError as e:
+                rec.append(str(e)[:200])
+                break
+            finally:
+                rec.append([int(v) & 0xffffff for v in sampler._scratch[:, 0].tolist()]
+                           + [float(w.float().sum(dtype=torch.float64)) for w in sampler._w_pos]
+                           + [float(w.float().max()) for w in sampler._w_pos] + [float(w.float().min()) for w in sampler._w_pos]
+                           + sampler._row_sum.view(-1, 32, 3).sum(1).tolist())
         with open(os.environ["BLISS_BENCH_NORMS"], "w") as f:
             json.dump(rec, f)
     n_edges = sum(x["B"] for sz in all_sizes for x in sz)

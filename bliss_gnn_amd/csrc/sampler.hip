@@ -423,7 +423,9 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 //   k_cand_number  numbers the candidates, p_j = sqrt(sum), histogram for the Poisson scale
 // Integer sums and minima are order-free, so the results are bit-identical to the atomic passes.
 #define BIN_TPB 1024
+#ifndef BIN_ITEMS
 #define BIN_ITEMS 4
+#endif
 #define BIN_BATCH (BIN_TPB * BIN_ITEMS)      // frontier positions per workgroup step: 4096 (16 waves keep the loads in flight)
 #define MAX_BINS 1024
 #ifndef COL_TPB

@@ -12,7 +12,10 @@ cp $O/prof/*/*_kernel_stats.csv $O/kernel_stats_pipelined.csv
 echo "[3] pmc fetch"; timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 bench.py --steps 10 --warmup 4 --no-roofline --cpu-baseline-steps 0 --tune-gemm 0 > $O/pmc_f.log 2>&1 || exit 1
 echo "[4] pmc write"; timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 bench.py --steps 10 --warmup 4 --no-roofline --cpu-baseline-steps 0 --tune-gemm 0 > $O/pmc_w.log 2>&1 || exit 1
 python scratch/pmc_traffic.py $O/pmc_f $O/pmc_w $O/pmc_traffic.json > $O/pmc_summary.txt
-echo "[5] other configs"; for c in yelp pubmed cora; do timeout -k 10 200 python bench.py --config $c --steps 200 --warmup 20 --cpu-baseline-steps 0 --no-roofline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c', round(o['value'],1), 'steps/s', round(o['ms_per_step'],4), 'ms/step', o['step_ms_percentiles'])" >> $O/other_configs.txt; done
+# (cora / pubmed: 40 + 20 steps only.  With N(0,1) synthetic features and in-degrees of ~5 the capped bandit factor e^1 is hit on
+# every step; after ~125 steps the smallest weights of a row have left bf16's range (1e-38), a column sums to zero and the
+# sampler raises its non-finite error -- the arithmetic the reference prescribes, on data it was never meant for.)
+echo "[5] other configs"; for c in yelp pubmed cora; do if [ $c = yelp ]; then N=200; else N=40; fi; timeout -k 10 200 python bench.py --config $c --steps $N --warmup 20 --cpu-baseline-steps 0 --no-roofline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c', round(o['value'],1), 'steps/s', round(o['ms_per_step'],4), 'ms/step', o['step_ms_percentiles'])" >> $O/other_configs.txt; done
 timeout -k 10 300 python bench.py --model gat --steps 100 --warmup 20 --cpu-baseline-steps 0 --no-roofline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('reddit-gat', round(o['value'],1), 'steps/s', round(o['ms_per_step'],4), 'ms/step', o['step_ms_percentiles'])" >> $O/other_configs.txt
 rm -rf $O/prof $O/pmc_f $O/pmc_w
 ls -la $O; cat $O/other_configs.txt
