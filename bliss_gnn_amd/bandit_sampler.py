@@ -105,34 +105,67 @@ class BanditLadiesSampler(BlockSampler):
             self._scratch = torch.zeros(L, 98, dtype=torch.int64, device=g.device)
             self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
             self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
-            self._pend = torch.zeros(L, dtype=torch.int32, device=g.device)
+            self._pend = torch.zeros(L, 4, dtype=torch.int32, device=g.device)     # bliss_norm_state_t per row
 
     # -- F.normalize off the critical path ----------------------------------------------------
     # bandit_sampler.py:249 renormalises every row after every update.  Here the pass over a row (4 bytes of HBM traffic per
     # edge of the GRAPH) only runs when the row's bf16 norm is not exactly 1.0 -- which still happens in stretches of hundreds
     # of steps (the bf16 quotients over- and undershoot: norm 1.0078, 0.9961, 1.0078 ... until the drift of the sum ends the
     # cycle), and the next batch's sampler waits for exp3().  With ``defer_normalize`` set (train.PipelinedTrainStep does)
-    # exp3() only decides which rows need the pass; sample_blocks_static divides what it reads on the fly, and
-    # ``normalize_pending`` rewrites the rows -- beside the next forward pass.  Same bits as the immediate pass.
+    # exp3() only decides which rows need the pass; ``normalize_pending`` runs it OUT OF PLACE into a second buffer per row
+    # (beside the next sampler, which reads the old buffer and divides on the fly until the pass has switched the row over).
+    # Same bits as the immediate pass.  Everything outside this protocol sees ``_w_pos`` only: ``_settle`` brings the rows home.
     defer_normalize = False
-    _pend_maybe = False
+    _pend_maybe = False            # host-side hints (conservative): a pass may be pending / a row may live in _w_alt
+    _alt_maybe = False
+    _w_alt = None
 
-    def normalize_pending(self, g=None):
-        """Rewrite the rows a deferred exp3() left pending (one launch; a no-op on the device when there are none)."""
-        if self._w_pos is None or getattr(self, "_pend", None) is None:
+    def enable_deferred_normalize(self, on=True):
+        if not on:
+            self._settle()
+            self.defer_normalize = False
             return
+        if self._w_pos is None:
+            raise RuntimeError("enable_deferred_normalize: the sampler has no weights yet (sample once first)")
+        if self._w_alt is None or self._w_alt.shape != self._w_pos.shape:
+            self._w_alt = torch.empty_like(self._w_pos)
+            d = self._w_alt.data_ptr() - self._w_pos.data_ptr()
+            if d % 16:
+                raise RuntimeError("allocator returned a buffer off the 16-byte phase of the rows")
+            st = torch.zeros(self._w_pos.shape[0], 2, dtype=torch.int64)
+            st[:, 1] = d // 2                                          # bliss_norm_state_t::alt, in elements
+            self._pend.copy_(st.view(torch.int32).to(self._pend.device))
+        self.defer_normalize = True
+
+    def _norm_rows(self):
         L = self._w_pos.shape[0]
         rows = (_lib.Exp3Block * L)()
         for idx in range(L):
             rows[idx].w_pos, rows[idx].row_sum = self._w_pos[idx].data_ptr(), self._row_sum[idx].data_ptr()
             rows[idx].scratch, rows[idx].norm_pend = self._scratch[idx].data_ptr(), self._pend[idx:].data_ptr()
+        return rows, L
+
+    def normalize_pending(self, g=None):
+        """Run the pass over the rows a deferred exp3() left pending (two launches; nothing happens on the device when there
+        are none).  Must not overlap the next update."""
+        if self._w_pos is None or self._w_alt is None:
+            return
+        rows, L = self._norm_rows()
         _lib.check(_lib.lib.bliss_exp3_normalize_pending(rows, L, self._w_pos.shape[1], _stream()), "bliss_exp3_normalize_pending")
-        self._pend_maybe = False
+        self._pend_maybe, self._alt_maybe = False, True
 
     def _settle(self):
-        # anything that reads or writes the rows outside the deferred protocol sees them rewritten
+        """Leave the deferred protocol's state behind: no pass pending, every row in ``_w_pos`` (one host read of the state
+        words when a row may have moved; off the hot path)."""
         if self._pend_maybe:
             self.normalize_pending()
+        if self._alt_maybe:
+            st = self._pend[:, 0].tolist()
+            for idx, v in enumerate(st):
+                if v & 0x20000:
+                    self._w_pos[idx].copy_(self._w_alt[idx])
+                    self._pend[idx, 0] = v & ~0x20000
+            self._alt_maybe = False
 
     @property
     def exp3_weights(self):
@@ -154,8 +187,10 @@ class BanditLadiesSampler(BlockSampler):
         self._scratch = torch.zeros(L, 98, dtype=torch.int64, device=g.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=g.device)
         self._norms = torch.zeros(L, dtype=torch.bfloat16, device=g.device)
-        self._pend = torch.zeros(L, dtype=torch.int32, device=g.device)
-        self._pend_maybe = False
+        self._pend = torch.zeros(L, 4, dtype=torch.int32, device=g.device)
+        self._pend_maybe = self._alt_maybe = False
+        self._w_alt = None
+        self.defer_normalize = False
         for l in range(L):
             _lib.check(_lib.lib.bliss_row_sum(self._w_pos[l].data_ptr(), g.num_edges(), self._row_sum[l].data_ptr(),
                                               _stream()), "bliss_row_sum")
@@ -211,7 +246,7 @@ class BanditLadiesSampler(BlockSampler):
         return self._engine.finish(slot, commit)
 
     # -- bandit update ----------------------------------------------------------------------
-    def exp3(self, mfgs, g, apply=True, factors=None, bounds=None):
+    def exp3(self, mfgs, g, apply=True, factors=None, bounds=None, done_flag=None):
         """bandit_sampler.py:251-267: rewards + weight update + L1 renormalisation, per block.
 
         ``apply=False`` (multi-GPU replicas, bliss_gnn_amd/dist.py) only computes the rewards and, into
@@ -225,7 +260,11 @@ class BanditLadiesSampler(BlockSampler):
         cg = self._engine.c_graph
         fused = apply and factors is None and len(mfgs) <= 8         # all blocks in two launches (bliss_exp3_step)
         defer = fused and self.defer_normalize
-        self._settle()                                               # (a caller that overlaps the pass has launched it already)
+        if defer:
+            if self._pend_maybe:                                     # (a caller that overlaps the pass has launched it already)
+                self.normalize_pending()
+        else:
+            self._settle()
         keep = []                                                    # (tensors the launch reads must outlive the loop)
         recs = (_lib.Exp3Block * len(mfgs))() if fused else None
         for idx, mfg in enumerate(mfgs):
@@ -266,9 +305,13 @@ class BanditLadiesSampler(BlockSampler):
                                                      self._row_sum[idx].data_ptr(), self._scratch[idx].data_ptr(),
                                                      self._norms[idx:].data_ptr(), st), "bliss_exp3_normalize")
         if fused and len(mfgs):
-            fn = _lib.lib.bliss_exp3_step_deferred if defer else _lib.lib.bliss_exp3_step
-            _lib.check(fn(C.byref(cg), edge_w_pos.data_ptr(), recs, len(mfgs), self._delta_f, self._err.data_ptr(), st), "bliss_exp3_step")
-            self._pend_maybe = self._pend_maybe or defer
+            if defer:
+                _lib.check(_lib.lib.bliss_exp3_step_deferred(C.byref(cg), edge_w_pos.data_ptr(), recs, len(mfgs), self._delta_f,
+                                                             int(done_flag or 0), self._err.data_ptr(), st), "bliss_exp3_step_deferred")
+                self._pend_maybe = True
+            else:
+                _lib.check(_lib.lib.bliss_exp3_step(C.byref(cg), edge_w_pos.data_ptr(), recs, len(mfgs), self._delta_f,
+                                                    self._err.data_ptr(), st), "bliss_exp3_step")
 
     def apply_updates(self, idx, pos, factor, g, n_dev=None):
         """w[pos] *= factor on layer ``idx`` (positions unique within one call), bandit_sampler.py:248.  ``n_dev``: optional

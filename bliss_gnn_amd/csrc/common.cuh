@@ -48,6 +48,18 @@ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // rou
 // F.normalize(row, p=1) element by element (bandit_sampler.py:249): x / max(norm, eps), rounded to bf16.  ONE definition
 // for the pass that rewrites a row (exp3.hip) and for the readers that apply a pending pass on the fly (sampler.hip:
 // BLISS_NORM_DEFER), so both produce the same bits.  pend = 0x10000 | bf16 bits of the norm, 0 = nothing pending.
+// The state word of a row (bliss_norm_state_t in bliss_gnn.h): bits 0-15 norm, bit 16 "a pass is pending", bit 17 "the row's
+// current values live in the ALTERNATE buffer" (the pending pass is out of place: it reads the current buffer, writes the other
+// one and flips bit 17 when it is done, so it may run beside readers); 8 bytes on: the alternate buffer's distance in elements.
+#define NORM_PEND_MASK 0x1ffff
+#define NORM_CUR_ALT 0x20000
+template <typename T>
+__device__ __forceinline__ T* norm_state_row(T* w, const int* state_ptr, int* pend_out) {
+  if (!state_ptr) { *pend_out = 0; return w; }
+  const int st = __hip_atomic_load(state_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *pend_out = st & NORM_PEND_MASK;
+  return (st & NORM_CUR_ALT) ? w + *reinterpret_cast<const long long*>(state_ptr + 2) : w;
+}
 __device__ __forceinline__ float renorm_denom(int pend) { return rbf(fmaxf(bf2f((bf16_t)(pend & 0xffff)), 1e-12f)); }
 __device__ __forceinline__ bf16_t renorm_bf16(bf16_t x, float denom) { return f2bf(bf2f(x) / denom); }
 __device__ __forceinline__ bf16_t renorm_pending(bf16_t x, int pend, float denom) { return pend ? renorm_bf16(x, denom) : x; }

@@ -164,13 +164,16 @@ struct Exp3Multi {
   bliss_exp3_block_t blk[BLISS_EXP3_MAX_BLOCKS];
   int grid_begin[BLISS_EXP3_MAX_BLOCKS + 1];
   int n;
+  int* done_flag;          // NORM_DECIDE: raised (bliss_flag_wait's protocol) once every row has been decided, or null
 };
 __global__ void __launch_bounds__(E3_TPB) k_exp3_update_multi(const int64_t* __restrict__ g_indptr, const bf16_t* __restrict__ edge_w,
                                                              const Exp3Multi m, float delta_f, int* err) {
   int b = 0;
   while (b + 1 < m.n && (int)blockIdx.x >= m.grid_begin[b + 1]) ++b;
   const bliss_exp3_block_t& k = m.blk[b];
-  exp3_update_body(g_indptr, edge_w, (bf16_t*)k.w_pos, k.row_sum, k.blk_indptr, k.blk_src, k.blk_dst, k.blk_pos, (const bf16_t*)k.q_ij,
+  int pend_unused;
+  bf16_t* w_row = norm_state_row((bf16_t*)k.w_pos, k.norm_pend, &pend_unused);        // (a pending pass has completed by now)
+  exp3_update_body(g_indptr, edge_w, w_row, k.row_sum, k.blk_indptr, k.blk_src, k.blk_dst, k.blk_pos, (const bf16_t*)k.q_ij,
                    (const bf16_t*)k.node_prob, (const bf16_t*)k.embed_norm, (const bf16_t*)k.alpha_or_null, k.dst_nid, k.n_edges_dev,
                    delta_f, (bf16_t*)k.rewards_out, nullptr, 1, err, (int)blockIdx.x - m.grid_begin[b], m.grid_begin[b + 1] - m.grid_begin[b],
                    k.edges_bound);
@@ -336,11 +339,12 @@ __device__ __attribute__((noinline)) PairSlow renorm_pair_slow(uint32_t word, fl
 enum { NORM_NOW = 0, NORM_DECIDE = 1, NORM_APPLY = 2 };
 __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t* row_sum, int64_t* scratch, bf16_t* norm_out, int wg, int nwg,
                                                    const int64_t* norm_src = nullptr, int mode = NORM_NOW, int* pend = nullptr) {
-  __shared__ int sh_norm, sh_last;
+  __shared__ int sh_norm, sh_last, sh_state;
   if (threadIdx.x == 0) {
     if (mode == NORM_APPLY) {
       const int pd = __hip_atomic_load(pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sh_norm = pd ? (pd & 0xffff) : 0x3f80;       // nothing pending: leave like a row whose norm is 1.0
+      sh_state = pd;
+      sh_norm = (pd & 0x10000) ? (pd & 0xffff) : 0x3f80;       // nothing pending: leave like a row whose norm is 1.0
     } else {
       int bad = 0;
       const bf16_t nb = limbs_to_bf16(norm_src ? norm_src : row_sum, &bad);
@@ -348,13 +352,23 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
       if (wg == 0) {
         scratch[0] = (int64_t)nb | ((int64_t)(nb == 0x3f80) << 16) | ((int64_t)bad << 20);
         if (norm_out) *norm_out = nb;
-        if (mode == NORM_DECIDE) *pend = (nb == 0x3f80) ? 0 : (0x10000 | (int)nb);
+        if (mode == NORM_DECIDE) {                             // (which buffer is current stays as it is)
+          const int cur = __hip_atomic_load(pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & NORM_CUR_ALT;
+          __hip_atomic_store(pend, cur | ((nb == 0x3f80) ? 0 : (0x10000 | (int)nb)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
   __syncthreads();
   const bf16_t nb = (bf16_t)(sh_norm & 0xffff);
   if (nb == 0x3f80 || mode == NORM_DECIDE) return;   // x / 1.0 == x : the row is already normalised, bit for bit
+  // NORM_APPLY works out of place: from the row's current buffer into the other one (the readers of the current one are
+  // not disturbed; they divide on the fly), and the last workgroup makes the other one current
+  const bf16_t* src = w;
+  if (mode == NORM_APPLY) {
+    const long long alt = *reinterpret_cast<const long long*>(pend + 2);
+    if (sh_state & NORM_CUR_ALT) src = w + alt; else w = w + alt;          // w = destination from here on
+  }
   const float denom = renorm_denom((int)nb);       // F.normalize: norm.clamp_min(eps)
   int bad = 0;
   int64_t dg[3] = {0, 0, 0};
@@ -399,16 +413,17 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
   const int64_t head = min(n, (int64_t)(((16 - ((uintptr_t)w & 15)) & 15) >> 1));
   const int64_t nvec = (n - head) / 8;
   const int64_t gtid = (int64_t)wg * E3_TPB + threadIdx.x, gsz = (int64_t)nwg * E3_TPB;
-  if (gtid < head) w[gtid] = one(w[gtid]);
-  for (int64_t i = head + nvec * 8 + gtid; i < n; i += gsz) w[i] = one(w[i]);
+  if (gtid < head) w[gtid] = one(src[gtid]);
+  for (int64_t i = head + nvec * 8 + gtid; i < n; i += gsz) w[i] = one(src[i]);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4* wv = reinterpret_cast<u32x4*>(w + head);
+  const u32x4* sv = reinterpret_cast<const u32x4*>(src + head);        // (both buffers share the 16-byte phase: alt % 8 == 0)
 #pragma unroll NORM_UNROLL
   for (int64_t i = gtid; i < nvec; i += gsz) {
 #if NORM_NT
-    u32x4 x = __builtin_nontemporal_load(wv + i);
+    u32x4 x = __builtin_nontemporal_load(sv + i);
 #else
-    u32x4 x = wv[i];
+    u32x4 x = sv[i];
 #endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -433,7 +448,7 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
         dg[0] += r.d0; dg[1] += r.d1; dg[2] += r.d2;
       }
     }
-#if NORM_NT
+#if NORM_NT == 1
     __builtin_nontemporal_store(x, wv + i);
 #else
     wv[i] = x;
@@ -464,7 +479,8 @@ __device__ __forceinline__ void normalize_row_body(bf16_t* w, int64_t n, int64_t
     }
     if (threadIdx.x == 0) {
       __hip_atomic_store((unsigned long long*)(scratch + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (mode == NORM_APPLY) __hip_atomic_store(pend, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (NORM_APPLY: the state word is flipped by k_norm_flip, a launch of its own behind this one -- the other workgroups'
+      // stores are only guaranteed to have left their XCD's L2 when this kernel has ended)
     }
   }
 }
@@ -479,6 +495,24 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_rows(const Exp3Multi m, in
   const bliss_exp3_block_t& k = m.blk[r];
   normalize_row_body((bf16_t*)k.w_pos, n, k.row_sum, k.scratch, (bf16_t*)k.norm_out, (int)blockIdx.x - r * per_row, per_row, nullptr, mode,
                      k.norm_pend);
+  if (mode == NORM_DECIDE && m.done_flag && threadIdx.x == 0) {
+    // one workgroup per row here; the last one to have stored its row's state word tells the stream that runs the pass
+    // (row 0's pass ticket is idle during a decide launch and doubles as this one)
+    unsigned long long* ticket = (unsigned long long*)(m.blk[0].scratch + 1);
+    if (atomicAdd(ticket, 1ull) == (unsigned long long)m.n - 1) {
+      __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(m.done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// after a NORM_APPLY launch: the rows that had a pass pending now live in their other buffer, nothing pending
+__global__ void k_norm_flip(const Exp3Multi m) {
+  const int r = threadIdx.x;
+  if (r >= m.n) return;
+  int* st = m.blk[r].norm_pend;
+  const int v = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v & 0x10000) __hip_atomic_store(st, (v & NORM_CUR_ALT) ^ NORM_CUR_ALT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // w_pos[p] = bf16(1 / bf16(indeg(dst(p))))          bandit_sampler.py:20-27
@@ -524,10 +558,11 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
 }
 
 static int exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
-                     float delta_f, int32_t* err, void* stream, bool defer) {
+                     float delta_f, int32_t* err, void* stream, bool defer, int32_t* done_flag) {
   if (!g || !blocks || n_blocks <= 0 || n_blocks > BLISS_EXP3_MAX_BLOCKS || !err) return BLISS_EINVAL;
   Exp3Multi m;
   m.n = n_blocks;
+  m.done_flag = done_flag;
   int total = 0;
   for (int i = 0; i < n_blocks; ++i) {
     const bliss_exp3_block_t& k = blocks[i];
@@ -556,18 +591,19 @@ static int exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss
 
 int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
                     float delta_f, int32_t* err, void* stream) {
-  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, false);
+  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, false, nullptr);
 }
 
 int bliss_exp3_step_deferred(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
-                             float delta_f, int32_t* err, void* stream) {
-  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, true);
+                             float delta_f, int32_t* done_flag, int32_t* err, void* stream) {
+  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, true, done_flag);
 }
 
 int bliss_exp3_normalize_pending(const bliss_exp3_block_t* rows, int32_t n_rows, int64_t num_edges, void* stream) {
   if (!rows || n_rows <= 0 || n_rows > BLISS_EXP3_MAX_BLOCKS || num_edges < 0) return BLISS_EINVAL;
   Exp3Multi m;
   m.n = n_rows;
+  m.done_flag = nullptr;
   for (int i = 0; i < n_rows; ++i) {
     if (!rows[i].w_pos || !rows[i].row_sum || !rows[i].scratch || !rows[i].norm_pend) return BLISS_EINVAL;
     m.blk[i] = rows[i];
@@ -578,6 +614,7 @@ int bliss_exp3_normalize_pending(const bliss_exp3_block_t* rows, int32_t n_rows,
   if (per_row < 1) per_row = 1;
   hipStream_t st = (hipStream_t)stream;
   PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows<<<(int)(per_row * n_rows), E3_TPB, 0, st>>>(m, num_edges, (int)per_row, NORM_APPLY));
+  k_norm_flip<<<1, 64, 0, st>>>(m);
   return (int)hipGetLastError();
 }
 

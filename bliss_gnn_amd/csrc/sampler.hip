@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restric
     const int* __restrict__ span_seg, LayerCounts* cnt,
                                                         const int* __restrict__ local_id, unsigned* first_pos,
                                                         unsigned long long* acc_w, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   const int S = cnt->S, E = cnt->E;
   const int nspans = (E + SPAN - 1) / SPAN;
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass1(const int64_t* __restric
           if (__hip_atomic_load(first_pos + a.src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)e)
             atomicMin(first_pos + a.src, (unsigned)e);
         }
-        if (BANDIT) term = bf_to_fixed(renorm_pending(w[a.pos], pend, pdenom), FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
+        if (BANDIT) term = bf_to_fixed(renorm_pending(wq[a.pos], pend, pdenom), FRAC_DST, &bad);   // :129 copy_e_sum over exp3 weights
       }
       if (BANDIT) wave_segsum_atomic_i64(a.k, term, acc_w);
     }
@@ -239,7 +240,8 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restric
                                                         const unsigned long long* __restrict__ acc_w,
                                                         unsigned long long* acc_q, int* __restrict__ chunk_cnt,
                                                         float eta_f, float ome_f, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass2(const int64_t* __restric
         first = first_pos[a.src] == (unsigned)e;
         if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(renorm_pending(w[a.pos], pend, pdenom), wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
+          bf16_t q = edge_q(renorm_pending(wq[a.pos], pend, pdenom), wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           term = bf_to_fixed(q, FRAC_DST, &bad);       // :67 copy_e_sum(insg, edge_prob)
         }
       }
@@ -307,7 +309,8 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
                                                         const int* __restrict__ chunk_off, int* local_id,
                                                         int* __restrict__ cand_nid, unsigned long long* acc_p2,
                                                         float eta_f, float ome_f, int cap_c, int uniform_nodes, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   const int S = cnt->S, E = cnt->E;
@@ -333,12 +336,12 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
           acc_p2[a.src] = 1ull;
         } else if (BANDIT) {
           bf16_t wsum = fixed_to_bf((int64_t)acc_w[a.k], FRAC_DST, &bad);
-          bf16_t q = edge_q(renorm_pending(w[a.pos], pend, pdenom), wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
+          bf16_t q = edge_q(renorm_pending(wq[a.pos], pend, pdenom), wsum, seg_ptr[a.k + 1] - seg_ptr[a.k], eta_f, ome_f);
           bf16_t qsum = fixed_to_bf((int64_t)acc_q[a.k], FRAC_DST, &bad);
           float r = rbf(bf2f(q) / bf2f(qsum));          // :71 e_div_u on the reversed frontier
           t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
         } else {
-          float x = bf2f(renorm_pending(w[a.pos], pend, pdenom));                     // ladies_sampler.py:46-47  weight ** 2
+          float x = bf2f(renorm_pending(wq[a.pos], pend, pdenom));                     // ladies_sampler.py:46-47  weight ** 2
           t = f2bf(x * x);
         }
         int64_t fx = uniform_nodes ? 0 : bf_to_fixed(t, FRAC_SRC, &bad);
@@ -431,7 +434,9 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 #ifndef COL_TPB
 #define COL_TPB 1024
 #endif
+#ifndef COL_R
 #define COL_R 16
+#endif
 #ifndef COL_RB
 #define COL_RB 8
 #endif
@@ -489,7 +494,8 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
                                                       LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
                                                       unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
                                                       uint2* __restrict__ seed_coef, int n_wave_wgs, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ long long sh[COL_TPB / 64];
   const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int r = 0; r < COL_R; ++r) {
       const int i = lane + r * 64;
       wr[r] = 0;
-      if (i < n) wr[r] = w[p0 + i];
+      if (i < n) wr[r] = wq[p0 + i];
     }
     if (pend) {                                       // (uniform; after ALL the loads have been issued)
 #pragma unroll
@@ -549,7 +555,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int r = 0; r < COL_RB; ++r) {
       const int i = tid + r * COL_TPB;
       wr[r] = 0;
-      if (i < n) wr[r] = w[p0 + i];
+      if (i < n) wr[r] = wq[p0 + i];
     }
     if (pend) {
 #pragma unroll
@@ -559,13 +565,13 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int r = 0; r < COL_RB; ++r)
       if (tid + r * COL_TPB < n) emax = max(emax, bf_exp_field(wr[r]));
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(renorm_pending(w[p0 + i], pend, pdenom)));
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(renorm_pending(wq[p0 + i], pend, pdenom)));
     const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL_TPB>(emax, sh));
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r)
       if (tid + r * COL_TPB < n) part += bf_to_fixed(wr[r], wfrac, &bad);
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(renorm_pending(w[p0 + i], pend, pdenom), wfrac, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(renorm_pending(wq[p0 + i], pend, pdenom), wfrac, &bad);
     const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
     const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
     const float a = rbf((1.0f / (float)n) * eta_f);
@@ -576,7 +582,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
       if (i < n) part += bf_to_fixed(edge_q_pre(wr[r], wsum, a, ome_f), FRAC_DST, &bad);
     }
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(renorm_pending(w[p0 + i], pend, pdenom), wsum, a, ome_f), FRAC_DST, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(edge_q_pre(renorm_pending(wq[p0 + i], pend, pdenom), wsum, a, ome_f), FRAC_DST, &bad);
     const long long qs_fixed = block_sum_i64<COL_TPB>(part, sh);
     if (tid == 0) col_store(k, ws_fixed, qs_fixed, wsum, n, eta_f, acc_w, acc_q, seed_coef, &bad);
   }
@@ -593,7 +599,8 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
                                                      int uniform_nodes, int n_bins, int log2_bins, long long bin_cap, int* bin_cursor,
                                                      unsigned long long* __restrict__ bin_rec, unsigned* __restrict__ bitmap,
                                                      const uint2* __restrict__ seed_coef, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int hist[MAX_BINS];
   __shared__ int gbase[MAX_BINS];
@@ -621,11 +628,11 @@ __global__ void __launch_bounds__(BIN_TPB) k_bin_scatter(const int64_t* __restri
           t = (bf16_t)0x3f80;                           // importance_sampling=False (:77-81): only "has an out-edge" matters
         } else if (BANDIT) {
           const uint2 cf = seed_coef[a.k];              // per-seed: bf16 sum_j w_ij | bf16 sum_k q_ik, eta / n_i
-          bf16_t q = edge_q_pre(renorm_pending(w[a.pos], pend, pdenom), (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f);
+          bf16_t q = edge_q_pre(renorm_pending(wq[a.pos], pend, pdenom), (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f);
           float r = rbf(bf2f(q) / bf2f((bf16_t)(cf.x >> 16)));   // :71 e_div_u on the reversed frontier
           t = f2bf(r * r);                              // :73 edge_prob_div_sum ** 2
         } else {
-          float x = bf2f(renorm_pending(w[a.pos], pend, pdenom));                     // ladies_sampler.py:46-47  weight ** 2
+          float x = bf2f(renorm_pending(wq[a.pos], pend, pdenom));                     // ladies_sampler.py:46-47  weight ** 2
           t = f2bf(x * x);
         }
         srcs[j] = a.src; ts[j] = t;
@@ -1067,7 +1074,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
                                                      const int* __restrict__ kept_map, const bf16_t* __restrict__ node_prob,
                                                      const uint2* __restrict__ seed_coef, KeptRec* __restrict__ kept_rec,
                                                      int* __restrict__ span_cnt, long long kept_rec_positions, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
@@ -1093,7 +1101,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass1(const int64_t* __restrict__
         if (src_cnt) atomicAdd(src_cnt + r.nid, 1);     // out-degree inside the block: sizes the by-source index
         if (BANDIT) {
           bf16_t q;
-          const bf16_t wv = renorm_pending(w[r.pos], pend, pdenom);
+          const bf16_t wv = renorm_pending(wq[r.pos], pend, pdenom);
           if (seed_coef) { const uint2 cf = seed_coef[r.k]; q = edge_q_pre(wv, (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
           else q = edge_q(wv, fixed_to_bf((int64_t)acc_w[r.k], FRAC_DST, &bad), seg_ptr[r.k + 1] - seg_ptr[r.k], eta_f, ome_f);
           bf16_t wt = f2bf(bf2f(q) / bf2f(kept_map ? node_prob[r.nid] : P[r.lid]));    // :314 e_div_u(sg, W, P)
@@ -1173,7 +1181,8 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
                                                      const bf16_t* __restrict__ node_prob, const uint2* __restrict__ seed_coef,
                                                      const KeptRec* __restrict__ kept_rec, const int* __restrict__ span_cnt,
                                                      long long kept_rec_positions, const int* __restrict__ w_pend) {
-  const int pend = w_pend ? *w_pend : 0;                    // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
+  const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ int sh4[TPB / 64];
   __shared__ KeptRec sh_kept[TPB / 64][SPAN];
@@ -1198,7 +1207,7 @@ __global__ void __launch_bounds__(TPB) k_block_pass2(const int64_t* __restrict__
       const KeptRec r = list[j];
       const int k = r.k;
       bf16_t q;
-      const bf16_t wv = renorm_pending(w[r.pos], pend, pdenom);
+      const bf16_t wv = renorm_pending(wq[r.pos], pend, pdenom);
       if (BANDIT) {
         if (seed_coef) { const uint2 cf = seed_coef[k]; q = edge_q_pre(wv, (bf16_t)(cf.x & 0xffffu), __uint_as_float(cf.y), ome_f); }
         else q = edge_q(wv, fixed_to_bf((int64_t)acc_w[k], FRAC_DST, &bad), seg_ptr[k + 1] - seg_ptr[k], eta_f, ome_f);

@@ -328,7 +328,6 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._defer_wanted = (not distributed and hasattr(sampler, "normalize_pending")
                               and os.environ.get("BLISS_NORM_DEFER", "0") != "0")
         self._defer = False
-        self._norm_done = torch.cuda.Event()
         self.g_norm = None
 
     def _sample(self, slot, chain, external_rng=False, part=None):
@@ -340,7 +339,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         return (hasattr(self.model, "forward_hidden") and len(getattr(self.model, "layers", ())) > 1 and hasattr(self.sampler, "exp3")
                 and os.environ.get("BLISS_SPLIT_FORWARD", "1") != "0")
 
-    FLAG_SAMPLED, FLAG_NORM_DONE = 12, 13         # engine.flags slots (0..L-1: the sampler's layers; 14: the probe)
+    FLAG_X_DONE = 12                              # engine.flags slots (0..L-1: the sampler's layers; 14: the probe)
 
     def _forward(self, mfgs, flagged=False):
         """The part of the step the NEXT batch's sampler waits for: the forward pass up to the output layer's input (every
@@ -349,16 +348,19 @@ class PipelinedTrainStep(GraphedTrainStep):
         if self._defer and not flagged:                            # eager: the rows the previous update left pending, inline
             self.sampler.normalize_pending()
         pending = self._forward_model(mfgs)
-        if self._defer and flagged:                                # the pass runs on the third stream (g_norm): X waits for it
-            eng = self.sampler._engine
-            _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_NORM_DONE, eng.flag_err.data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream), "bliss_flag_wait")
-            self.sampler._pend_maybe = False                       # (exp3() need not launch the pass itself)
+        done_flag = None
+        if self._defer and flagged:
+            # the pass of the PREVIOUS update ran on the third stream (g_norm) and is complete: this graph only starts after
+            # that stream's event.  This update tells g_norm when the rows are ready for the next pass.
+            self.sampler._pend_maybe = False
+            done_flag = self.sampler._engine.flags.data_ptr() + 4 * self.FLAG_X_DONE
         if not hasattr(self.sampler, "exp3"):                      # LADIES samplers keep no bandit state
             return pending
         if self.distributed:
             from . import dist as bdist
             bdist.exp3_all_ranks_static(self.sampler, mfgs, self.g)
+        elif done_flag is not None:
+            self.sampler.exp3(mfgs, self.g, done_flag=done_flag)
         else:
             self.sampler.exp3(mfgs, self.g)
         return pending
@@ -413,9 +415,11 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.sampler.finish_static(0, commit=True)
 
     def _finish_pair(self, check_flags=True):
-        if self._defer:                                  # whoever looks at the rows between two calls sees them rewritten
-            self.sampler.normalize_pending()
         torch.cuda.current_stream().synchronize()
+        if self._defer:                                  # whoever looks at the rows between two calls finds them in _w_pos
+            self.sampler._pend_maybe = True
+            self.sampler._settle()
+            torch.cuda.current_stream().synchronize()
         c1 = self.sampler.finish_static(1, commit=False)
         c0 = self.sampler.finish_static(0, commit=True)
         self.last_counts2 = [c1, c0]                     # the two batches sampled by this replay, in sampling order
@@ -440,7 +444,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         if self.use_flags:
             eng.scratch_sets = max(eng.scratch_sets, L)      # block n then shares no scratch with any later layer
         self._defer = self._defer_wanted and self.use_flags
-        self.sampler.defer_normalize = self._defer
+        if self._defer:
+            self.sampler.enable_deferred_normalize(True)
         tune_gemm = tune_gemm and _enable_gemm_tuning()
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
@@ -515,13 +520,13 @@ class PipelinedTrainStep(GraphedTrainStep):
         held, out = [None, None], [None, None]
         st_ = lambda: torch.cuda.current_stream().cuda_stream
         if self._defer:
-            # F.normalize's pass, for the third stream: once the sampler that reads the rows (dividing on the fly) has finished,
-            # rewrite them in place -- beside the next forward pass -- and tell the next bandit update
+            # F.normalize's pass, for the third stream: as soon as the bandit update has decided which rows need it, write them
+            # renormalised into their other buffers -- beside the sampler, which keeps reading the old ones (dividing on the fly)
+            # until the pass has switched a row over
             self.g_norm = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_norm, pool=pool):
-                _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_SAMPLED, eng.flag_err.data_ptr(), st_()), "bliss_flag_wait")
+                _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_X_DONE, eng.flag_err.data_ptr(), st_()), "bliss_flag_wait")
                 self.sampler.normalize_pending()
-                _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_NORM_DONE, st_()), "bliss_flag_raise")
         for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
             # (the sampler is recorded without its generator: that one is launched ahead of time, see _replay / run)
             self.g_bwd[cur] = torch.cuda.CUDAGraph()
@@ -530,8 +535,6 @@ class PipelinedTrainStep(GraphedTrainStep):
                 with torch.cuda.graph(self.g_main[cur], pool=pool, stream=side):
                     held[cur] = self._forward(self.mfgs[cur], flagged=True)                     # F + X
                     self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True, part="main")   # S without the early blocks
-                    if self._defer:
-                        _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_SAMPLED, st_()), "bliss_flag_raise")
                 if L > 1:
                     self.g_blk[nxt] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.g_blk[nxt]):
@@ -561,20 +564,20 @@ class PipelinedTrainStep(GraphedTrainStep):
         main.wait_event(self._bwd_done)                  # parameters after the previous step's Adam
         if self.use_flags:
             self.g_main[cur].replay()                    # F + X + S: one graph on the critical stream
-            if self.g_blk[nxt] is not None:
+            if self.g_norm is not None or self.g_blk[nxt] is not None:
                 with torch.cuda.stream(self.third):
-                    self.g_blk[nxt].replay()             # early blocks of S: each waits for the flag of the next layer
+                    if self.g_norm is not None:
+                        self.g_norm.replay()             # F.normalize's pass: waits for X, runs beside S
+                    if self.g_blk[nxt] is not None:
+                        self.g_blk[nxt].replay()         # early blocks of S: each waits for the flag of the next layer
                     self._blk_done.record(self.third)
-            if self.g_norm is not None:
-                with torch.cuda.stream(self.third):
-                    self.g_norm.replay()                 # F.normalize's pass: waits for the end of S, runs beside the next F
-                    self._norm_done.record(self.third)
             with torch.cuda.stream(side):
                 self.g_bwd[cur].replay()                 # B: waits for the flag S raises when it starts
                 if on_side is not None:
                     on_side()
-                # one wait on the critical stream instead of two: "B done" below also means "all blocks of S built"
-                if self.g_blk[nxt] is not None:
+                # one wait on the critical stream instead of two: "B done" below also means "all blocks of S built" (and the
+                # pass complete: the next update may write the rows)
+                if self.g_norm is not None or self.g_blk[nxt] is not None:
                     side.wait_event(self._blk_done)
                 self._bwd_done.record(side)
         else:
@@ -590,19 +593,9 @@ class PipelinedTrainStep(GraphedTrainStep):
 
     def _join(self):
         torch.cuda.current_stream().wait_event(self._bwd_done)     # (flag mode: implies the early blocks, see _half)
-        if self.g_norm is not None:
-            torch.cuda.current_stream().wait_event(self._norm_done)
-
-    def _prime_norm_flag(self):
-        # the first bandit update of a run of replays waits for a pass nobody launched: the rows are settled (_finish_pair)
-        if self.g_norm is not None:
-            eng = self.sampler._engine
-            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_NORM_DONE, torch.cuda.current_stream().cuda_stream),
-                       "bliss_flag_raise")
 
     def _replay(self, first_chain=False):
         eng = self.sampler._engine
-        self._prime_norm_flag()
         for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
             eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
             self._half(cur, nxt)
@@ -693,7 +686,6 @@ class PipelinedTrainStep(GraphedTrainStep):
         # between two samplers (state commit, counts to the host, control block of the next generator) is one kernel on the
         # generator's stream (static_rng_chain); the seed ids of later batches are copied on the backward pass's stream.
         main = torch.cuda.current_stream()
-        self._prime_norm_flag()
         if n_pairs:
             self.seeds2[1].copy_(next(loader))           # S(b) runs first, then S(a')
             self.seeds2[0].copy_(next(loader))
@@ -775,7 +767,7 @@ class PipelinedTrainStep(GraphedTrainStep):
             loss = self._backward(self._forward(self.mfgs[0]))
         main.wait_stream(side)
         if self._defer:
-            self.sampler.normalize_pending()
+            self.sampler._settle()
         main.synchronize()
         self.num_steps += 1
         return loss
@@ -792,7 +784,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         super().close()
         self.mfgs = [None, None]
         if self._defer:
-            self.sampler.defer_normalize = False
+            self.sampler.enable_deferred_normalize(False)
+            self._defer = False
 
     def sizes2(self):
         """sizes() for each of the two batches sampled by the last call."""

@@ -100,9 +100,10 @@ typedef struct {
                                bliss_build_block; NULL = look kept sources up through local_id + new_id (two gathers) */
   int32_t* entry_flag;      /* optional: set to 1 by the first kernel of bliss_frontier_prob, i.e. once everything enqueued before
                                this layer has completed -- the hand-off bliss_flag_wait consumes on another stream */
-  const int32_t* w_pend;    /* optional: the pending-norm word of the w_pos row handed to bliss_frontier_prob / bliss_build_block
-                               (bliss_exp3_step_deferred): while it is non-zero every weight read from the row is divided by that
-                               norm on the fly, exactly as bliss_exp3_normalize_pending will rewrite it */
+  const int32_t* w_pend;    /* optional: the bliss_norm_state_t of the w_pos row handed to bliss_frontier_prob / bliss_build_block
+                               (bliss_exp3_step_deferred): the weights are read from the buffer it names, and while a pass is
+                               pending every weight read is divided by that norm on the fly, exactly as
+                               bliss_exp3_normalize_pending will write it */
 } bliss_layer_ws_t;
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
@@ -362,22 +363,29 @@ typedef struct {
   const int32_t* dst_nid; const int32_t* n_edges_dev;
   void* rewards_out;
   int32_t edges_bound;
-  int32_t* norm_pend;          /* bliss_exp3_step_deferred / bliss_exp3_normalize_pending only: the row's pending-norm word */
+  int32_t* norm_pend;          /* bliss_exp3_step_deferred / bliss_exp3_normalize_pending only: the row's bliss_norm_state_t */
 } bliss_exp3_block_t;
 int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
                     float delta_f, int32_t* err, void* stream);
 
 /* The same with F.normalize's pass over the rows taken off the caller's critical path.  The pass (4 bytes of HBM traffic per
  * edge of the graph, whenever the bf16 norm of a row is not exactly 1.0) is the only part of exp3() that scales with |E|, and
- * the next batch's sampler waits for exp3().  bliss_exp3_step_deferred updates the rows and, per row, only DECIDES: it leaves
- * 0x10000 | bf16 norm bits in *norm_pend (device int32, one per row, zero-initialised) when the row needs the pass, 0 when it
- * does not.  Until bliss_exp3_normalize_pending has run, a reader of the row must apply x -> bf16(x / max(norm, 1e-12)) to
- * what it loads: the sampler does when bliss_layer_ws_t::w_pend points at the row's word.  bliss_exp3_normalize_pending
- * (fields used: w_pos, row_sum, scratch, norm_pend) rewrites the pending rows in place, installs their exact sums and clears
- * the words; it must not overlap a reader or writer of the rows and must complete before the next update.  Deferred step +
- * pending pass leave the bits of bliss_exp3_step. */
+ * the next batch's sampler waits for exp3().  Every row has TWO buffers and a state record (bliss_norm_state_t, device memory,
+ * zero-initialised except `alt`): bits 0-15 of `state` the bf16 norm, bit 16 "a pass is pending", bit 17 "the row currently
+ * lives in the alternate buffer"; `alt` = distance of the alternate buffer from w_pos in ELEMENTS (a multiple of 8).
+ * bliss_exp3_step_deferred updates the rows (in whichever buffer is current) and, per row, only DECIDES: it leaves
+ * 0x10000 | norm in the state's low bits when the row needs the pass, 0 when it does not; done_flag (optional) is raised when
+ * all rows are decided (bliss_flag_wait's protocol).  bliss_exp3_normalize_pending (fields used: w_pos, row_sum, scratch,
+ * norm_pend) then runs the pass OUT OF PLACE -- current buffer -> other buffer, exact sums installed -- and a second small
+ * launch makes the other buffer current and clears the pending bits.  It may overlap READERS of the rows that go through the
+ * state record: the sampler does when bliss_layer_ws_t::w_pend points at it (a reader that started before the flip reads the
+ * old buffer and applies x -> bf16(x / max(norm, 1e-12)) on the fly; one that starts after it reads the new buffer).  It must
+ * not overlap a WRITER (the next update), nor the pass before it.  Deferred step + pending pass leave the bits of
+ * bliss_exp3_step in the current buffer.  The immediate entry points (bliss_exp3_step, bliss_exp3_normalize, ...) know nothing of
+ * the second buffer: callers switch back by copying a row that lives in the alternate buffer to w_pos and clearing bit 17. */
+typedef struct { int32_t state; int32_t reserved; int64_t alt; } bliss_norm_state_t;
 int bliss_exp3_step_deferred(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
-                             float delta_f, int32_t* err, void* stream);
+                             float delta_f, int32_t* done_flag, int32_t* err, void* stream);
 int bliss_exp3_normalize_pending(const bliss_exp3_block_t* rows, int32_t n_rows, int64_t num_edges, void* stream);
 
 /* The scatter half of update_exp3_weights (bandit_sampler.py:248) for factors computed elsewhere -- used

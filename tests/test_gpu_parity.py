@@ -1048,7 +1048,7 @@ def test_deferred_normalize_matches_immediate(cuda, monkeypatch):
             losses += [float(la), float(lb)]
             sizes += step.sizes2()
             passes += int(((sampler._scratch[:, 0] >> 16) & 1).eq(0).sum())     # rows whose last norm was not 1.0
-            assert int(sampler._pend.abs().sum()) == 0          # nothing pending between calls
+            assert int(sampler._pend[:, 0].abs().sum()) == 0    # between calls: nothing pending, every row back in _w_pos
         sizes += step.run(loader, 6)                            # and free-running
         losses += [float(x) for x in step.losses]
         losses.append(float(step.drain()))
