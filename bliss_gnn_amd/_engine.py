@@ -74,6 +74,8 @@ class LayerEngine:
         self.acc_p2 = torch.zeros(V, dtype=torch.int64, device=dev)
         self.c_graph = _lib.Graph(g.indptr.data_ptr(), g.indices.data_ptr(), _ptr(g.eid), V, self.Eg)
         self.flags = torch.zeros(16, dtype=torch.int32, device=dev)              # cross-stream hand-offs (bliss_flag_wait)
+        self.fs_ticket = torch.zeros(1, dtype=torch.int32, device=dev)           # bliss_layer_ws_t::fs_ticket
+        self.fuse_scale = os.environ.get("BLISS_FUSE_SCALE", "1") != "0"
         self.flag_err = torch.zeros(1, dtype=torch.int32, device=dev)
         # binned candidate pipeline (csrc/sampler.hip): LDS-resident per-source reductions when |V| / n_bins slots fit in
         # 64 KiB; otherwise (or with BLISS_BINS=0) the memory-side atomic passes.  Scratch shared by all layers.
@@ -505,6 +507,13 @@ class LayerEngine:
             if part == "main":                  # layer n raises flag n when it starts (= everything before it has completed)
                 c_ws.entry_flag = self.flags.data_ptr() + 4 * n
             if part in (None, "main"):          # candidates, probabilities, draw: all the next layer needs (its seeds = kept_nid)
+                if self.n_bins and self.fuse_scale:
+                    # the Poisson scale rides in the last workgroup of the candidate numbering (one launch less per layer)
+                    c_ws.fs_ticket = self.fs_ticket.data_ptr()
+                    c_ws.fs_fanout, c_ws.fs_eps = int(fanouts[n]), float(eps)
+                    if use_rng:
+                        c_ws.fs_rng_ctl, c_ws.fs_layer_off = self.rng_ctl.data_ptr(), self.rng_ctl.data_ptr() + 4 * (8 + n)
+                        c_ws.fs_is_last, c_ws.fs_rng_cap = int(n == L - 1), self.rng_cap
                 _lib.check(_lib.lib.bliss_frontier_prob(C.byref(self.c_graph), C.byref(self._set(n)["c_maps"]), w_pos.data_ptr(),
                                                         cur_seeds.data_ptr(), n_seeds, n_seeds_dev, cs, mode, eta_f, ome_f,
                                                         cap.get("E", self.Eg), C.byref(c_ws), st), "bliss_frontier_prob")

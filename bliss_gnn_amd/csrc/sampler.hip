@@ -743,13 +743,90 @@ __global__ void __launch_bounds__(1024) k_bitmap_tiles(const unsigned* __restric
   }
 }
 
+// ---------------------------------------------------------------- K_h: Poisson scale c  (bandit_sampler.py:391-401)
+__device__ __forceinline__ double block_sum_f64(double v, double* shd) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    long long b = __double_as_longlong(v);
+    int lo = __shfl_down((int)(b & 0xffffffffll), d), hi = __shfl_down((int)(b >> 32), d);
+    v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+  __syncthreads();
+  if (lane_id() == 0) shd[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += shd[i];   // same order in every thread
+  return t;
+}
+
+// (1024 threads.  COHERENT: the caller is the last workgroup of the launch that filled `hist` with memory-side atomics -- read it
+// past this XCD's L2)
+template <bool COHERENT>
+__device__ __forceinline__ void poisson_scale_body(int* hist, LayerCounts* cnt, int C, int num, double eps, int* rng_ctl,
+                                                   int* layer_off, int is_last, int rng_cap_total, int* __restrict__ sel_state,
+                                                   double* shd) {
+  // ticket + one status word per 1024-candidate chunk for k_select_fused's look-back
+  for (int i = threadIdx.x; i < (C + CHUNK - 1) / CHUNK + 2; i += 1024) sel_state[i] = 0;
+  // the random numbers of this layer come from the streaming generator: one lane waits for them while the others work
+  if (rng_ctl && threadIdx.x == 1023) rng_stream_acquire(rng_ctl, C, layer_off, is_last, rng_cap_total);
+  // every thread owns 32 bins; load the counts and leave the histogram zero for the next layer
+  int n[HIST_BINS / 1024];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < HIST_BINS / 1024; ++i) {
+    const int b = i * 1024 + threadIdx.x;
+    n[i] = COHERENT ? __hip_atomic_load(hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hist[b];
+  }
+#pragma unroll
+  for (int i = 0; i < HIST_BINS / 1024; ++i) {
+    const int b = i * 1024 + threadIdx.x;
+    if (n[i]) {
+      if (COHERENT) __hip_atomic_store(hist + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else hist[b] = 0;
+      any = true;
+    }
+  }
+  if (C <= num) {                                     // :392-393 everything is kept
+    if (threadIdx.x == 0) { cnt->c = 1.0; cnt->all_one = 1; cnt->iters = 0; }
+    return;
+  }
+  double c = 1.0;
+  int it = 0;
+  for (; it < 50; ++it) {                             // :396
+    const float c32 = (float)c;                       // torch multiplies a bf16 tensor by a Python float in fp32
+    double loc = 0;
+    if (any) {
+#pragma unroll
+      for (int i = 0; i < HIST_BINS / 1024; ++i) {
+        if (n[i]) {
+          float v = rbf(bf2f((bf16_t)(i * 1024 + threadIdx.x)) * c32);
+          v = v < 1.0f ? v : (v != v ? v : 1.0f);     // torch.minimum propagates NaN
+          loc += (double)n[i] * (double)v;            // count * bf16 value: exact in fp64
+        }
+      }
+    }
+    double Ssum = block_sum_f64(loc, shd);            // :397, exact in fp64 (bf16 terms, < 2^24 of them)
+    double lo = Ssum < (double)num ? Ssum : (double)num, hi = Ssum < (double)num ? (double)num : Ssum;
+    if (lo / hi >= eps) { ++it; break; }              // :398
+    c *= (double)num / Ssum;                          // :401
+  }
+  if (threadIdx.x == 0) { cnt->c = c; cnt->all_one = 0; cnt->iters = it > 50 ? 50 : it; }
+}
+
+__global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps, int* rng_ctl,
+                                                        int* layer_off, int is_last, int rng_cap_total, int* __restrict__ sel_state) {
+  __shared__ double shd[16];
+  poisson_scale_body<false>(hist, cnt, cnt->C, num, eps, rng_ctl, layer_off, is_last, rng_cap_total, sel_state, shd);
+}
+
+// the Poisson scale in k_cand_number's launch: the last workgroup to have flushed its histogram runs it (one launch less on
+// the sampler's critical chain, ~4.5 us per layer)
+struct FusedScale { int* ticket; int num; double eps; int* rng_ctl; int* layer_off; int is_last; int rng_cap_total; int* sel_state; };
 __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__ seeds, LayerCounts* cnt, int* __restrict__ cand_nid,
                                                          int* local_id, const unsigned long long* __restrict__ seed_p2,
                                                          const unsigned long long* __restrict__ touched_key,
                                                          const unsigned long long* __restrict__ touched_sum,
                                                          const unsigned* __restrict__ bitmap, const int* __restrict__ word_prefix,
                                                          const int* __restrict__ tile_sum, bf16_t* __restrict__ p, int* hist,
-                                                         int cap_c, int uniform_nodes) {
+                                                         int cap_c, int uniform_nodes, const FusedScale fs) {
   __shared__ int lh[HIST_BINS];                       // 128 KiB static LDS (one workgroup per CU; gfx950 has 160 KiB)
   __shared__ int tile_off[MAX_TILES];
   __shared__ int sh[17];
@@ -765,7 +842,7 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
   int C = S + run;
   if (C > cap_c) { C = cap_c; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, BLISS_ERR_CAP_CAND); }
   if (blockIdx.x == 0 && threadIdx.x == 0) cnt->C = C;
-  if ((int)blockIdx.x * FIN_TPB >= C) return;
+  if (blockIdx.x != 0 && (int)blockIdx.x * FIN_TPB >= C) return;      // surplus workgroups (workgroup 0 always takes part)
   {                                                   // (16 bytes per LDS access: the 128 KiB are most of this kernel's work)
     int4* lh4 = reinterpret_cast<int4*>(lh);
     for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) lh4[b] = make_int4(0, 0, 0, 0);
@@ -806,65 +883,24 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
     }
   }
   if (bad) atomicOr(&cnt->err, bad);
-}
-
-// ---------------------------------------------------------------- K_h: Poisson scale c  (bandit_sampler.py:391-401)
-__device__ __forceinline__ double block_sum_f64(double v, double* shd) {
-  for (int d = 32; d >= 1; d >>= 1) {
-    long long b = __double_as_longlong(v);
-    int lo = __shfl_down((int)(b & 0xffffffffll), d), hi = __shfl_down((int)(b >> 32), d);
-    v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-  }
-  __syncthreads();
-  if (lane_id() == 0) shd[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double t = 0;
-  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += shd[i];   // same order in every thread
-  return t;
-}
-
-__global__ void __launch_bounds__(1024) k_poisson_scale(int* hist, LayerCounts* cnt, int num, double eps, int* rng_ctl,
-                                                        int* layer_off, int is_last, int rng_cap_total, int* __restrict__ sel_state) {
-  __shared__ double shd[16];
-  const int C = cnt->C;
-  // ticket + one status word per 1024-candidate chunk for k_select_fused's look-back
-  for (int i = threadIdx.x; i < (C + CHUNK - 1) / CHUNK + 2; i += 1024) sel_state[i] = 0;
-  // the random numbers of this layer come from the streaming generator: one lane waits for them while the others work
-  if (rng_ctl && threadIdx.x == 1023) rng_stream_acquire(rng_ctl, C, layer_off, is_last, rng_cap_total);
-  // every thread owns 32 bins; load the counts and leave the histogram zero for the next layer
-  int n[HIST_BINS / 1024];
-  bool any = false;
-#pragma unroll
-  for (int i = 0; i < HIST_BINS / 1024; ++i) {
-    const int b = i * 1024 + threadIdx.x;
-    n[i] = hist[b];
-    if (n[i]) { hist[b] = 0; any = true; }
-  }
-  if (C <= num) {                                     // :392-393 everything is kept
-    if (threadIdx.x == 0) { cnt->c = 1.0; cnt->all_one = 1; cnt->iters = 0; }
-    return;
-  }
-  double c = 1.0;
-  int it = 0;
-  for (; it < 50; ++it) {                             // :396
-    const float c32 = (float)c;                       // torch multiplies a bf16 tensor by a Python float in fp32
-    double loc = 0;
-    if (any) {
-#pragma unroll
-      for (int i = 0; i < HIST_BINS / 1024; ++i) {
-        if (n[i]) {
-          float v = rbf(bf2f((bf16_t)(i * 1024 + threadIdx.x)) * c32);
-          v = v < 1.0f ? v : (v != v ? v : 1.0f);     // torch.minimum propagates NaN
-          loc += (double)n[i] * (double)v;            // count * bf16 value: exact in fp64
-        }
-      }
+  if (fs.ticket) {
+    // the histogram is complete when every participating workgroup has passed here: atomics drained, then a ticket
+    static_assert(FIN_TPB == 1024, "the fused Poisson scale runs in a 1024-thread workgroup");
+    __shared__ int sh_is_last;
+    __shared__ double shd[16];
+    int active = (C + FIN_TPB - 1) / FIN_TPB;
+    if (active > (int)gridDim.x) active = (int)gridDim.x;
+    if (active < 1) active = 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      sh_is_last = atomicAdd(fs.ticket, 1) == active - 1;
+      if (sh_is_last) __hip_atomic_store(fs.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double Ssum = block_sum_f64(loc, shd);            // :397, exact in fp64 (bf16 terms, < 2^24 of them)
-    double lo = Ssum < (double)num ? Ssum : (double)num, hi = Ssum < (double)num ? (double)num : Ssum;
-    if (lo / hi >= eps) { ++it; break; }              // :398
-    c *= (double)num / Ssum;                          // :401
+    __syncthreads();
+    if (sh_is_last)
+      poisson_scale_body<true>(hist, cnt, C, fs.num, fs.eps, fs.rng_ctl, fs.layer_off, fs.is_last, fs.rng_cap_total, fs.sel_state, shd);
   }
-  if (threadIdx.x == 0) { cnt->c = c; cnt->all_one = 0; cnt->iters = it > 50 ? 50 : it; }
 }
 
 __device__ __forceinline__ bf16_t incl_prob(const bf16_t* __restrict__ p, int j, int S, int all_one, float c32) {
@@ -1409,7 +1445,8 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     if (gf > 256) gf = 256;
     PROF_LAUNCH(BK_CAND_NUMBER, st, k_cand_number<<<gf, FIN_TPB, 0, st>>>(
         seeds, cnt, ws->cand_nid, m->local_id, seed_p2, (const unsigned long long*)ws->touched_key,
-        (const unsigned long long*)ws->touched_sum, ws->bitmap, word_prefix, tile_sum, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes));
+        (const unsigned long long*)ws->touched_sum, ws->bitmap, word_prefix, tile_sum, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes,
+        FusedScale{ws->fs_ticket, ws->fs_fanout, ws->fs_eps, ws->fs_rng_ctl, ws->fs_layer_off, ws->fs_is_last, ws->fs_rng_cap, ws->chunk_cnt}));
     return (int)hipGetLastError();
   }
   if (mode == BLISS_MODE_BANDIT) {
@@ -1442,7 +1479,8 @@ int bliss_poisson_select(const bliss_layer_ws_t* ws, int32_t fanout, double eps,
   LayerCounts* cnt = (LayerCounts*)ws->counts;
   if (cand_bound < 1) cand_bound = 1;
   if (cand_bound > ws->cap_c) cand_bound = ws->cap_c;
-  PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps, rng_ctl, uniforms_offset_dev, is_last, rng_cap_total, ws->chunk_cnt));
+  if (!ws->fs_ticket)                                  // (else k_cand_number's last workgroup has computed the scale)
+    PROF_LAUNCH(BK_POISSON_SCALE, st, k_poisson_scale<<<1, 1024, 0, st>>>(ws->hist, cnt, fanout, eps, rng_ctl, uniforms_offset_dev, is_last, rng_cap_total, ws->chunk_cnt));
   PROF_LAUNCH(BK_SELECT2, st, k_select_fused<<<grid_for(cand_bound, CHUNK, 1 << 20), TPB, 0, st>>>(
       (const bf16_t*)ws->p, uniforms, uniforms_offset_dev, cnt, (bf16_t*)ws->P, ws->chunk_cnt, ws->cand_nid, ws->new_id, ws->kept_nid,
       (bf16_t*)ws->node_prob, ws->cap_c, ws->cap_k, ws->kept_map));

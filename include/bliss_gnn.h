@@ -104,6 +104,11 @@ typedef struct {
                                (bliss_exp3_step_deferred): the weights are read from the buffer it names, and while a pass is
                                pending every weight read is divided by that norm on the fly, exactly as
                                bliss_exp3_normalize_pending will write it */
+  /* optional (binned pipeline only): fs_ticket != NULL (int32 device word, zero, left zero) makes the last workgroup of
+     bliss_frontier_prob's final kernel compute the Poisson scale, and bliss_poisson_select skips its own scale launch; the
+     other fs_* fields are then the fanout / eps / rng_ctl / uniforms_offset_dev / is_last / rng_cap_total arguments that
+     bliss_poisson_select will be called with */
+  int32_t* fs_ticket; int32_t fs_fanout, fs_is_last, fs_rng_cap, fs_reserved; double fs_eps; int32_t* fs_rng_ctl; int32_t* fs_layer_off;
 } bliss_layer_ws_t;
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
