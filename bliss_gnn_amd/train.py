@@ -312,7 +312,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         super().__init__(g, sampler, model, batch_size, lr, multilabel, distributed)
         self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
         self.mfgs = [None, None]
-        self.side = torch.cuda.Stream()          # backward pass + Adam
+        prio = int(os.environ.get("BLISS_SIDE_PRIORITY", "0"))
+        self.side = torch.cuda.Stream(priority=prio)     # backward pass + Adam
         self.third = torch.cuda.Stream()         # blocks of all but the last-sampled layer (flag mode)
         self._fwd_done, self._bwd_done, self._blk_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self._seed_ev = torch.cuda.Event()
@@ -329,6 +330,7 @@ class PipelinedTrainStep(GraphedTrainStep):
                               and os.environ.get("BLISS_NORM_DEFER", "0") != "0")
         self._defer = False
         self.g_norm = None
+        self._flag_boundary = os.environ.get("BLISS_FLAG_BOUNDARY", "1") != "0"
 
     def _sample(self, slot, chain, external_rng=False, part=None):
         return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng,
@@ -339,7 +341,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         return (hasattr(self.model, "forward_hidden") and len(getattr(self.model, "layers", ())) > 1 and hasattr(self.sampler, "exp3")
                 and os.environ.get("BLISS_SPLIT_FORWARD", "1") != "0")
 
-    FLAG_X_DONE = 12                              # engine.flags slots (0..L-1: the sampler's layers; 14: the probe)
+    FLAG_B_DONE, FLAG_X_DONE = 11, 12             # engine.flags slots (0..L-1: the sampler's layers; 14: the probe)
 
     def _forward(self, mfgs, flagged=False):
         """The part of the step the NEXT batch's sampler waits for: the forward pass up to the output layer's input (every
@@ -533,6 +535,12 @@ class PipelinedTrainStep(GraphedTrainStep):
             if self.use_flags:
                 self.g_main[cur] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_main[cur], pool=pool, stream=side):
+                    if self._flag_boundary:
+                        # "the previous step's backward pass, Adam and early blocks are done", as a device flag: the graph is
+                        # launched ahead and its first kernel waits ~3 us past the raise; a stream-event wait in front of the
+                        # graph launch cost ~30 us from the end of B to the first kernel of F
+                        _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_B_DONE, eng.flag_err.data_ptr(), st_()),
+                                   "bliss_flag_wait")
                     held[cur] = self._forward(self.mfgs[cur], flagged=True)                     # F + X
                     self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True, part="main")   # S without the early blocks
                 if L > 1:
@@ -561,7 +569,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         """Enqueue F(cur) X(cur) [ S(nxt) || B(cur) ].  The generator of S(nxt) has been started by the caller.
         ``on_side``: extra work for the backward pass's stream, after B."""
         main, side = torch.cuda.current_stream(), self.side
-        main.wait_event(self._bwd_done)                  # parameters after the previous step's Adam
+        if not (self.use_flags and self._flag_boundary):
+            main.wait_event(self._bwd_done)              # parameters after the previous step's Adam
         if self.use_flags:
             self.g_main[cur].replay()                    # F + X + S: one graph on the critical stream
             if self.g_norm is not None or self.g_blk[nxt] is not None:
@@ -579,6 +588,9 @@ class PipelinedTrainStep(GraphedTrainStep):
                 # pass complete: the next update may write the rows)
                 if self.g_norm is not None or self.g_blk[nxt] is not None:
                     side.wait_event(self._blk_done)
+                if self._flag_boundary:
+                    _lib.check(_lib.lib.bliss_flag_raise(self.sampler._engine.flags.data_ptr() + 4 * self.FLAG_B_DONE, side.cuda_stream),
+                               "bliss_flag_raise")
                 self._bwd_done.record(side)
         else:
             self.g_fwd[cur].replay()                     # F + X
@@ -594,8 +606,16 @@ class PipelinedTrainStep(GraphedTrainStep):
     def _join(self):
         torch.cuda.current_stream().wait_event(self._bwd_done)     # (flag mode: implies the early blocks, see _half)
 
+    def _prime_boundary(self):
+        # the first forward pass of a run of replays waits for a backward pass nobody launched
+        if self.use_flags and self._flag_boundary and self.graph:
+            eng = self.sampler._engine
+            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_B_DONE, torch.cuda.current_stream().cuda_stream),
+                       "bliss_flag_raise")
+
     def _replay(self, first_chain=False):
         eng = self.sampler._engine
+        self._prime_boundary()
         for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
             eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
             self._half(cur, nxt)
@@ -686,6 +706,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         # between two samplers (state commit, counts to the host, control block of the next generator) is one kernel on the
         # generator's stream (static_rng_chain); the seed ids of later batches are copied on the backward pass's stream.
         main = torch.cuda.current_stream()
+        self._prime_boundary()
         if n_pairs:
             self.seeds2[1].copy_(next(loader))           # S(b) runs first, then S(a')
             self.seeds2[0].copy_(next(loader))
