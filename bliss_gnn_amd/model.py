@@ -71,7 +71,7 @@ class SAGE(nn.Module):
         for fc_neigh + fc_self (+ the feature gather and the input norms), per aggregate-first layer ONE launch for both
         Linears, the bias, ReLU, dropout and the next layer's norms.  The aggregation stays the merge-style SpMM of
         csrc/spmm.hip."""
-        from .nn import LazyRows, _SageDualLinear, _SageLinearPair, weighted_aggregate
+        from .nn import LazyRows, _SageLinearPair, sage_agg_dual, weighted_aggregate
         n_layers = len(self.layers)
         for l in range(lo, hi):
             layer, block = self.layers[l], blocks[l]
@@ -96,8 +96,7 @@ class SAGE(nn.Module):
                 if isinstance(h, LazyRows):
                     h = h.materialize()
                 block.srcdata["embed_norm"] = embed_norm(h) if norm is None else norm
-                agg = weighted_aggregate(block, h, ew, mean=True)
-                h, norm = _SageDualLinear.apply(agg, h[:S_b], fc_n.weight, fc_s.weight, fc_s.bias, not last, p, ctr, seed, S_b, dst_dev)
+                h, norm = sage_agg_dual(block, h, ew, fc_n.weight, fc_s.weight, fc_s.bias, not last, p, ctr, seed, dst_dev)
                 if last:
                     norm = None
         return h, norm

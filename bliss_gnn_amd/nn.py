@@ -50,6 +50,7 @@ class _SageEpilogue(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, p, ctr, seed):
+        ctx.set_materialize_grads(False)          # (no zero-filled gradients for the outputs nothing differentiates through)
         a, b = a.contiguous(), b.contiguous()
         n, d = a.shape
         out = torch.empty_like(a)
@@ -65,6 +66,8 @@ class _SageEpilogue(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dnorm):
         (out,) = ctx.saved_tensors
+        if dout is None:
+            return None, None, None, None, None
         dout = dout.contiguous()
         if dout.dtype != torch.bfloat16:
             dout = dout.bfloat16()
@@ -102,6 +105,16 @@ class _CrossEntropy(torch.autograd.Function):
         return dx * g.to(dx.dtype), None, None
 
 
+def _ce_launch(x, labels, state):
+    n, c = x.shape
+    dx = torch.empty(n, c, dtype=torch.bfloat16, device=x.device)
+    rows = torch.empty(n, dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib.bliss_cross_entropy(x.data_ptr(), x.stride(0), labels.data_ptr(), n, c, rows.data_ptr(), dx.data_ptr(), dx.stride(0),
+                                            loss.data_ptr(), state.data_ptr(), state.data_ptr() + 4, _stream()), "bliss_cross_entropy")
+    return loss, dx
+
+
 class CrossEntropyLoss(nn.Module):
     """``nn.CrossEntropyLoss()`` as the reference builds it (train_lightning.py:77-79): mean over the batch, class-index
     targets.  bf16 logits on the GPU take the one-launch kernel; anything else goes to torch's functional form."""
@@ -112,6 +125,24 @@ class CrossEntropyLoss(nn.Module):
                 self._state = torch.zeros(2, dtype=torch.int32, device=logits.device)       # [0] ticket, [1] error word
             return _CrossEntropy.apply(logits, target.contiguous(), self._state)
         return torch.nn.functional.cross_entropy(logits, target)
+
+    def _eligible(self, logits, target):
+        return logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2 and target.dtype == torch.int64 and target.dim() == 1
+
+    def backward_from(self, logits, target):
+        """loss.backward() without the loss node: the kernel produces d loss / d logits with the loss, so the train loops call
+        ``logits.backward(that)`` directly (saves the ones-fill, the scalar cast and the elementwise product of the generic
+        route).  Returns the loss (fp32 scalar, detached)."""
+        if not self._eligible(logits, target):
+            loss = self.forward(logits, target)
+            loss.backward()
+            return loss.detach()
+        if getattr(self, "_state", None) is None or self._state.device != logits.device:
+            self._state = torch.zeros(2, dtype=torch.int32, device=logits.device)
+        x = logits.detach()
+        loss, dx = _ce_launch(x if x.stride(1) == 1 else x.contiguous(), target.contiguous(), self._state)
+        logits.backward(dx)
+        return loss
 
 
 # ------------------------------------------------------------------------------------------------ MFMA tile GEMM (csrc/sage.hip)
@@ -171,6 +202,7 @@ class _SageLinearPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ids, w_neigh, w_self, b_self, n_src, n_dst, src_dev, dst_dev):
+        ctx.set_materialize_grads(False)          # (else autograd zero-fills a gradient for `rows`: 13 MB on the input layer)
         x, wn, ws = _bf16c(x), _bf16c(w_neigh), _bf16c(w_self)
         dev, n_out = x.device, wn.shape[0]
         z = torch.empty(n_src, n_out, dtype=torch.bfloat16, device=dev)
@@ -187,14 +219,23 @@ class _SageLinearPair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, dy, _drows, _dnorm):
         rows, wn, ws = ctx.saved_tensors
-        dz, dy = _bf16c(dz), _bf16c(dy)
-        d_wn = _weight_grad(dz, rows)
-        d_ws = _weight_grad(dy, rows[: ctx.n_dst])
-        d_b = dy.sum(0) if ctx.has_bias else None
-        dx = None
-        if not ctx.gathered and ctx.needs_input_grad[0]:
-            dx = dz @ wn
-            dx[: ctx.n_dst] += dy @ ws
+        want_dx = not ctx.gathered and ctx.needs_input_grad[0]
+        d_wn = d_ws = d_b = dx = None
+        if dz is not None:
+            dz = _bf16c(dz)
+            d_wn = _weight_grad(dz, rows)
+            if want_dx:
+                dx = dz @ wn
+        if dy is not None:
+            dy = _bf16c(dy)
+            d_ws = _weight_grad(dy, rows[: ctx.n_dst])
+            d_b = dy.sum(0) if ctx.has_bias else None
+            if want_dx:
+                if dx is None:
+                    dx = torch.zeros_like(rows)
+                dx[: ctx.n_dst].addmm_(dy, ws)                                   # (the GEMM accumulates: no separate add)
+        if _drows is not None and want_dx:
+            dx = _drows if dx is None else dx + _drows
         return dx, None, d_wn, d_ws, d_b, None, None, None, None
 
 
@@ -217,6 +258,7 @@ class _SageDualLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a_neigh, a_self, w_neigh, w_self, bias, relu, p, ctr, seed, n_rows, rows_dev):
+        ctx.set_materialize_grads(False)
         a1, a2, w1, w2 = _bf16c(a_neigh), _bf16c(a_self), _bf16c(w_neigh), _bf16c(w_self)
         out = torch.empty(n_rows, w1.shape[0], dtype=torch.bfloat16, device=a1.device)
         norm = torch.empty(n_rows, dtype=torch.bfloat16, device=a1.device)
@@ -229,6 +271,8 @@ class _SageDualLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dnorm):
         a1, a2, w1, w2, out = ctx.saved_tensors
+        if dout is None:
+            return (None,) * 11
         d = _bf16c(dout)
         if ctx.relu or ctx.p > 0:
             din = torch.empty_like(out)
@@ -237,6 +281,62 @@ class _SageDualLinear(torch.autograd.Function):
                        "bliss_sage_epilogue_bwd")
             d = din
         return (d @ w1, d @ w2, d.t() @ a1, d.t() @ a2, d.sum(0) if ctx.has_bias else None, None, None, None, None, None, None)
+
+
+class _SageAggDual(torch.autograd.Function):
+    """Aggregation + _SageDualLinear as ONE autograd node: the layer input h feeds both the SpMM and (its first rows) fc_self, and
+    two nodes made autograd zero-pad the slice's gradient and add the two (fill + copy + add kernels, 5 K x 256 each); here the
+    fc_self product accumulates straight into the transposed SpMM's result."""
+
+    @staticmethod
+    def forward(ctx, h, indptr, src, dst, w, counts, t_indptr, t_edge, n_dst, w_neigh, w_self, bias, relu, p, ctr, seed, rows_dev):
+        from . import ops
+        ctx.set_materialize_grads(False)
+        h, w1, w2 = _bf16c(h), _bf16c(w_neigh), _bf16c(w_self)
+        agg = ops.spmm(indptr, src, dst, w, h, n_dst, counts, True, False, None, None)
+        out = torch.empty(n_dst, w1.shape[0], dtype=torch.bfloat16, device=h.device)
+        norm = torch.empty(n_dst, dtype=torch.bfloat16, device=h.device)
+        _tile_gemm(_tg_args(agg, w1, out, n_dst, a2=h, w2=w2, bias=bias, m_dev=rows_dev, out_norm=norm, relu=relu, p=p, seed=seed, ctr=ctr))
+        ctx.save_for_backward(agg, h, w1, w2, out, indptr, src, dst, w, counts, t_indptr, t_edge)
+        ctx.relu, ctx.p, ctx.has_bias, ctx.n_dst = relu, float(p), bias is not None, n_dst
+        ctx.mark_non_differentiable(norm)
+        return out, norm
+
+    @staticmethod
+    def backward(ctx, dout, _dnorm):
+        from . import ops
+        agg, h, w1, w2, out, indptr, src, dst, w, counts, t_indptr, t_edge = ctx.saved_tensors
+        if dout is None:
+            return (None,) * 17
+        d = _bf16c(dout)
+        if ctx.relu or ctx.p > 0:
+            din = torch.empty_like(out)
+            _lib.check(_lib.lib.bliss_sage_epilogue_bwd(d.data_ptr(), d.stride(0), out.data_ptr(), out.stride(0), out.shape[0],
+                                                        out.shape[1], ctx.p, din.data_ptr(), din.stride(0), _stream()),
+                       "bliss_sage_epilogue_bwd")
+            d = din
+        gh = None
+        if ctx.needs_input_grad[0]:
+            if t_indptr is None or t_edge is None:
+                raise RuntimeError("the block's by-source index (Block.transposed()) is needed to differentiate w.r.t. h")
+            gh = ops.spmm_t(t_indptr, t_edge, src, dst, indptr, w, d @ w1, h.shape[0], counts, True)
+            gh[: ctx.n_dst].addmm_(d, w2)
+        return (gh, None, None, None, None, None, None, None, None, d.t() @ agg, d.t() @ h[: ctx.n_dst],
+                d.sum(0) if ctx.has_bias else None, None, None, None, None, None)
+
+
+def sage_agg_dual(block, h, edge_weight, w_neigh, w_self, bias, relu, p, ctr, seed, rows_dev):
+    """mean-aggregate ``h`` over ``block`` and apply fc_neigh(h_neigh) + fc_self(h_dst) + bias (+ ReLU, dropout, row norms)."""
+    assert h.is_cuda and h.dtype == torch.bfloat16
+    w = None
+    if edge_weight is not None:
+        w = edge_weight.reshape(-1)
+        w = (w if w.dtype == torch.bfloat16 else w.bfloat16()).contiguous()
+    counts = getattr(block, "_counts_dev", None) if block._nnz_ptr else None
+    need_t = h.requires_grad and torch.is_grad_enabled()
+    t_indptr, t_edge = block.transposed() if need_t else (None, None)
+    return _SageAggDual.apply(h, block.indptr, block.src, block.dst, w, counts, t_indptr, t_edge, block.num_dst_nodes(), w_neigh, w_self,
+                              bias, relu, p, ctr, seed, rows_dev)
 
 
 def tile_gemm_ok(in_feats, out_feats):

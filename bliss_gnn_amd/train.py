@@ -61,6 +61,17 @@ def _ce_loss():
     return CrossEntropyLoss()
 
 
+def _loss_backward(loss_fn, pred, labels, opt):
+    """loss = loss_fn(pred, labels); opt.zero_grad(); loss.backward() (train_lightning.py:142 + Lightning).  The one-launch
+    cross-entropy hands d loss / d pred over with the loss, so its route skips the loss node.  Returns the detached loss."""
+    opt.zero_grad(set_to_none=True)
+    if hasattr(loss_fn, "backward_from"):
+        return loss_fn.backward_from(pred, labels)
+    loss = loss_fn(pred, labels)
+    loss.backward()
+    return loss.detach()
+
+
 def make_adam(model, lr, capturable=False):
     """th.optim.Adam(self.parameters(), lr) (train_lightning.py:206).  For the reference's precision (bf16 module on the GPU,
     :596-618) this is the one-launch gfx950 Adam of csrc/optim.hip; anything else gets torch's own."""
@@ -109,9 +120,7 @@ class TrainStep:
         batch_inputs = _inputs(self.model, mfgs)                                         # :138
         batch_labels = mfgs[-1].dstdata["labels"]                                        # :139
         batch_pred = self.model(mfgs, batch_inputs)                                      # :141
-        loss = self.loss_fn(batch_pred, batch_labels)                                    # :142
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss = _loss_backward(self.loss_fn, batch_pred, batch_labels, self.opt)          # :142
         if self.grad_sync is not None:
             self.grad_sync(self.model)
         self.opt.step()
@@ -187,9 +196,7 @@ class GraphedTrainStep:
         x = _inputs(self.model, mfgs)
         y = mfgs[-1].dstdata["labels"]
         pred = self.model(mfgs, x)
-        loss = self.loss_fn(pred, y)
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss = _loss_backward(self.loss_fn, pred, y, self.opt)
         bandit = hasattr(self.sampler, "exp3")                     # train_lightning.py:469: only for the bandit samplers
         if self.distributed:
             from . import dist as bdist
@@ -372,23 +379,19 @@ class PipelinedTrainStep(GraphedTrainStep):
             pending = ("hidden", self.model.forward_hidden(mfgs, _inputs(self.model, mfgs)), mfgs)
         else:
             pred = self.model(mfgs, _inputs(self.model, mfgs))
-            pending = ("loss", self.loss_fn(pred, mfgs[-1].dstdata["labels"]), mfgs)
+            pending = ("pred", pred, mfgs)
         return pending
 
     def _backward(self, pending):
         """Output layer + loss (when _forward left them), backward, optimizer.  Returns the detached loss."""
         kind, val, mfgs = pending
-        if kind == "hidden":
-            loss = self.loss_fn(self.model.forward_last(mfgs, val), mfgs[-1].dstdata["labels"])
-        else:
-            loss = val
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        pred = self.model.forward_last(mfgs, val) if kind == "hidden" else val
+        loss = _loss_backward(self.loss_fn, pred, mfgs[-1].dstdata["labels"], self.opt)
         if self.distributed:
             from . import dist as bdist
             bdist.allreduce_gradients(self.model)
         self.opt.step()
-        return loss.detach()
+        return loss
 
     def _pair(self):
         # Eager version (warm-up, kernel-by-kernel timing).  The sampler stays on the origin stream (its random-number
