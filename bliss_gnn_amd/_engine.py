@@ -419,7 +419,7 @@ class LayerEngine:
         _lib.check(_lib.lib.bliss_rng_stream_ready(_stream()), "bliss_rng_stream_ready")
 
     def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False, part=None,
-                       w_pend=None):
+                       w_pend=None, last_block=True):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
         blocks (sampling order); sizes, errors and the generator state are read back by finish().
 
@@ -429,12 +429,15 @@ class LayerEngine:
         n raises ``flags[n]`` when it starts; "early_blocks" = only those blocks, each behind a bliss_flag_wait on
         ``flags[n + 1]`` -- to be enqueued on ANOTHER stream, with ``scratch_sets`` >= the number of layers (block n then shares
         no scratch with any later layer) and external_rng.  The caller orders the next "main" after both parts.
+        ``last_block=False`` with "main": the last-sampled layer's block is left out as well and ``flags[L]`` is raised at the end
+        (its draw is done); part "last_block" = only that block, behind a bliss_flag_wait on ``flags[L]`` -- the caller raises
+        whatever its consumer waits for.
         ``w_pend``: per layer (sampling order) the address of the row's pending-norm word (bliss_exp3_step_deferred)."""
         if part is not None and (self.scratch_sets < len(fanouts) or not external_rng):
             raise ValueError("split enqueue needs one scratch set per layer and an external generator")
         L = len(fanouts)
         out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng,
-                            external_rng=external_rng, part=part, w_pend=w_pend)
+                            external_rng=external_rng, part=part, w_pend=w_pend, last_block=last_block)
         counts_dev, layers = out
         if slot not in self._slot_counts_host:
             self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
@@ -475,7 +478,7 @@ class LayerEngine:
         return cnts
 
     def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False, external_rng=False,
-                 part=None, w_pend=None):
+                 part=None, w_pend=None, last_block=True):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
         if snapshot is not None and not chain_rng and not external_rng:
@@ -529,14 +532,18 @@ class LayerEngine:
                     _lib.check(_lib.lib.bliss_poisson_select(C.byref(c_ws), int(fanouts[n]), float(eps), ws.uniforms.data_ptr(),
                                                              0, 0, 0, 0, cap["C"], st), "bliss_poisson_select")
             # the block of this layer: nothing the next layer's candidate pipeline reads or writes (own scratch set)
-            if part is None or (part == "main" and last) or (part == "early_blocks" and not last):
-                if part == "early_blocks":      # on another stream: wait until layer n + 1 has started, i.e. layer n's draw is done
+            if part is None or (part == "main" and last and last_block) or (part == "early_blocks" and not last) or \
+                    (part == "last_block" and last):
+                if part in ("early_blocks", "last_block"):   # on another stream: wait until layer n + 1 has started (the last
+                    # layer: until the "main" part has raised flags[L]), i.e. layer n's draw is done
                     _lib.check(_lib.lib.bliss_flag_wait(self.flags.data_ptr() + 4 * (n + 1), self.flag_err.data_ptr(), st), "bliss_flag_wait")
                 _lib.check(_lib.lib.bliss_build_block(C.byref(self.c_graph), C.byref(self._set(n)["c_maps"]), w_pos.data_ptr(),
                                                       cur_seeds.data_ptr(), cs, mode, eta_f, ome_f, cap.get("E", self.Eg), C.byref(c_ws),
                                                       C.byref(c_out), st), "bliss_build_block")
             layers.append(lay)
             cur_seeds, n_seeds, n_seeds_dev = kept_nid, -1, cnt_ptr + 12          # next layer: S = this layer's K
+        if part == "main" and not last_block:
+            _lib.check(_lib.lib.bliss_flag_raise(self.flags.data_ptr() + 4 * L, st), "bliss_flag_raise")
         if use_rng and not external_rng:      # join; mt_dev = generator state after exactly sum(C) draws
             _lib.check(_lib.lib.bliss_rng_stream_end(self.mt_dev.data_ptr(), self.rng_ctl.data_ptr(), self.rng_raw.data_ptr(),
                                                      self.rng_cap, counts.data_ptr() + 20, _stream()), "bliss_rng_stream_end")

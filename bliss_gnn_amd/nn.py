@@ -24,12 +24,22 @@ def embed_norm(h):
     return ops.embed_norm(h)
 
 
+def _wait_block(block):
+    # A block whose build was left to another stream (train.PipelinedTrainStep: the input layer's block is built beside the
+    # first transform of the forward pass): its first consumer waits for the builder's flag.  Set during graph capture only.
+    r = getattr(block, "_ready", None)
+    if r is not None:
+        _lib.check(_lib.lib.bliss_flag_wait(r[0], r[1], _stream()), "bliss_flag_wait")
+        block._ready = None
+
+
 def weighted_aggregate(block, h, edge_weight=None, mean=True, out_fp32=False):
     """out[i] = (1/deg_i if mean) * sum_{e -> i} w_e h[src_e] over a Block -- ``torch.ops.bliss.spmm`` (bliss_gnn_amd/ops.py: a
     torch.library custom op with a fake kernel and the transposed SpMM as its autograd formula); gradient w.r.t. h only
     (the sampler's edge weights carry no grad)."""
     from . import ops
     assert h.is_cuda and h.dtype == torch.bfloat16, "bf16 features on the GPU (load_graph.py:7)"
+    _wait_block(block)
     if h.stride(1) != 1:
         h = h.contiguous()
     w = None
@@ -328,6 +338,7 @@ class _SageAggDual(torch.autograd.Function):
 def sage_agg_dual(block, h, edge_weight, w_neigh, w_self, bias, relu, p, ctr, seed, rows_dev):
     """mean-aggregate ``h`` over ``block`` and apply fc_neigh(h_neigh) + fc_self(h_dst) + bias (+ ReLU, dropout, row norms)."""
     assert h.is_cuda and h.dtype == torch.bfloat16
+    _wait_block(block)
     w = None
     if edge_weight is not None:
         w = edge_weight.reshape(-1)

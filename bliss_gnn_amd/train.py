@@ -338,17 +338,23 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._defer = False
         self.g_norm = None
         self._flag_boundary = os.environ.get("BLISS_FLAG_BOUNDARY", "1") != "0"
+        # The input layer's block (the LAST one the sampler builds: ~90 us at the end of its chain) built on the third stream
+        # beside the next step's first transform, which needs the kept-node list only; the first aggregation waits for a
+        # flag (nn._wait_block).  SAGE only: its first reader of the block's arrays is that aggregation.
+        self._defer_block0 = False
+        self.g_blk0 = [None, None]
+        self._blk0_done = torch.cuda.Event()
 
-    def _sample(self, slot, chain, external_rng=False, part=None):
+    def _sample(self, slot, chain, external_rng=False, part=None, last_block=True):
         return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng,
-                                                 part=part)[2]
+                                                 part=part, last_block=last_block)[2]
 
     def _split_forward(self):
         # BLISS_SPLIT_FORWARD=0 keeps the whole forward pass ahead of the bandit update (the round-1 order)
         return (hasattr(self.model, "forward_hidden") and len(getattr(self.model, "layers", ())) > 1 and hasattr(self.sampler, "exp3")
                 and os.environ.get("BLISS_SPLIT_FORWARD", "1") != "0")
 
-    FLAG_B_DONE, FLAG_X_DONE = 11, 12             # engine.flags slots (0..L-1: the sampler's layers; 14: the probe)
+    FLAG_BLOCK0, FLAG_B_DONE, FLAG_X_DONE = 10, 11, 12    # engine.flags slots (0..L: the sampler's layers; 14: the probe)
 
     def _forward(self, mfgs, flagged=False):
         """The part of the step the NEXT batch's sampler waits for: the forward pass up to the output layer's input (every
@@ -451,6 +457,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._defer = self._defer_wanted and self.use_flags
         if self._defer:
             self.sampler.enable_deferred_normalize(True)
+        self._defer_block0 = (self.use_flags and self._flag_boundary and L > 1 and L < self.FLAG_BLOCK0 and type(self.model).__name__ == "SAGE"
+                              and self._split_forward() and os.environ.get("BLISS_DEFER_BLOCK0", "1") != "0")
         tune_gemm = tune_gemm and _enable_gemm_tuning()
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
@@ -520,7 +528,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         side = self.side
         pool = torch.cuda.graph_pool_handle()
         self.graph = None
-        self.g_main, self.g_fwd, self.g_bwd, self.g_smp, self.g_blk = ([None, None] for _ in range(5))
+        self.g_main, self.g_fwd, self.g_bwd, self.g_smp, self.g_blk, self.g_blk0 = ([None, None] for _ in range(6))
         self.g_norm = None
         held, out = [None, None], [None, None]
         st_ = lambda: torch.cuda.current_stream().cuda_stream
@@ -544,12 +552,21 @@ class PipelinedTrainStep(GraphedTrainStep):
                         # graph launch cost ~30 us from the end of B to the first kernel of F
                         _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_B_DONE, eng.flag_err.data_ptr(), st_()),
                                    "bliss_flag_wait")
+                    if self._defer_block0:              # (the wait itself is recorded by the first aggregation over that block)
+                        self.mfgs[cur][0]._ready = (eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0, eng.flag_err.data_ptr())
                     held[cur] = self._forward(self.mfgs[cur], flagged=True)                     # F + X
-                    self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True, part="main")   # S without the early blocks
+                    self.mfgs[cur][0]._ready = None
+                    self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True, part="main",   # S without the early blocks
+                                                  last_block=not self._defer_block0)
                 if L > 1:
                     self.g_blk[nxt] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.g_blk[nxt]):
                         self._sample(nxt, chain, external_rng=True, part="early_blocks")
+                if self._defer_block0:
+                    self.g_blk0[nxt] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_blk0[nxt]):
+                        self._sample(nxt, chain, external_rng=True, part="last_block")
+                        _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0, st_()), "bliss_flag_raise")
                 with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
                     # B may start once S has (flag 0 is raised by the sampler's first kernel: F and X have completed)
                     _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr(), eng.flag_err.data_ptr(),
@@ -583,6 +600,9 @@ class PipelinedTrainStep(GraphedTrainStep):
                     if self.g_blk[nxt] is not None:
                         self.g_blk[nxt].replay()         # early blocks of S: each waits for the flag of the next layer
                     self._blk_done.record(self.third)
+                    if self.g_blk0[nxt] is not None:
+                        self.g_blk0[nxt].replay()        # the input layer's block: waits for the end of S, raises FLAG_BLOCK0
+                        self._blk0_done.record(self.third)
             with torch.cuda.stream(side):
                 self.g_bwd[cur].replay()                 # B: waits for the flag S raises when it starts
                 if on_side is not None:
@@ -608,6 +628,8 @@ class PipelinedTrainStep(GraphedTrainStep):
 
     def _join(self):
         torch.cuda.current_stream().wait_event(self._bwd_done)     # (flag mode: implies the early blocks, see _half)
+        if self._defer_block0 and self.graph:
+            torch.cuda.current_stream().wait_event(self._blk0_done)
 
     def _prime_boundary(self):
         # the first forward pass of a run of replays waits for a backward pass nobody launched
@@ -615,6 +637,14 @@ class PipelinedTrainStep(GraphedTrainStep):
             eng = self.sampler._engine
             _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_B_DONE, torch.cuda.current_stream().cuda_stream),
                        "bliss_flag_raise")
+            if self._defer_block0:                       # (the batch in flight was sampled completely: _join / prime)
+                _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0, torch.cuda.current_stream().cuda_stream),
+                           "bliss_flag_raise")
+
+    def _after_blocks(self):
+        """The stream on which 'the sampler of the last half has finished' is to be recorded: the third one when it builds the
+        last block (its counts record and error word are complete only then)."""
+        return torch.cuda.stream(self.third) if (self._defer_block0 and self.graph) else contextlib.nullcontext()
 
     def _replay(self, first_chain=False):
         eng = self.sampler._engine
@@ -622,6 +652,8 @@ class PipelinedTrainStep(GraphedTrainStep):
         for cur, nxt, chain in ((0, 1, first_chain), (1, 0, True)):
             eng.static_rng_begin(chain)                  # the serial MT19937 chain of S starts now, beside F + X
             self._half(cur, nxt)
+            if self._defer_block0:
+                torch.cuda.current_stream().wait_event(self._blk0_done)   # (the counts record static_rng_end copies)
             eng.static_rng_end(nxt)
         self._join()
 
@@ -729,9 +761,11 @@ class PipelinedTrainStep(GraphedTrainStep):
                 if k == 0 and cur == 0:
                     eng.static_rng_begin(False)          # from the host-staged state
                 elif cur == 0:                           # ends S(a') of the previous pair; its sizes complete that pair's record
-                    eng.static_rng_chain(0, self._ring[(k - 1) % ring][L * 10:])
+                    with self._after_blocks():
+                        eng.static_rng_chain(0, self._ring[(k - 1) % ring][L * 10:])
                 else:
-                    eng.static_rng_chain(1, r[:L * 10])
+                    with self._after_blocks():
+                        eng.static_rng_chain(1, r[:L * 10])
                 # (no wait for the hand-over on the main stream: the sampler's first random-number wait checks that the control
                 # block is the new generator's -- the event round trip cost ~12 us between every two steps)
                 if cur == 0 and k > 0:                   # the previous pair's record is complete once that hand-over has run
@@ -750,6 +784,8 @@ class PipelinedTrainStep(GraphedTrainStep):
                         self.seeds2[c].copy_(b)
                 self._half(cur, nxt, on_side=on_side)
             if last:
+                if self._defer_block0:
+                    main.wait_event(self._blk0_done)
                 eng.static_rng_end(0)
                 r[L * 10:].copy_(eng._slot_counts[0], non_blocking=True)
                 self._join()
@@ -797,7 +833,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         return loss
 
     def _graph_attrs(self):
-        return ("graph", "g_main", "g_fwd", "g_bwd", "g_smp", "g_blk", "g_norm")
+        return ("graph", "g_main", "g_fwd", "g_bwd", "g_smp", "g_blk", "g_blk0", "g_norm")
 
     def close(self):
         """Train the batch still in flight (``drain``), wait for every stream of the loop, then destroy the graphs."""
