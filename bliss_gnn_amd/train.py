@@ -319,8 +319,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         super().__init__(g, sampler, model, batch_size, lr, multilabel, distributed)
         self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
         self.mfgs = [None, None]
-        prio = int(os.environ.get("BLISS_SIDE_PRIORITY", "0"))
-        self.side = torch.cuda.Stream(priority=prio)     # backward pass + Adam
+        self.side = torch.cuda.Stream()          # backward pass + Adam (a high-priority stream measured no different)
         self.third = torch.cuda.Stream()         # blocks of all but the last-sampled layer (flag mode)
         self._fwd_done, self._bwd_done, self._blk_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self._seed_ev = torch.cuda.Event()
