@@ -419,7 +419,7 @@ class LayerEngine:
         _lib.check(_lib.lib.bliss_rng_stream_ready(_stream()), "bliss_rng_stream_ready")
 
     def enqueue_static(self, w_rows, seeds, fanouts, mode, eta, eps=0.9999, slot=0, chain_rng=False, external_rng=False, part=None,
-                       w_pend=None, last_block=True):
+                       w_pend=None, last_block=True, ready_flag=0):
         """Enqueue one sample_blocks on the current stream with capacity-padded outputs and NO sync.  Returns the
         blocks (sampling order); sizes, errors and the generator state are read back by finish().
 
@@ -430,14 +430,14 @@ class LayerEngine:
         ``flags[n + 1]`` -- to be enqueued on ANOTHER stream, with ``scratch_sets`` >= the number of layers (block n then shares
         no scratch with any later layer) and external_rng.  The caller orders the next "main" after both parts.
         ``last_block=False`` with "main": the last-sampled layer's block is left out as well and ``flags[L]`` is raised at the end
-        (its draw is done); part "last_block" = only that block, behind a bliss_flag_wait on ``flags[L]`` -- the caller raises
-        whatever its consumer waits for.
+        (its draw is done); part "last_block" = only that block, behind a bliss_flag_wait on ``flags[L]``; ``ready_flag``
+        (address of a device flag) is raised as soon as the block's forward arrays are final, before its by-source index.
         ``w_pend``: per layer (sampling order) the address of the row's pending-norm word (bliss_exp3_step_deferred)."""
         if part is not None and (self.scratch_sets < len(fanouts) or not external_rng):
             raise ValueError("split enqueue needs one scratch set per layer and an external generator")
         L = len(fanouts)
         out = self._enqueue(w_rows, seeds, fanouts, mode, eta, eps, None, True, slot=slot, chain_rng=chain_rng,
-                            external_rng=external_rng, part=part, w_pend=w_pend, last_block=last_block)
+                            external_rng=external_rng, part=part, w_pend=w_pend, last_block=last_block, ready_flag=ready_flag)
         counts_dev, layers = out
         if slot not in self._slot_counts_host:
             self._slot_counts_host[slot] = torch.empty(L * 10, dtype=torch.int32).pin_memory()
@@ -478,7 +478,7 @@ class LayerEngine:
         return cnts
 
     def _enqueue(self, w_rows, seeds, fanouts, mode, eta, eps, uniforms, snapshot, slot=None, chain_rng=False, external_rng=False,
-                 part=None, w_pend=None, last_block=True):
+                 part=None, w_pend=None, last_block=True, ready_flag=0):
         dev, st = self.g.device, _stream()
         L = len(fanouts)
         if snapshot is not None and not chain_rng and not external_rng:
@@ -534,6 +534,8 @@ class LayerEngine:
             # the block of this layer: nothing the next layer's candidate pipeline reads or writes (own scratch set)
             if part is None or (part == "main" and last and last_block) or (part == "early_blocks" and not last) or \
                     (part == "last_block" and last):
+                if part == "last_block" and ready_flag:
+                    c_ws.block_ready_flag = int(ready_flag)
                 if part in ("early_blocks", "last_block"):   # on another stream: wait until layer n + 1 has started (the last
                     # layer: until the "main" part has raised flags[L]), i.e. layer n's draw is done
                     _lib.check(_lib.lib.bliss_flag_wait(self.flags.data_ptr() + 4 * (n + 1), self.flag_err.data_ptr(), st), "bliss_flag_wait")

@@ -48,7 +48,8 @@ class LayerWs(C.Structure):
                 ("span_seg", C.c_void_p), ("kept_rec", C.c_void_p), ("span_cnt", C.c_void_p), ("kept_rec_positions", C.c_int64),
                 ("kept_map", C.c_void_p), ("entry_flag", C.c_void_p), ("w_pend", C.c_void_p),
                 ("fs_ticket", C.c_void_p), ("fs_fanout", C.c_int32), ("fs_is_last", C.c_int32), ("fs_rng_cap", C.c_int32),
-                ("fs_reserved", C.c_int32), ("fs_eps", C.c_double), ("fs_rng_ctl", C.c_void_p), ("fs_layer_off", C.c_void_p)]
+                ("fs_reserved", C.c_int32), ("fs_eps", C.c_double), ("fs_rng_ctl", C.c_void_p), ("fs_layer_off", C.c_void_p),
+                ("block_ready_flag", C.c_void_p)]
 
 
 class Exp3Block(C.Structure):

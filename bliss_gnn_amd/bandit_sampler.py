@@ -218,7 +218,7 @@ class BanditLadiesSampler(BlockSampler):
             blocks.insert(0, blk)                                       # :366
         return blocks[0].srcdata[NID], output_nodes, blocks             # :364,:367
 
-    def sample_blocks_static(self, g, seed_nodes, slot=0, chain_rng=False, external_rng=False, part=None, last_block=True):
+    def sample_blocks_static(self, g, seed_nodes, slot=0, chain_rng=False, external_rng=False, part=None, last_block=True, ready_flag=0):
         """sample_blocks with capacity-padded (static-shape) blocks and no host round trip: everything is only
         ENQUEUED, so the whole train step can be recorded into a HIP graph.  Call ``engine.stage_rng_from_torch()``
         before and ``finish_static()`` after the stream has been synchronised.  Padded rows / edges are inert:
@@ -233,7 +233,7 @@ class BanditLadiesSampler(BlockSampler):
             self._settle()
         blks = eng.enqueue_static([self._w_pos[b] for b in order], seed_nodes, [self.nodes_per_layer[b] for b in order],
                                   self._mode(), self.eta, self.eps, slot=slot, chain_rng=chain_rng, external_rng=external_rng, part=part,
-                                  w_pend=pend, last_block=last_block)
+                                  w_pend=pend, last_block=last_block, ready_flag=ready_flag)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights

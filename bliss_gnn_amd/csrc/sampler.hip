@@ -1288,9 +1288,9 @@ __device__ __forceinline__ void maps_cleanup(LayerCounts* cnt, const int* __rest
 __global__ void __launch_bounds__(TPB) k_tr_sort_lists(const int* __restrict__ t_indptr, const int* __restrict__ t_unsorted,
                                                        const int* __restrict__ dst, LayerCounts* cnt, int cap_k, int cap_s,
                                                        int* __restrict__ t_edge, const int* __restrict__ cand_nid, int* local_id,
-                                                       int cap_c, const int* __restrict__ kept_nid, int* kept_map) {
+                                                       int cap_c, const int* __restrict__ kept_nid, int* kept_map, int do_cleanup) {
   extern __shared__ unsigned bm_all[];
-  maps_cleanup(cnt, cand_nid, local_id, cap_c, kept_nid, kept_map, cap_k);   // independent of the lists below
+  if (do_cleanup) maps_cleanup(cnt, cand_nid, local_id, cap_c, kept_nid, kept_map, cap_k);   // independent of the lists below
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int words = (cap_s + 31) / 32;
   unsigned* bm = bm_all + (size_t)wave * (words + 1);
@@ -1539,11 +1539,20 @@ int bliss_build_block(const bliss_graph_t* g, const bliss_node_maps_t* m, const 
     PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<true><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions, ws->w_pend));
   else
     PROF_LAUNCH(BK_BLOCK2, st, k_block_pass2<false><<<gc, TPB, 0, st>>>(g->indptr, g->indices, g->eid, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, m->local_id, ws->new_id, (const bf16_t*)ws->P, deg_blk, acc_wt, ws->chunk_cnt, out->src, out->dst, out->pos, out->eid, (bf16_t*)out->edge_weights, (bf16_t*)out->q_ij, sc, out->t_scratch, eta_f, one_minus_eta_f, out->cap_b, ws->kept_map, (const bf16_t*)ws->node_prob, seed_coef, kept_rec, ws->span_cnt, (long long)ws->kept_rec_positions, ws->w_pend));
-  if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
+  if (want_t && ws->block_ready_flag) {
+    // a consumer on another stream waits for the block itself (the forward pass): tell it before the by-source lists, which
+    // only the backward pass reads, are sorted; the dense maps go back to -1 first (the next sampler's layers reuse them)
+    PROF_LAUNCH(BK_CLEANUP, st, k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map, ws->cap_k));
+    k_flag_raise<<<1, 64, 0, st>>>(ws->block_ready_flag);
     const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
-    PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map));
+    PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map, 0));
+  } else if (want_t) {        // the by-source lists, and (same launch) the dense maps back to -1
+    const size_t lds = (size_t)(TPB / 64) * ((cap_s + 31) / 32 + 1) * sizeof(unsigned);
+    PROF_LAUNCH(BK_TRANSPOSE, st, k_tr_sort_lists<<<grid_for(ws->cap_k, TPB / 64), TPB, lds, st>>>(out->t_indptr, out->t_scratch, out->dst, cnt, ws->cap_k, cap_s, out->t_edge, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map, 1));
+    if (ws->block_ready_flag) k_flag_raise<<<1, 64, 0, st>>>(ws->block_ready_flag);
   } else {
     PROF_LAUNCH(BK_CLEANUP, st, k_cleanup<<<grid_for(ws->cap_c, TPB), TPB, 0, st>>>(cnt, ws->cand_nid, m->local_id, ws->cap_c, ws->kept_nid, ws->kept_map, ws->cap_k));
+    if (ws->block_ready_flag) k_flag_raise<<<1, 64, 0, st>>>(ws->block_ready_flag);
   }
   return (int)hipGetLastError();
 }

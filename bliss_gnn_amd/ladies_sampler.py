@@ -65,7 +65,7 @@ class LadiesSampler(BlockSampler):
             self._engine = LayerEngine(g)
         return self._engine
 
-    def sample_blocks_static(self, g, seed_nodes, slot=0, chain_rng=False, external_rng=False, part=None, last_block=True):
+    def sample_blocks_static(self, g, seed_nodes, slot=0, chain_rng=False, external_rng=False, part=None, last_block=True, ready_flag=0):
         if not self._poisson:
             raise NotImplementedError("the multinomial draw is torch.multinomial on the host: no static-shape variant")
         g = self._graph(g)
@@ -73,7 +73,7 @@ class LadiesSampler(BlockSampler):
         w_pos = g.edata_by_position(self.edge_weight)
         order = list(reversed(range(len(self.nodes_per_layer))))
         blks = eng.enqueue_static([w_pos] * len(order), seed_nodes, [self.nodes_per_layer[b] for b in order], self._mode(), 0.0,
-                                  self.eps, slot=slot, chain_rng=chain_rng, external_rng=external_rng, part=part, last_block=last_block)
+                                  self.eps, slot=slot, chain_rng=chain_rng, external_rng=external_rng, part=part, last_block=last_block, ready_flag=ready_flag)
         blocks = []
         for blk in blks:
             blk.edata[self.output_weight] = blk._edge_weights

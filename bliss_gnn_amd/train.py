@@ -344,9 +344,9 @@ class PipelinedTrainStep(GraphedTrainStep):
         self.g_blk0 = [None, None]
         self._blk0_done = torch.cuda.Event()
 
-    def _sample(self, slot, chain, external_rng=False, part=None, last_block=True):
+    def _sample(self, slot, chain, external_rng=False, part=None, last_block=True, ready_flag=0):
         return self.sampler.sample_blocks_static(self.g, self.seeds2[slot], slot=slot, chain_rng=chain, external_rng=external_rng,
-                                                 part=part, last_block=last_block)[2]
+                                                 part=part, last_block=last_block, ready_flag=ready_flag)[2]
 
     def _split_forward(self):
         # BLISS_SPLIT_FORWARD=0 keeps the whole forward pass ahead of the bandit update (the round-1 order)
@@ -564,8 +564,12 @@ class PipelinedTrainStep(GraphedTrainStep):
                 if self._defer_block0:
                     self.g_blk0[nxt] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.g_blk0[nxt]):
-                        self._sample(nxt, chain, external_rng=True, part="last_block")
-                        _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0, st_()), "bliss_flag_raise")
+                        # (raises FLAG_BLOCK0 itself, before it sorts the by-source index the backward pass will read)
+                        early = os.environ.get("BLISS_BLOCK0_EARLY_FLAG", "1") != "0"
+                        self._sample(nxt, chain, external_rng=True, part="last_block",
+                                     ready_flag=eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0 if early else 0)
+                        if not early:
+                            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0, st_()), "bliss_flag_raise")
                 with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
                     # B may start once S has (flag 0 is raised by the sampler's first kernel: F and X have completed)
                     _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr(), eng.flag_err.data_ptr(),
@@ -591,6 +595,10 @@ class PipelinedTrainStep(GraphedTrainStep):
         if not (self.use_flags and self._flag_boundary):
             main.wait_event(self._bwd_done)              # parameters after the previous step's Adam
         if self.use_flags:
+            if self._defer_block0:
+                # B(cur) reads the by-source index of its input block, sorted behind that block's ready flag in the PREVIOUS
+                # half's g_blk0 (this wait must precede the record further down, which is this half's)
+                side.wait_event(self._blk0_done)
             self.g_main[cur].replay()                    # F + X + S: one graph on the critical stream
             if self.g_norm is not None or self.g_blk[nxt] is not None:
                 with torch.cuda.stream(self.third):

@@ -109,6 +109,9 @@ typedef struct {
      other fs_* fields are then the fanout / eps / rng_ctl / uniforms_offset_dev / is_last / rng_cap_total arguments that
      bliss_poisson_select will be called with */
   int32_t* fs_ticket; int32_t fs_fanout, fs_is_last, fs_rng_cap, fs_reserved; double fs_eps; int32_t* fs_rng_ctl; int32_t* fs_layer_off;
+  int32_t* block_ready_flag; /* optional: bliss_build_block raises it (bliss_flag_wait's protocol) as soon as the block's forward
+                               arrays (indptr, src, dst, pos, eid, edge_weights, q_ij, counts) and the dense maps are final --
+                               before the by-source index, which only a backward pass reads, is sorted */
 } bliss_layer_ws_t;
 
 /* The block (MFG) of one layer, CSR by destination, edges in frontier order. */
