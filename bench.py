@@ -195,8 +195,8 @@ def main():
             step.calibrate(loader, steps=8)
             step.capture(loader, warmup=2, tune_gemm=args.tune_gemm)
             launch = ("one HIP graph per step" if args.no_pipeline else
-                      ("one HIP graph per step on the critical stream (forward + exp3 + sampling of batch t+1); backward+Adam of batch t "
-                       "and the early layers' blocks on two more streams, handed off through device flags") if step.use_flags else
+                      ("one HIP graph per step on the critical stream (forward up to the output layer's input + exp3 + sampling of batch t+1); "
+                       "output layer, loss, backward and Adam of batch t on a second stream, all block builds on a third, handed off through device flags") if step.use_flags else
                       "HIP graphs on two streams ordered by events (sampler | model); sampling of batch t+1 overlaps backward+Adam of batch t")
         except Exception as e:                       # e.g. a runtime that cannot capture collectives: launch kernel by kernel
             if world == 1:
