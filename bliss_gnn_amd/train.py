@@ -446,6 +446,10 @@ class PipelinedTrainStep(GraphedTrainStep):
     def capture(self, loader, warmup=2, tune_gemm=False):
         eng = self.sampler._bind(self.g)
         L = len(self.sampler.nodes_per_layer)
+        if torch.cuda.current_stream() != torch.cuda.default_stream():
+            import warnings
+            warnings.warn("PipelinedTrainStep: captured from a non-default stream; HIP maps streams onto a few hardware queues and the "
+                          "critical chain then shares one with a side stream (measured 1.08 instead of 0.70 ms per step)")
         if self.use_flags and not self._flags_usable():       # (before the warm-up: autograd remembers the streams it ran on)
             import warnings
             warnings.warn("PipelinedTrainStep: streams do not run side by side here (a profiler serialising kernels?); "
