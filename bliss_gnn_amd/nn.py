@@ -239,7 +239,7 @@ class _SageLinearPair(torch.autograd.Function):
         if dy is not None:
             dy = _bf16c(dy)
             d_ws = _weight_grad(dy, rows[: ctx.n_dst])
-            d_b = dy.sum(0) if ctx.has_bias else None
+            d_b = _bias_grad(dy) if ctx.has_bias else None
             if want_dx:
                 if dx is None:
                     dx = torch.zeros_like(rows)
@@ -249,13 +249,29 @@ class _SageLinearPair(torch.autograd.Function):
         return dx, None, d_wn, d_ws, d_b, None, None, None, None
 
 
+_ones_rows = {}
+
+
+def _bias_grad(d):
+    """d.sum(0) (the bias gradient of a Linear layer) as a [1, rows] x [rows, out] product with a row of ones: fp32 accumulation,
+    one rounding, like aten::sum -- which runs this tall reduction as a memset plus an atomic kernel (15.7 vs 9.8 us for
+    5 K x 256, 11.7 vs 6.5 for 2 K x 256; scratch/biasbench.py)."""
+    if not (d.is_cuda and d.dim() == 2 and d.shape[0] >= 1024):
+        return d.sum(0)
+    key = (d.device.index, d.dtype)
+    buf = _ones_rows.get(key)
+    if buf is None or buf.shape[1] < d.shape[0]:
+        buf = _ones_rows[key] = torch.ones(1, max(d.shape[0], 16384), dtype=d.dtype, device=d.device)
+    return (buf[:, : d.shape[0]] @ d)[0]
+
+
 def _weight_grad(d, x, split=4):
     """d.t() @ x for a long reduction (thousands of block rows) and a small result (out x in features): the library runs it on
     out/64 x in/64 = 40 workgroups, a sixth of the chip.  Split the rows into ``split`` batches (fp32 partial products, one
     rounding at the end: the bits of the plain call): 44 -> 32 us for 11 K x 256 x 602, 22.5 -> 19.6 for 5 K rows
     (scratch/dwbench.py, graph replay)."""
     R = d.shape[0]
-    if R < 4096 or x.shape[1] < 512 or R % split or not d.is_cuda:
+    if R < 8192 or x.shape[1] < 512 or R % split or not d.is_cuda:       # (in the loop the 5 K-row product is no faster split)
         return d.t() @ x
     p = torch.bmm(d.view(split, R // split, d.shape[1]).transpose(1, 2), x.reshape(split, R // split, x.shape[1]), out_dtype=torch.float32)
     return p.sum(0).to(d.dtype)
@@ -290,7 +306,7 @@ class _SageDualLinear(torch.autograd.Function):
                                                         out.shape[1], ctx.p, din.data_ptr(), din.stride(0), _stream()),
                        "bliss_sage_epilogue_bwd")
             d = din
-        return (d @ w1, d @ w2, d.t() @ a1, d.t() @ a2, d.sum(0) if ctx.has_bias else None, None, None, None, None, None, None)
+        return (d @ w1, d @ w2, d.t() @ a1, d.t() @ a2, _bias_grad(d) if ctx.has_bias else None, None, None, None, None, None, None)
 
 
 class _SageAggDual(torch.autograd.Function):
@@ -332,7 +348,7 @@ class _SageAggDual(torch.autograd.Function):
             gh = ops.spmm_t(t_indptr, t_edge, src, dst, indptr, w, d @ w1, h.shape[0], counts, True)
             gh[: ctx.n_dst].addmm_(d, w2)
         return (gh, None, None, None, None, None, None, None, None, d.t() @ agg, d.t() @ h[: ctx.n_dst],
-                d.sum(0) if ctx.has_bias else None, None, None, None, None, None)
+                _bias_grad(d) if ctx.has_bias else None, None, None, None, None, None)
 
 
 def sage_agg_dual(block, h, edge_weight, w_neigh, w_self, bias, relu, p, ctr, seed, rows_dev):
