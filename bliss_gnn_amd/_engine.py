@@ -42,7 +42,7 @@ class _LayerWs:
     def __init__(self, dev, cap_s, cap_c):
         self.cap_s, self.cap_c = cap_s, cap_c
         self.seg_ptr = torch.empty(cap_s + 1, dtype=torch.int32, device=dev)
-        self.seed_acc = torch.empty(56 * cap_s, dtype=torch.uint8, device=dev)
+        self.seed_acc = torch.empty(60 * cap_s + 64, dtype=torch.uint8, device=dev)    # 7 x u64 per seed + k_seg_scan's long-column list
         self.cand_nid = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.new_id = torch.empty(cap_c, dtype=torch.int32, device=dev)
         self.p = torch.empty(cap_c, dtype=torch.bfloat16, device=dev)

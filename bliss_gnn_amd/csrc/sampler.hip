@@ -39,6 +39,7 @@ namespace {
 // ordered ranks come from ballots + one 4-entry LDS exchange per chunk instead of a block scan per item.
 #define SPAN (64 * ITEMS)
 #define SEG_ZERO_WGS 8
+#define LONG_COL 1024                     // = COL_BIG below: columns longer than this get a workgroup in k_col_sums
 
 struct EdgeAt {
   int k;          // seed index (local destination id); valid iff e < E
@@ -105,7 +106,10 @@ __device__ __forceinline__ void seg_scan_body(const int64_t* __restrict__ indptr
   // This kernel runs <=> everything enqueued before this layer has completed (stream / graph order): tell a consumer on
   // another stream (bliss_flag_wait) without an event, i.e. without cutting a captured graph in two.
   if (entry_flag && wg == 0 && threadIdx.x == 0) __hip_atomic_store(entry_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (hub_count && wg == n_wgs - 1 && threadIdx.x == 0) *hub_count = 0;      // k_col_sums' hub list starts empty
+  // hub_count (optional): int[cap_s + 1] -- the columns of more than COL_BIG edges, in no particular order, count last: k_col_sums
+  // gives each of them a workgroup without walking over the short ones
+  __shared__ int sh_long;
+  if (hub_count && threadIdx.x == 0) sh_long = 0;     // (appended to behind the first block_excl_scan's barriers)
   int S = S_host >= 0 ? S_host : *S_dev;
   int bad = 0;
   if (S > cap_s) { S = cap_s; bad |= BLISS_ERR_CAP_SEEDS; }         // clamp: results invalid but in bounds
@@ -150,6 +154,16 @@ __device__ __forceinline__ void seg_scan_body(const int64_t* __restrict__ indptr
         // what every frontier pass needs to find its edges without a search and without chasing seeds -> indptr:
         col_base[k] = deg > 0 ? cols[i] - start : 0;    // CSC position = col_base[k] + frontier position
       }
+      if (hub_count) {
+        const bool is_long = k < S && deg > LONG_COL;
+        const unsigned long long mask = __ballot(is_long);
+        if (mask) {
+          int base_l = 0;
+          if (lane_id() == 0) base_l = atomicAdd(&sh_long, __popcll(mask));
+          base_l = __shfl(base_l, 0);
+          if (is_long) hub_count[base_l + __popcll(mask & ((1ull << lane_id()) - 1ull))] = k;
+        }
+      }
       // span_seg[sp] = the seed column holding frontier position sp * 256.  Done by the whole workgroup over the round's
       // spans (a search in the round's 1024 column starts), not by every thread over its own column: a hub column of 30 K
       // edges has > 100 spans, and a round used to wait for the thread that owned it.
@@ -172,6 +186,7 @@ __device__ __forceinline__ void seg_scan_body(const int64_t* __restrict__ indptr
   }
   int any_bad = __syncthreads_or(bad);
   if (threadIdx.x == 0) {
+    if (hub_count) hub_count[cap_s] = sh_long;
     seg_ptr[S] = (int)run;
     cnt->S = S; cnt->E = (any_bad & BLISS_ERR_CAP_FRONTIER) ? 0 : (int)run;
     cnt->C = 0; cnt->K = 0; cnt->B = 0; cnt->iters = 0; cnt->all_one = 0; cnt->c = 1.0;
@@ -441,6 +456,7 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_finalize(const int* __restrict
 #define COL_RB 8
 #endif
 #define COL_BIG (COL_R * 64)              // a wave keeps a whole column of up to 1024 edges in registers
+static_assert(LONG_COL == COL_BIG, "k_seg_scan lists the columns k_col_sums treats as long");
 #ifndef BINRED_TPB
 #define BINRED_TPB 1024          // one workgroup per bin, 256 bins: 16 waves per CU (512: 23.1 us per launch, 1024: 21.0, 256: 28.1)
 #endif
@@ -493,7 +509,8 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
                                                       const long long* __restrict__ col_base, const int* __restrict__ span_seg,
                                                       LayerCounts* cnt, unsigned long long* __restrict__ acc_w,
                                                       unsigned long long* __restrict__ acc_q, float eta_f, float ome_f,
-                                                      uint2* __restrict__ seed_coef, int n_wave_wgs, const int* __restrict__ w_pend) {
+                                                      uint2* __restrict__ seed_coef, int n_wave_wgs, const int* __restrict__ w_pend,
+                                                      const int* __restrict__ long_list, int cap_s) {
   int pend;                                                 // a deferred F.normalize pass over this row (bliss_exp3_step_deferred)
   const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
@@ -544,9 +561,10 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
   }
   // ---- the long columns: one per workgroup, the first COL_RB * COL_TPB edges held in registers between the two sums
   if ((int)blockIdx.x >= n_wave_wgs)
-  for (int k = (int)blockIdx.x - n_wave_wgs; k < S; k += n_block_wgs) {
+  for (int li = (int)blockIdx.x - n_wave_wgs, n_long = long_list[cap_s]; li < n_long; li += n_block_wgs) {
+    const int k = long_list[li];                      // (k_seg_scan's list: no workgroup walks over short columns)
     const int s0 = seg_ptr[k], n = seg_ptr[k + 1] - s0;
-    if (n <= COL_BIG) continue;                       // block-uniform
+    if (n <= COL_BIG) continue;                       // block-uniform (cannot happen: the list holds exactly the long ones)
     const long long p0 = col_base[k] + s0;
     bf16_t wr[COL_RB];
     long long part = 0;
@@ -1417,10 +1435,11 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
   const long long fcap = (long long)(g->num_edges < 0x7fffffffll ? g->num_edges : 0x7fffffffll);
   // the bandit's column sums write the first two per-seed accumulators themselves: the scan's zeroing leaves them alone
   const bool col_sums = binned && mode == BLISS_MODE_BANDIT;
+  int* long_list = (int*)(acc_w + 7 * (size_t)cap_s);                      // [cap_s + 1], written by k_seg_scan
   PROF_LAUNCH(BK_SEG_SCAN, st, k_seg_scan<<<1 + SEG_ZERO_WGS, 1024, 0, st>>>(g->indptr, seeds, cnt, n_seeds, n_seeds_dev, cap_s, acc_w, ws->seg_ptr,
                                                             m->local_id, g->num_nodes, ws->src_cnt, ws->cap_k,
                                                             binned ? ws->bin_cursor : nullptr, ws->n_bins, (long long*)col_base, ws->span_seg,
-                                                            fcap, ws->entry_flag, col_sums ? 1 : 0, nullptr));
+                                                            fcap, ws->entry_flag, col_sums ? 1 : 0, col_sums ? long_list : nullptr));
   if (binned) {
     unsigned long long* seed_p2 = acc_w + 4 * (size_t)cap_s;
     uint2* seed_coef = (uint2*)(acc_w + 6 * (size_t)cap_s);               // [cap_s], written by k_col_sums
@@ -1428,7 +1447,7 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     const int gb = grid_for(frontier_bound, BIN_BATCH);
     const int n_wave_wgs = grid_for(cap_s, COL_TPB / 64, 2048);
     if (col_sums)                                        // (the block passes need sum_j w_ij even when p_j does not)
-      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs, ws->w_pend));
+      PROF_LAUNCH(BK_COL_SUMS, st, k_col_sums<<<n_wave_wgs + (cap_s < 2048 ? cap_s : 2048), COL_TPB, 0, st>>>(g->indptr, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, seed_coef, n_wave_wgs, ws->w_pend, long_list, cap_s));
     if (mode == BLISS_MODE_BANDIT)
       PROF_LAUNCH(BK_BIN_SCATTER, st, k_bin_scatter<true><<<gb, BIN_TPB, 0, st>>>(g->indptr, g->indices, w, seeds, ws->seg_ptr, col_base, ws->span_seg, cnt, acc_w, acc_q, eta_f, one_minus_eta_f, uniform_nodes, ws->n_bins, log2_bins, ws->bin_cap, ws->bin_cursor, bin_rec, ws->bitmap, seed_coef, ws->w_pend));
     else
