@@ -1771,6 +1771,51 @@ def test_sage_mfma_path_matches_unfused_path(cuda, monkeypatch):
     assert float((a.float() - c.float()).abs().max()) <= 3 * 2.0 ** -8 * scale
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_sage_forward_split_is_the_forward_pass(cuda, monkeypatch, mfma):
+    """forward == forward_last(forward_hidden): the pipelined loop runs the two halves on different streams (the bandit update
+    needs nothing the output layer computes); same logits, same row norms on every block, same parameter gradients, bit for bit."""
+    from bliss_gnn_amd.model import SAGE
+    from bliss_gnn_amd.synth import chung_lu_csc
+    bg = _bg()
+    monkeypatch.setenv("BLISS_SAGE_MFMA", mfma)
+    ip, ix, ei = chung_lu_csc(5000, 90000, seed=23)
+    feats = torch.randn(5000, 120, generator=torch.Generator().manual_seed(1)).bfloat16().to(cuda)
+    g = bg.Graph(ip.to(cuda), ix.to(cuda), ei.to(cuda), ndata={"features": feats})
+    g.edata["w"] = bg.normalized_edata(g)
+    torch.manual_seed(3)
+    _, _, blocks = bg.PoissonBanditLadiesSampler([300, 200, 100], eta=0.1).sample_blocks(g, torch.arange(48, dtype=torch.int32, device=cuda))
+    torch.manual_seed(0)
+    model = SAGE(120, 64, 7, 3, torch.relu, 0.0).to(cuda).bfloat16()
+    outs = []
+    for split in (False, True):
+        model.zero_grad(set_to_none=True)
+        x = blocks[0].srcdata.lazy("features")
+        out = model.forward_last(blocks, model.forward_hidden(blocks, x)) if split else model(blocks, x)
+        out.float().square().sum().backward()
+        outs.append((out.detach().clone(), [b.srcdata["embed_norm"].clone() for b in blocks], [p.grad.clone() for p in model.parameters()]))
+    (a, na, ga), (b, nb, gb) = outs
+    assert torch.equal(a, b)
+    assert all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in zip(na, nb))
+    assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+
+
+def test_weight_and_bias_gradient_helpers(cuda):
+    """nn._weight_grad (d^T x over four row batches with fp32 partials) and nn._bias_grad (ones-row product) against the fp32
+    products / column sums: one bf16 rounding of an fp32 accumulation, like the calls they replace."""
+    from bliss_gnn_amd import nn as bnn
+    gen = torch.Generator().manual_seed(5)
+    d = torch.randn(8192, 256, generator=gen).bfloat16().to(cuda)
+    x = torch.randn(8192, 602, generator=gen).bfloat16().to(cuda)
+    for got, ref, mag in ((bnn._weight_grad(d, x), d.float().t() @ x.float(), d.float().abs().t() @ x.float().abs()),
+                          (bnn._bias_grad(d), d.float().sum(0), d.float().abs().sum(0)),
+                          (bnn._weight_grad(d[:1000], x[:1000]), d[:1000].float().t() @ x[:1000].float(), None),
+                          (bnn._bias_grad(d[:100]), d[:100].float().sum(0), None)):
+        assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+        tol = ref.abs() * 2.0 ** -7 + (2e-6 * mag if mag is not None else 2.0 ** -7)
+        assert bool(((got.float() - ref).abs() <= tol).all())
+
+
 def test_capacity_regrow_keeps_the_run_valid(cuda):
     """Static capacities calibrated with NO margin overflow as soon as a batch is a little larger than the calibration
     batches.  The pipelined loop watches the sizes that come back with every pair and re-captures with larger capacities
