@@ -721,6 +721,19 @@ class PipelinedTrainStep(GraphedTrainStep):
         return [primed] + self.sizes2()                   # every batch sampled here, in sampling order
 
     def run(self, loader, n_pairs, ring=4, pair_events=None):
+        # The host stays a few pairs ahead of the device; a generation-2 garbage collection in the middle of the loop can take
+        # longer than that lead and drain the queues (one pair of > 3 ms in some 400-step windows): not during the loop.
+        import gc
+        was_enabled = gc.isenabled()
+        if was_enabled:
+            gc.disable()
+        try:
+            return self._run(loader, n_pairs, ring, pair_events)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _run(self, loader, n_pairs, ring=4, pair_events=None):
         """``n_pairs`` calls without a host round trip in between: the generator state is chained on the device from
         batch to batch (torch's CPU generator is brought up to date once, at the end), and sizes / error words come back
         through a small ring of pinned buffers while later pairs are already running.  Returns the block sizes of every
