@@ -12,28 +12,35 @@ namespace {
 
 #define CE_TPB 256
 
-__global__ void __launch_bounds__(CE_TPB) k_cross_entropy(const bf16_t* __restrict__ logits, long long stride, const long long* __restrict__ labels,
+// logits2 (optional): the logits are bf16(logits + logits2), the output layer's `rst = fc_self + h_neigh` (model.py:321-329) taken
+// in here instead of an element-wise launch; label_ids (optional): row r's label is labels[label_ids[r]], the gather of
+// train_lightning.py:139 (mfgs[-1].dstdata['labels']) likewise
+__global__ void __launch_bounds__(CE_TPB) k_cross_entropy(const bf16_t* __restrict__ logits, long long stride, const bf16_t* __restrict__ logits2,
+                                                          long long stride2, const long long* __restrict__ labels,
+                                                          const int* __restrict__ label_ids,
                                                           int n_rows, int n_cls, float* __restrict__ row_loss, bf16_t* __restrict__ dlogits,
                                                           long long d_stride, float* __restrict__ loss_out, unsigned* ticket, int* err) {
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const float inv_n = 1.0f / (float)n_rows;
   for (int r = blockIdx.x * (CE_TPB / 64) + wave; r < n_rows; r += gridDim.x * (CE_TPB / 64)) {
-    const bf16_t* x = logits + (long long)r * stride;
+    const bf16_t* x1 = logits + (long long)r * stride;
+    const bf16_t* x2 = logits2 ? logits2 + (long long)r * stride2 : nullptr;
+    auto X = [&](int c) { return x2 ? rbf(bf2f(x1[c]) + bf2f(x2[c])) : bf2f(x1[c]); };
     float m = -__builtin_inff();
-    for (int c = lane; c < n_cls; c += 64) m = fmaxf(m, bf2f(x[c]));
+    for (int c = lane; c < n_cls; c += 64) m = fmaxf(m, X(c));
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     float s = 0.f;
-    for (int c = lane; c < n_cls; c += 64) s += __expf(bf2f(x[c]) - m);
+    for (int c = lane; c < n_cls; c += 64) s += __expf(X(c) - m);
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    const long long y = labels[r];
+    const long long y = labels[label_ids ? (long long)label_ids[r] : (long long)r];
     const bool ok = y >= 0 && y < n_cls;
     if (!ok && lane == 0) atomicOr(err, BLISS_ERR_CAP_CAND);            // label out of range (torch raises a device assert)
     const float lse = m + __logf(s);
-    if (lane == 0) row_loss[r] = ok ? lse - bf2f(x[y]) : 0.f;
+    if (lane == 0) row_loss[r] = ok ? lse - X((int)y) : 0.f;
     const float inv_s = 1.0f / s;
     bf16_t* g = dlogits + (long long)r * d_stride;
     for (int c = lane; c < n_cls; c += 64) {
-      const float p = __expf(bf2f(x[c]) - m) * inv_s;
+      const float p = __expf(X(c) - m) * inv_s;
       g[c] = f2bf((p - ((ok && c == (int)y) ? 1.0f : 0.0f)) * inv_n);
     }
   }
@@ -64,13 +71,27 @@ __global__ void __launch_bounds__(CE_TPB) k_cross_entropy(const bf16_t* __restri
 
 }  // namespace
 
-extern "C" int bliss_cross_entropy(const void* logits, int64_t stride, const int64_t* labels, int32_t n_rows, int32_t n_cls,
-                                   float* row_loss, void* dlogits, int64_t d_stride, float* loss_out, uint32_t* ticket, int32_t* err,
-                                   void* stream) {
+static int ce_launch(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* labels, const int32_t* label_ids,
+                     int32_t n_rows, int32_t n_cls, float* row_loss, void* dlogits, int64_t d_stride, float* loss_out, uint32_t* ticket,
+                     int32_t* err, void* stream) {
   if (!logits || !labels || !row_loss || !dlogits || !loss_out || !ticket || !err || n_rows <= 0 || n_cls <= 0) return BLISS_EINVAL;
   int grid = (n_rows + CE_TPB / 64 - 1) / (CE_TPB / 64);
   if (grid > 1024) grid = 1024;
-  k_cross_entropy<<<grid, CE_TPB, 0, (hipStream_t)stream>>>((const bf16_t*)logits, stride, (const long long*)labels, n_rows, n_cls, row_loss,
-                                                            (bf16_t*)dlogits, d_stride, loss_out, ticket, err);
+  k_cross_entropy<<<grid, CE_TPB, 0, (hipStream_t)stream>>>((const bf16_t*)logits, stride, (const bf16_t*)logits2, stride2, (const long long*)labels,
+                                                            label_ids, n_rows, n_cls, row_loss, (bf16_t*)dlogits, d_stride, loss_out, ticket, err);
   return (int)hipGetLastError();
+}
+
+extern "C" int bliss_cross_entropy(const void* logits, int64_t stride, const int64_t* labels, int32_t n_rows, int32_t n_cls,
+                                   float* row_loss, void* dlogits, int64_t d_stride, float* loss_out, uint32_t* ticket, int32_t* err,
+                                   void* stream) {
+  return ce_launch(logits, stride, nullptr, 0, labels, nullptr, n_rows, n_cls, row_loss, dlogits, d_stride, loss_out, ticket, err, stream);
+}
+
+extern "C" int bliss_cross_entropy_sum(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* label_table,
+                                       const int32_t* label_ids, int32_t n_rows, int32_t n_cls, float* row_loss, void* dlogits,
+                                       int64_t d_stride, float* loss_out, uint32_t* ticket, int32_t* err, void* stream) {
+  if (!logits2 && !label_ids) return BLISS_EINVAL;
+  return ce_launch(logits, stride, logits2, stride2, label_table, label_ids, n_rows, n_cls, row_loss, dlogits, d_stride, loss_out, ticket, err,
+                   stream);
 }

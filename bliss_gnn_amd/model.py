@@ -66,7 +66,7 @@ class SAGE(nn.Module):
                    and l.feat_drop.p == 0 for l in self.layers)
         return relu and dims and x.is_cuda and x.dtype == torch.bfloat16 and isinstance(self.dropout, nn.Dropout)
 
-    def _layers_mfma(self, blocks, h, norm, lo, hi):
+    def _layers_mfma(self, blocks, h, norm, lo, hi, parts=False):
         """model.py:312-333, layers lo..hi-1, with the Linear layers on hand-written MFMA tiles: per W-first layer ONE launch
         for fc_neigh + fc_self (+ the feature gather and the input norms), per aggregate-first layer ONE launch for both
         Linears, the bias, ReLU, dropout and the next layer's norms.  The aggregation stays the merge-style SpMM of
@@ -89,7 +89,7 @@ class SAGE(nn.Module):
                 block.srcdata["embed_norm"] = in_norm if norm is None else norm  # model.py:318-320 (same bits either way)
                 agg = weighted_aggregate(block, z, ew, mean=True)
                 if last:
-                    h, norm = y + agg, None
+                    h, norm = ((y, agg) if parts else y + agg), None          # (parts: the loss kernel adds them itself)
                 else:
                     h, norm = sage_epilogue(y, agg, p, ctr, seed)
             else:
@@ -157,6 +157,16 @@ class SAGE(nn.Module):
         h, norm, mfma = hidden
         n = len(self.layers)
         return self._layers(blocks, h, norm, n - 1, n, mfma)[0]
+
+    def forward_last_parts(self, blocks, hidden):
+        """forward_last as the two addends of ``rst = fc_self + h_neigh`` (model.py:321-329) when the output layer runs
+        fc_neigh before the aggregation on the fused path (the loss kernel then adds them itself); else None."""
+        h, norm, mfma = hidden
+        n = len(self.layers)
+        layer = self.layers[n - 1]
+        if not (mfma and layer._in_src_feats > layer._out_feats):
+            return None
+        return self._layers_mfma(blocks, h, norm, n - 1, n, parts=True)[0]
 
     @torch.no_grad()
     def inference(self, g, device=None, batch_size=128, use_uva=False, num_workers=0, node_chunk=16384):

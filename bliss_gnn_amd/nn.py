@@ -115,13 +115,21 @@ class _CrossEntropy(torch.autograd.Function):
         return dx * g.to(dx.dtype), None, None
 
 
-def _ce_launch(x, labels, state):
+def _ce_launch(x, labels, state, x2=None, label_ids=None):
     n, c = x.shape
     dx = torch.empty(n, c, dtype=torch.bfloat16, device=x.device)
     rows = torch.empty(n, dtype=torch.float32, device=x.device)
     loss = torch.empty((), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib.bliss_cross_entropy(x.data_ptr(), x.stride(0), labels.data_ptr(), n, c, rows.data_ptr(), dx.data_ptr(), dx.stride(0),
-                                            loss.data_ptr(), state.data_ptr(), state.data_ptr() + 4, _stream()), "bliss_cross_entropy")
+    if x2 is None and label_ids is None:
+        _lib.check(_lib.lib.bliss_cross_entropy(x.data_ptr(), x.stride(0), labels.data_ptr(), n, c, rows.data_ptr(), dx.data_ptr(),
+                                                dx.stride(0), loss.data_ptr(), state.data_ptr(), state.data_ptr() + 4, _stream()),
+                   "bliss_cross_entropy")
+    else:
+        _lib.check(_lib.lib.bliss_cross_entropy_sum(x.data_ptr(), x.stride(0), 0 if x2 is None else x2.data_ptr(),
+                                                    0 if x2 is None else x2.stride(0), labels.data_ptr(),
+                                                    0 if label_ids is None else label_ids.data_ptr(), n, c, rows.data_ptr(), dx.data_ptr(),
+                                                    dx.stride(0), loss.data_ptr(), state.data_ptr(), state.data_ptr() + 4, _stream()),
+                   "bliss_cross_entropy_sum")
     return loss, dx
 
 
@@ -152,6 +160,21 @@ class CrossEntropyLoss(nn.Module):
         x = logits.detach()
         loss, dx = _ce_launch(x if x.stride(1) == 1 else x.contiguous(), target.contiguous(), self._state)
         logits.backward(dx)
+        return loss
+
+    def backward_from_parts(self, a, b, label_table, label_ids):
+        """backward_from for logits = a + b that are never formed (the output layer's fc_self + h_neigh) and labels
+        = label_table[label_ids] that are never gathered: one launch, then the same gradient into both addends."""
+        ok = (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape and a.dim() == 2
+              and a.stride(1) == 1 and b.stride(1) == 1 and label_table.dtype == torch.int64 and label_table.dim() == 1
+              and label_table.is_contiguous() and label_ids.dtype == torch.int32 and label_ids.is_contiguous()
+              and label_ids.numel() == a.shape[0])
+        if not ok:
+            return self.backward_from(a + b, torch.index_select(label_table, 0, label_ids.long()))
+        if getattr(self, "_state", None) is None or self._state.device != a.device:
+            self._state = torch.zeros(2, dtype=torch.int32, device=a.device)
+        loss, dx = _ce_launch(a.detach(), label_table, self._state, x2=b.detach(), label_ids=label_ids)
+        torch.autograd.backward([a, b], [dx, dx])
         return loss
 
 

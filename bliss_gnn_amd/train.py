@@ -390,8 +390,18 @@ class PipelinedTrainStep(GraphedTrainStep):
     def _backward(self, pending):
         """Output layer + loss (when _forward left them), backward, optimizer.  Returns the detached loss."""
         kind, val, mfgs = pending
-        pred = self.model.forward_last(mfgs, val) if kind == "hidden" else val
-        loss = _loss_backward(self.loss_fn, pred, mfgs[-1].dstdata["labels"], self.opt)
+        loss = None
+        if kind == "hidden" and hasattr(self.model, "forward_last_parts") and hasattr(self.loss_fn, "backward_from_parts"):
+            # output layer's sum and the label gather inside the loss kernel (two small launches less on the backward stream)
+            lab = mfgs[-1].dstdata
+            table = lab._parent["labels"] if getattr(lab, "_parent", None) is not None and "labels" in lab._parent else None
+            parts = self.model.forward_last_parts(mfgs, val) if table is not None and not dict.__contains__(lab, "labels") else None
+            if parts is not None:
+                self.opt.zero_grad(set_to_none=True)
+                loss = self.loss_fn.backward_from_parts(parts[0], parts[1], table, lab._index_fn())
+        if loss is None:
+            pred = self.model.forward_last(mfgs, val) if kind == "hidden" else val
+            loss = _loss_backward(self.loss_fn, pred, mfgs[-1].dstdata["labels"], self.opt)
         if self.distributed:
             from . import dist as bdist
             bdist.allreduce_gradients(self.model)

@@ -266,6 +266,13 @@ int bliss_tile_gemm(const bliss_tile_gemm_t* first, const bliss_tile_gemm_t* sec
 int bliss_cross_entropy(const void* logits, int64_t stride, const int64_t* labels, int32_t n_rows, int32_t n_cls,
                         float* row_loss, void* dlogits, int64_t d_stride, float* loss_out, uint32_t* ticket, int32_t* err,
                         void* stream);
+/* The same with the two launches in front of it taken in: logits2 != NULL: the logits are bf16(logits + logits2) -- the output
+ * layer's `rst = fc_self + h_neigh` (model.py:321-329); dlogits is then the gradient of both addends.  label_ids != NULL: row r's
+ * label is label_table[label_ids[r]] -- mfgs[-1].dstdata['labels'] (train_lightning.py:139) without the gather.  At least one
+ * of the two must be given. */
+int bliss_cross_entropy_sum(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* label_table,
+                            const int32_t* label_ids, int32_t n_rows, int32_t n_cls, float* row_loss, void* dlogits, int64_t d_stride,
+                            float* loss_out, uint32_t* ticket, int32_t* err, void* stream);
 
 /* th.optim.Adam(self.parameters(), lr) (train_lightning.py:205-206) for a bf16 module: parameters, gradients and both moment
  * buffers bf16, one launch over all tensors, math in fp32, one rounding per stored value.  state: float[4] on the device --

@@ -1879,3 +1879,25 @@ def test_one_launch_cross_entropy_vs_torch(cuda, n, c):
     x2 = x.detach().clone().requires_grad_()
     (CrossEntropyLoss()(x2, y) * 0.5).backward()                          # a non-unit incoming gradient
     assert torch.allclose(x2.grad.float(), 0.5 * xr.grad, rtol=2.0 ** -6, atol=2e-6)
+
+
+def test_cross_entropy_with_sum_and_label_gather_inside(cuda):
+    """bliss_cross_entropy_sum (the output layer's `fc_self + h_neigh` and the gather of the batch's labels taken into the loss
+    kernel) == the plain kernel on the materialised sum and labels: same loss bits, same gradient bits, delivered to both
+    addends."""
+    from bliss_gnn_amd.nn import CrossEntropyLoss
+    gen = torch.Generator().manual_seed(7)
+    n, c, V = 256, 41, 5000
+    a = (torch.randn(n, c, generator=gen) * 3).bfloat16().to(cuda).requires_grad_(True)
+    b = (torch.randn(n, c, generator=gen) * 3).bfloat16().to(cuda).requires_grad_(True)
+    table = torch.randint(0, c, (V,), generator=gen).to(cuda)
+    ids = torch.randperm(V, generator=gen)[:n].to(torch.int32).to(cuda)
+    lf = CrossEntropyLoss()
+    l1 = lf.backward_from_parts(a, b, table, ids)
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    s = (a + b)
+    l2 = lf.backward_from(s, table[ids.long()])
+    assert torch.equal(l1, l2)
+    assert torch.equal(ga, a.grad) and torch.equal(gb, b.grad) and torch.equal(ga, gb)
+
