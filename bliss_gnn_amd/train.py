@@ -730,7 +730,7 @@ class PipelinedTrainStep(GraphedTrainStep):
         self._capture_graphs(loader)
         return [primed] + self.sizes2()                   # every batch sampled here, in sampling order
 
-    def run(self, loader, n_pairs, ring=4, pair_events=None):
+    def run(self, loader, n_pairs, ring=8, pair_events=None):
         # The host stays a few pairs ahead of the device; a generation-2 garbage collection in the middle of the loop can take
         # longer than that lead and drain the queues (one pair of > 3 ms in some 400-step windows): not during the loop.
         import gc
@@ -743,7 +743,7 @@ class PipelinedTrainStep(GraphedTrainStep):
             if was_enabled:
                 gc.enable()
 
-    def _run(self, loader, n_pairs, ring=4, pair_events=None):
+    def _run(self, loader, n_pairs, ring=8, pair_events=None):
         """``n_pairs`` calls without a host round trip in between: the generator state is chained on the device from
         batch to batch (torch's CPU generator is brought up to date once, at the end), and sizes / error words come back
         through a small ring of pinned buffers while later pairs are already running.  Returns the block sizes of every
