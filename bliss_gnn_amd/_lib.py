@@ -149,6 +149,7 @@ SIGNATURES = {
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],
     "bliss_gat_logits": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
+    "bliss_gat_logits_f32": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
     "bliss_gat_edge_dot": [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _P, _P],
     "bliss_gat_edge_softmax": [_P, _I32, _P, _P, _I32, C.c_int, _P, _P],
     "bliss_gat_rows": [C.c_int, _P, _I32, _P, _P, _P, _P, _I32, _P, _P, _I64, _P, _I32, _I32, _F, _P, _I64, _P, _P, _P],

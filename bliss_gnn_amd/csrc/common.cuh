@@ -97,8 +97,80 @@ __device__ __forceinline__ bf16_t fixed_to_bf(int64_t n, int frac, int* bad) {
     q = mag << (7 - msb);
   }
   int e = msb - frac + 127;
+  if (msb - frac + 127 <= 0) {
+    // below the normal range (only the block-floating column sums get here: frac > 126): round at the subnormal spacing
+    // 2^-133 like IEEE (torch's CPU ops do not flush); q == 128 is the smallest normal number, same encoding
+    const int sh = frac - 133;
+    if (sh <= 0) return (bf16_t)(sign | (uint32_t)(mag << (-sh)));
+    uint64_t qs = sh > 63 ? 0 : mag >> sh;
+    if (sh <= 63) {
+      const uint64_t rem = mag & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+      if (rem > half || (rem == half && (qs & 1))) qs += 1;
+    }
+    return (bf16_t)(sign | (uint32_t)qs);
+  }
   if (q >= 256) { q >>= 1; e += 1; }
-  if (e <= 0 || e >= 255) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+  if (e >= 255) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+  return (bf16_t)(sign | ((uint32_t)e << 7) | ((uint32_t)q & 0x7f));
+}
+
+// ---- wide form of the two helpers above, for the one sum whose terms span bf16's whole range (sum_j w_ij of a seed column
+// once the bandit has concentrated a row, bandit_sampler.py:129).  Found by the long reference run of tests/golden
+// (collapse0_*): a column holding 0.4766, 0.4902 and a few weights around 1e-14 sums to a hair above a rounding tie; the
+// tiny terms fell below the accumulator's last bit, the sum looked like an exact tie and rounded to even -- the reference's
+// (exact) sum rounds up.  So the bits a term loses below the accumulator's unit go to a SECOND accumulator 40 bits finer,
+// and whatever falls below even that sets a sticky flag that breaks ties upward (all terms are >= 0).  The common case --
+// nothing lost anywhere in the column -- costs one ballot.
+__device__ __forceinline__ long long bf_to_fixed_wide(bf16_t b, int frac, long long* lo, int* sticky, int* bad) {
+  uint32_t e = (b >> 7) & 0xff, m = b & 0x7f;
+  if (e == 255) { *bad |= BLISS_ERR_NONFINITE; return 0; }
+  if (e == 0) e = 1; else m |= 0x80;
+  const int shift = (int)e - 134 + frac;
+  const bool neg = (b & 0x8000) != 0;
+  if (shift >= 0) {
+    if (shift > 55) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
+    const long long mag = (long long)((uint64_t)m << shift);
+    return neg ? -mag : mag;
+  }
+  const int rs = -shift;
+  const uint32_t top = rs >= 8 ? 0u : (m >> rs);
+  const uint32_t r = rs >= 8 ? m : (m & ((1u << rs) - 1u));          // the bits below the accumulator's unit
+  if (r) {
+    long long l;
+    if (rs <= 40) l = (long long)((uint64_t)r << (40 - rs));
+    else {
+      const int d = rs - 40;
+      l = d >= 8 ? 0 : (long long)(r >> d);
+      if (d >= 8 || (r & ((1u << d) - 1u))) *sticky = 1;
+    }
+    *lo += neg ? -l : l;
+  }
+  return neg ? -(long long)top : (long long)top;
+}
+
+// (hi * 2^40 + lo) * 2^-(frac + 40) -> bf16, round to nearest even on the EXACT value; sticky = more (positive) bits below
+__device__ __forceinline__ bf16_t fixed_wide_to_bf(int64_t hi, int64_t lo, int sticky, int frac, int* bad) {
+  if (lo == 0 && !sticky) return fixed_to_bf(hi, frac, bad);
+  __int128 t = ((__int128)hi << 40) + (__int128)lo;
+  if (t == 0) return 0;
+  const uint32_t sign = t < 0 ? 0x8000u : 0u;
+  const unsigned __int128 mag = t < 0 ? (unsigned __int128)(-t) : (unsigned __int128)t;
+  const uint64_t mh = (uint64_t)(mag >> 64), ml = (uint64_t)mag;
+  const int msb = mh ? 127 - __clzll((long long)mh) : 63 - __clzll((long long)ml);
+  const int f = frac + 40;
+  auto round_shift = [&](int sh) -> uint64_t {           // mag >> sh, nearest even, ties broken upward when sticky
+    if (sh <= 0) return (uint64_t)(mag << (-sh));
+    if (sh > 126) return 0;
+    uint64_t q = (uint64_t)(mag >> sh);
+    const unsigned __int128 rem = mag & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+    if (rem > half || (rem == half && (sticky || (q & 1)))) q += 1;
+    return q;
+  };
+  if (msb - f + 127 <= 0) return (bf16_t)(sign | (uint32_t)round_shift(f - 133));     // subnormal result (see fixed_to_bf)
+  uint64_t q = round_shift(msb - 7);
+  int e = msb - f + 127;
+  if (q >= 256) { q >>= 1; e += 1; }
+  if (e >= 255) { *bad |= BLISS_ERR_FIXED_RANGE; return 0; }
   return (bf16_t)(sign | ((uint32_t)e << 7) | ((uint32_t)q & 0x7f));
 }
 

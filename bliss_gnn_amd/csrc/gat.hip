@@ -8,7 +8,12 @@
 // kernel recomputes el+er on the fly from the two gathered rows, so only [B, H] logits/attention ever touch HBM.
 // Balanced traversal: a wave owns a fixed number of consecutive edges (like csrc/spmm.hip); row sums that cross
 // chunk boundaries go through fp32 partials and the shared fix-up kernel, so everything is deterministic.
-// fp32 math, bf16 storage (compared with an fp32 torch reference in tests/, tolerance stated there).
+// Arithmetic of the forward kernels (round 3): the reference runs this path as a chain of bf16 tensor ops, so every op
+// rounds (u_add_v, leaky_relu, * attn, the sum over D in fp32; e - max, exp, the per-destination sum, the division); the
+// kernels round at the same points (tests/golden/gat*_model_exp3.npz: a reference run of model.py's own forward), the
+// per-destination sum of the softmax is exact fixed point like every copy_e_sum (common.cuh), and the aggregation adds
+// fp32 products with one rounding.  F32 variants (no intermediate rounding, float outputs) exist for the north star's
+// 1e-4 check against fp32 math on the same bf16 operands.  The backward kernels differentiate the fp32 formulas.
 #include "common.cuh"
 #include "bliss_gnn.h"
 #include "prof.h"
@@ -34,17 +39,24 @@ __device__ __forceinline__ g4 gload4(const bf16_t* p) {
 }
 __device__ __forceinline__ int gb_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }    // wave-uniform lane index
 
-template <int MODE, bool VEC4>
+template <int MODE, bool VEC4, bool F32>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict__ src, const int* __restrict__ dst,
                                                          const int* __restrict__ nnz_dev, int nnz_host,
                                                          const bf16_t* __restrict__ feat, int64_t feat_stride,
                                                          const bf16_t* __restrict__ g, int64_t g_stride,
                                                          const bf16_t* __restrict__ attn, int H, int D, float slope,
-                                                         bf16_t* __restrict__ out) {
+                                                         void* __restrict__ out_v) {
+  bf16_t* out = (bf16_t*)out_v;
+  float* out32 = (float*)out_v;
   const int nnz = nnz_dev ? min(*nnz_dev, nnz_host) : nnz_host;
   const int lane = lane_id();
   const int chunk = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
   const int e0 = chunk * GAT_EC, e1 = min(nnz, e0 + GAT_EC);
+  // MODE 0, bf16 mode: model.py:82-86 op by op -- rbf(el + er), rbf(leaky_relu), rbf(* attn), fp32 sum over D, one rounding
+  auto term = [&](float t, float x, float y) -> float {
+    if (F32) return t * lrelu(x + y, slope);
+    return rbf(t * rbf(lrelu(rbf(x + y), slope)));
+  };
   const int HD = H * D;
   constexpr int W = VEC4 ? 4 : 1;
   // the chunk's endpoints once, coalesced; broadcast per edge with v_readlane
@@ -62,11 +74,11 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict_
         const g4 x = gload4(a + idx), y = gload4(b + idx);
         if (MODE == 0) {
           const g4 t = gload4(attn + idx);
-          v = t.x * lrelu(x.x + y.x, slope) + t.y * lrelu(x.y + y.y, slope) + t.z * lrelu(x.z + y.z, slope) + t.w * lrelu(x.w + y.w, slope);
+          v = term(t.x, x.x, y.x) + term(t.y, x.y, y.y) + term(t.z, x.z, y.z) + term(t.w, x.w, y.w);
         } else v = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
       } else {
         const float x = bf2f(a[idx]), y = bf2f(b[idx]);
-        v = MODE == 0 ? bf2f(attn[idx]) * lrelu(x + y, slope) : x * y;
+        v = MODE == 0 ? term(bf2f(attn[idx]), x, y) : x * y;
       }
       const int hd = idx / D;
 #pragma unroll
@@ -77,7 +89,7 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict_
       if (h < H) {
         float s = part[h];
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0) out[(int64_t)e * H + h] = f2bf(s);
+        if (lane == 0) { if (F32) out32[(int64_t)e * H + h] = s; else out[(int64_t)e * H + h] = f2bf(s); }
       }
     }
   }
@@ -87,20 +99,34 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_edge_dot(const int* __restrict_
 //   FWD: a = exp(e - max) / sum                      BWD: de = a * (da - sum_e' a da)
 template <bool BWD>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_softmax(const int* __restrict__ indptr, int n_dst, const bf16_t* __restrict__ x,
-                                                        const bf16_t* __restrict__ a_in, int H, bf16_t* __restrict__ out) {
+                                                        const bf16_t* __restrict__ a_in, int H, bf16_t* __restrict__ out, int* err) {
   const int lane = lane_id();
   const int row = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
   if (row >= n_dst) return;
   const int beg = indptr[row], end = indptr[row + 1];
   for (int h = 0; h < H; ++h) {
     if (!BWD) {
+      // [DGL-recalled] edge_softmax = max, exp(e - max), sum, divide -- four tensor ops in the dtype of e: every one rounds to
+      // bf16, and the sum is a copy_e_sum (exact, rounded once).  exp through double: the correctly rounded fp32 value, which
+      // is what torch's CPU kernel rounds to bf16 (csrc/exp3.hip does the same, exhaustively tested there)
       float m = -__builtin_inff();
       for (int e = beg + lane; e < end; e += 64) m = fmaxf(m, bf2f(x[(int64_t)e * H + h]));
       for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-      float s = 0.f;
-      for (int e = beg + lane; e < end; e += 64) s += __expf(bf2f(x[(int64_t)e * H + h]) - m);
-      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-      for (int e = beg + lane; e < end; e += 64) out[(int64_t)e * H + h] = f2bf(__expf(bf2f(x[(int64_t)e * H + h]) - m) / s);
+      int bad = 0;
+      int64_t s = 0;
+      for (int e = beg + lane; e < end; e += 64) {
+        const bf16_t sc = f2bf((float)exp((double)rbf(bf2f(x[(int64_t)e * H + h]) - m)));
+        out[(int64_t)e * H + h] = sc;                   // (own element, re-read by the same lane below)
+        s += bf_to_fixed(sc, FRAC_DST, &bad);
+      }
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int lo = __shfl_xor((int)(s & 0xffffffffll), d), hi = __shfl_xor((int)(s >> 32), d);
+        s += ((int64_t)hi << 32) | (uint32_t)lo;
+      }
+      float ssum = bf2f(fixed_to_bf(s, FRAC_DST, &bad));
+      if (__any(bad != 0)) ssum = __builtin_nanf("");   // a non-finite logit: the reference's sum, and with it the whole row, is NaN
+      for (int e = beg + lane; e < end; e += 64) out[(int64_t)e * H + h] = f2bf(bf2f(out[(int64_t)e * H + h]) / ssum);
+      if (bad && err) atomicOr(err, bad);
     } else {
       float t = 0.f;                                   // x = d_a, a_in = a
       for (int e = beg + lane; e < end; e += 64) t += bf2f(a_in[(int64_t)e * H + h]) * bf2f(x[(int64_t)e * H + h]);
@@ -113,6 +139,24 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_softmax(const int* __restrict__
   }
 }
 
+// the same softmax in plain fp32 on float logits, float result (the 1e-4 check)
+__global__ void __launch_bounds__(GAT_TPB) k_gat_softmax_f32(const int* __restrict__ indptr, int n_dst, const float* __restrict__ x, int H,
+                                                            float* __restrict__ out) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * (GAT_TPB / 64) + (threadIdx.x >> 6);
+  if (row >= n_dst) return;
+  const int beg = indptr[row], end = indptr[row + 1];
+  for (int h = 0; h < H; ++h) {
+    float m = -__builtin_inff();
+    for (int e = beg + lane; e < end; e += 64) m = fmaxf(m, x[(int64_t)e * H + h]);
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    float s = 0.f;
+    for (int e = beg + lane; e < end; e += 64) s += expf(x[(int64_t)e * H + h] - m);
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    for (int e = beg + lane; e < end; e += 64) out[(int64_t)e * H + h] = expf(x[(int64_t)e * H + h] - m) / s;
+  }
+}
+
 // Row sums of per-edge vectors that are never materialised:
 //   val(e, col) = coef[e, h(col)] * feat[nbr_e, col]                                   (LBWD == false: aggregation fwd / bwd)
 //   val(e, col) = de[e, h(col)] * attn[col] * lrelu'(feat[src_e, col] + feat[dst_e, col])   (LBWD == true: logits backward)
@@ -121,7 +165,7 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_softmax(const int* __restrict__
 // With LBWD && !BY_SRC the kernel also accumulates d_attn[col] = sum_e de[e,h] * lrelu(x) (fp32 atomics per workgroup).
 #define GEC 16                                          // edges per wave: every edge costs up to 2 KB of row gathers, so short
                                                         // chunks (many waves in flight) beat long serial ones
-template <bool LBWD, bool BY_SRC, bool VEC4>
+template <bool LBWD, bool BY_SRC, bool VEC4, bool F32 = false>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ row_ptr, const int* __restrict__ t_edge,
                                                      const int* __restrict__ src, const int* __restrict__ dst,
                                                      const int* __restrict__ nnz_dev, int nnz_host,
@@ -159,7 +203,11 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
           const int rb = row_ptr[r], re = row_ptr[r + 1];
           const bool starts = rb >= c0, ends = re <= c1;
           if (starts && ends) {
-            if (VEC4) {
+            if (F32) {
+              float* o32 = reinterpret_cast<float*>(out) + r * out_stride + col;
+#pragma unroll
+              for (int i = 0; i < W; ++i) o32[i] = acc[i];
+            } else if (VEC4) {
               uint2 v;
               v.x = (uint32_t)f2bf(acc[0]) | ((uint32_t)f2bf(acc[1 % W]) << 16);
               v.y = (uint32_t)f2bf(acc[2 % W]) | ((uint32_t)f2bf(acc[3 % W]) << 16);
@@ -178,7 +226,7 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
         const int r = gb_i(my_row, j), e = gb_i(my_e, j), s_ = gb_i(my_s, j), d_ = gb_i(my_d, j);
         if (r != cur) { flush(cur); cur = r; }
         if (act) {
-          const float cf = bf2f(coef[(int64_t)e * H + hd]);
+          const float cf = F32 ? reinterpret_cast<const float*>(coef)[(int64_t)e * H + hd] : bf2f(coef[(int64_t)e * H + hd]);
           if (LBWD) {
             float xs[W], xd[W];
             if (VEC4) {
@@ -216,7 +264,7 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
 
 // rows without edges -> 0; rows cut by chunk boundaries -> tail partial of their first chunk + head partials of the rest
 // (added in chunk order: deterministic).  VEC4: a lane owns four consecutive columns (float4 partials, 8-byte stores).
-template <bool VEC4>
+template <bool VEC4, bool F32 = false>
 __global__ void __launch_bounds__(GAT_TPB) k_gat_fixup(const int* __restrict__ row_ptr, int n_rows, int HD,
                                                       const float* __restrict__ part, bf16_t* __restrict__ out, int64_t out_stride) {
   const int lane = lane_id();
@@ -224,6 +272,18 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_fixup(const int* __restrict__ r
   if (r >= n_rows) return;
   const int rb = row_ptr[r], re = row_ptr[r + 1];
   constexpr int W = VEC4 ? 4 : 1;
+  if (F32) {                                            // float rows (the 1e-4 check): element-wise, same order of additions
+    float* o32 = reinterpret_cast<float*>(out);
+    if (re <= rb) { for (int col = lane; col < HD; col += 64) o32[r * out_stride + col] = 0.f; return; }
+    const int c = rb / GEC, c_end = (re - 1) / GEC;
+    if (c_end == c) return;
+    for (int col = lane; col < HD; col += 64) {
+      float sum = part[((int64_t)c * 2 + 1) * HD + col];
+      for (int cc = c + 1; cc <= c_end; ++cc) sum += part[((int64_t)cc * 2) * HD + col];
+      o32[r * out_stride + col] = sum;
+    }
+    return;
+  }
   if (re <= rb) {
     for (int col = lane * W; col < HD; col += 64 * W) {
       if (VEC4) *reinterpret_cast<uint2*>(out + r * out_stride + col) = make_uint2(0u, 0u); else out[r * out_stride + col] = 0;
@@ -287,19 +347,34 @@ extern "C" {
 
 int bliss_gat_chunk_edges(void) { return GEC; }
 
-int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
-                     int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
-                     void* stream) {
+static int gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                      int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
+                      void* stream, bool f32) {
   if (!feat || !attn || !e_out || heads <= 0 || heads > GAT_MAXH || head_dim <= 0 || nnz < 0) return BLISS_EINVAL;
   if (nnz == 0) return 0;
   if (!src || !dst) return BLISS_EINVAL;
   const int chunks = (nnz + GAT_EC - 1) / GAT_EC;
   const bool v4 = head_dim % 4 == 0 && feat_stride % 4 == 0 && ((uintptr_t)feat) % 8 == 0 && ((uintptr_t)attn) % 8 == 0;
-  if (v4) k_gat_edge_dot<0, true><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0,
-                                                                        (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)e_out);
-  else k_gat_edge_dot<0, false><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0,
-                                                                        (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)e_out);
+  const dim3 grid((chunks + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+#define LG(V, F) k_gat_edge_dot<0, V, F><<<grid, GAT_TPB, 0, st>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, nullptr, 0, \
+                                                                  (const bf16_t*)attn, heads, head_dim, negative_slope, e_out)
+  if (f32) { if (v4) LG(true, true); else LG(false, true); }
+  else { if (v4) LG(true, false); else LG(false, false); }
+#undef LG
   return (int)hipGetLastError();
+}
+
+int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                     int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
+                     void* stream) {
+  return gat_logits(src, dst, nnz_dev, nnz, feat, feat_stride, attn, heads, head_dim, negative_slope, e_out, stream, false);
+}
+
+int bliss_gat_logits_f32(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                         int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, float* e_out,
+                         void* stream) {
+  return gat_logits(src, dst, nnz_dev, nnz, feat, feat_stride, attn, heads, head_dim, negative_slope, e_out, stream, true);
 }
 
 int bliss_gat_edge_dot(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
@@ -309,20 +384,21 @@ int bliss_gat_edge_dot(const int32_t* src, const int32_t* dst, const int32_t* nn
   if (!src || !dst) return BLISS_EINVAL;
   const int chunks = (nnz + GAT_EC - 1) / GAT_EC;
   const bool v4 = head_dim % 4 == 0 && feat_stride % 4 == 0 && g_stride % 4 == 0 && ((uintptr_t)feat) % 8 == 0 && ((uintptr_t)g) % 8 == 0;
-  if (v4) k_gat_edge_dot<1, true><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
+  if (v4) k_gat_edge_dot<1, true, false><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
                                                                         g_stride, nullptr, heads, head_dim, 0.f, (bf16_t*)out);
-  else k_gat_edge_dot<1, false><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
+  else k_gat_edge_dot<1, false, false><<<(chunks + 3) / 4, GAT_TPB, 0, (hipStream_t)stream>>>(src, dst, nnz_dev, nnz, (const bf16_t*)feat, feat_stride, (const bf16_t*)g,
                                                                         g_stride, nullptr, heads, head_dim, 0.f, (bf16_t*)out);
   return (int)hipGetLastError();
 }
 
 int bliss_gat_edge_softmax(const int32_t* indptr, int32_t n_dst, const void* x, const void* a_or_null, int32_t heads, int backward,
                            void* out, void* stream) {
-  if (!indptr || !x || !out || heads <= 0 || (backward && !a_or_null)) return BLISS_EINVAL;
+  if (!indptr || !x || !out || heads <= 0 || (backward == 1 && !a_or_null) || backward < 0 || backward > 2) return BLISS_EINVAL;
   if (n_dst <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (backward) k_gat_softmax<true><<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const bf16_t*)x, (const bf16_t*)a_or_null, heads, (bf16_t*)out);
-  else k_gat_softmax<false><<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const bf16_t*)x, nullptr, heads, (bf16_t*)out);
+  if (backward == 2) k_gat_softmax_f32<<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const float*)x, heads, (float*)out);
+  else if (backward) k_gat_softmax<true><<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const bf16_t*)x, (const bf16_t*)a_or_null, heads, (bf16_t*)out, nullptr);
+  else k_gat_softmax<false><<<(n_dst + 3) / 4, GAT_TPB, 0, st>>>(indptr, n_dst, (const bf16_t*)x, nullptr, heads, (bf16_t*)out, nullptr);
   return (int)hipGetLastError();
 }
 
@@ -332,6 +408,16 @@ int bliss_gat_rows(int which, const int32_t* row_ptr, int32_t n_rows, const int3
                    float* d_attn, void* stream) {
   if (!row_ptr || !coef || !feat || !out || heads <= 0 || heads > GAT_MAXH || head_dim <= 0 || n_rows <= 0 || nnz < 0) return BLISS_EINVAL;
   if (nnz > 0 && (!src || !dst || !partials)) return BLISS_EINVAL;
+  if (which == 4) {             // the forward aggregation with float coefficients and float rows (no rounding: the 1e-4 check)
+    if (nnz > 0 && (!src || !dst || !partials)) return BLISS_EINVAL;
+    hipStream_t st4 = (hipStream_t)stream;
+    const int chunks4 = nnz > 0 ? (nnz + GEC - 1) / GEC : 1;
+    k_gat_rows<false, false, false, true><<<(chunks4 + 3) / 4, GAT_TPB, 0, st4>>>(row_ptr, t_edge, src, dst, nnz_dev, nnz, (const bf16_t*)coef, (const bf16_t*)feat,
+                                                                                 feat_stride, (const bf16_t*)attn, heads, head_dim, negative_slope,
+                                                                                 (bf16_t*)out, out_stride, partials, d_attn);
+    k_gat_fixup<false, true><<<(n_rows + 3) / 4, GAT_TPB, 0, st4>>>(row_ptr, n_rows, heads * head_dim, partials, (bf16_t*)out, out_stride);
+    return (int)hipGetLastError();
+  }
   if ((which & 1) && nnz > 0 && !t_edge) return BLISS_EINVAL;
   if ((which & 2) && (!attn || heads * head_dim > 2048)) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;

@@ -544,11 +544,15 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
     for (int r = 0; r < COL_R; ++r)
       if (lane + r * 64 < n) emax = max(emax, bf_exp_field(wr[r]));
     const int wfrac = rel_frac(FRAC_DST, wave_max_u31(emax));      // block-floating: exact relative to the column's largest weight
+    long long part_lo = 0;
+    int sticky = 0;
 #pragma unroll
     for (int r = 0; r < COL_R; ++r)
-      if (lane + r * 64 < n) part += bf_to_fixed(wr[r], wfrac, &bad);                         // :129 copy_e_sum over exp3 weights
+      if (lane + r * 64 < n) part += bf_to_fixed_wide(wr[r], wfrac, &part_lo, &sticky, &bad);  // :129 copy_e_sum over exp3 weights
     const long long ws_fixed = wave_total_i64(part);
-    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+    bf16_t wsum;
+    if (__ballot(part_lo != 0 || sticky) == 0ull) wsum = fixed_to_bf(ws_fixed, wfrac, &bad);   // nothing lost below the last bit
+    else wsum = fixed_wide_to_bf(ws_fixed, wave_total_i64(part_lo), __ballot(sticky) != 0ull, wfrac, &bad);
     const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll
@@ -585,13 +589,24 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
 #pragma unroll 8
     for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) emax = max(emax, bf_exp_field(renorm_pending(wq[p0 + i], pend, pdenom)));
     const int wfrac = rel_frac(FRAC_DST, block_max_u31<COL_TPB>(emax, sh));
+    long long part_lo = 0;
+    int sticky = 0;
 #pragma unroll
     for (int r = 0; r < COL_RB; ++r)
-      if (tid + r * COL_TPB < n) part += bf_to_fixed(wr[r], wfrac, &bad);
+      if (tid + r * COL_TPB < n) part += bf_to_fixed_wide(wr[r], wfrac, &part_lo, &sticky, &bad);
 #pragma unroll 8
-    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB) part += bf_to_fixed(renorm_pending(wq[p0 + i], pend, pdenom), wfrac, &bad);
+    for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB)
+      part += bf_to_fixed_wide(renorm_pending(wq[p0 + i], pend, pdenom), wfrac, &part_lo, &sticky, &bad);
     const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
-    const bf16_t wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+    // (lost bits anywhere in the column: block-uniform after the reduction -- the sticky count rides in the same sum)
+    const long long lost = block_sum_i64<COL_TPB>((part_lo != 0 || sticky) ? 1 : 0, sh);
+    bf16_t wsum;
+    if (lost == 0) wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
+    else {
+      const long long lo_tot = block_sum_i64<COL_TPB>(part_lo, sh);
+      const long long st_tot = block_sum_i64<COL_TPB>(sticky, sh);
+      wsum = fixed_wide_to_bf(ws_fixed, lo_tot, st_tot != 0, wfrac, &bad);
+    }
     const float a = rbf((1.0f / (float)n) * eta_f);
     part = 0;
 #pragma unroll

@@ -66,7 +66,13 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
                        uint64_t seed, uint64_t step, int32_t layer, void* P_bf16, uint8_t* keep, void* stream) {
   if (n < 0 || !counts || (n > 0 && (!nid || !p_bf16 || !is_seed || !P_bf16 || !keep))) return BLISS_EINVAL;
   if (n == 0) return 0;
+  // the key is FINALISED before the node id is mixed in (round-2 advice): with key = seed*G + step the step sat in the low
+  // bits next to the node id, and an aligned block of 2^k ids saw the same 2^k uniforms, permuted, on every step that shares
+  // (K + step) >> k -- kept counts per block constant instead of binomial.  splitmix64(key) spreads the step over all 64 bits.
   unsigned long long key = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + (unsigned long long)step;
+  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+  key ^= key >> 31;
   key ^= (unsigned long long)((unsigned)layer & 0xffu) << 56;
   int grid = (n + SH_TPB - 1) / SH_TPB;
   if (grid > 1024) grid = 1024;

@@ -580,6 +580,29 @@ def edge_softmax(graph, logits):
     return _EdgeSoftmax.apply(logits.reshape(shape[0], H), graph, H).view(shape)
 
 
+def gat_forward_f32(graph, feat, attn, H, D, slope):
+    """The message-passing part of custom_GATv2Conv.forward (model.py:82-99) WITHOUT the intermediate bf16 roundings of the
+    default kernels and with float results: (e [B, H], a [B, H], out [S, H*D]) from the bf16 operands ``feat`` = fc_src(h)
+    [K, H*D] and ``attn``.  Forward only -- the check of the north star's 1e-4 bound against fp32 math (tests/); the model
+    path rounds where the reference's bf16 tensor ops round."""
+    feat, attn = feat.detach().contiguous(), attn.detach().reshape(-1).contiguous()
+    assert feat.dtype == torch.bfloat16 and attn.dtype == torch.bfloat16 and feat.is_cuda
+    nnz_ptr, B = _nnz(graph)
+    S, HD, dev = graph.num_dst_nodes(), H * D, feat.device
+    e = torch.empty(B, H, dtype=torch.float32, device=dev)
+    a = torch.empty(B, H, dtype=torch.float32, device=dev)
+    out = torch.empty(S, HD, dtype=torch.float32, device=dev)
+    part = torch.empty(max(2 * (-(-B // _lib.lib.bliss_gat_chunk_edges())) * HD, 1), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.bliss_gat_logits_f32(graph.src.data_ptr(), graph.dst.data_ptr(), nnz_ptr, B, feat.data_ptr(), feat.stride(0),
+                                             attn.data_ptr(), H, D, float(slope), e.data_ptr(), _stream()), "bliss_gat_logits_f32")
+    _lib.check(_lib.lib.bliss_gat_edge_softmax(graph.indptr.data_ptr(), S, e.data_ptr(), 0, H, 2, a.data_ptr(), _stream()),
+               "bliss_gat_edge_softmax")
+    _lib.check(_lib.lib.bliss_gat_rows(4, graph.indptr.data_ptr(), S, 0, graph.src.data_ptr(), graph.dst.data_ptr(), nnz_ptr, B,
+                                       a.data_ptr(), feat.data_ptr(), feat.stride(0), 0, H, D, 0.0, out.data_ptr(), out.stride(0),
+                                       part.data_ptr(), 0, _stream()), "bliss_gat_rows")
+    return e, a, out
+
+
 class GATv2Conv(nn.Module):
     """The reference's ``custom_GATv2Conv`` (model.py:13-112): dglnn.GATv2Conv with the forward that returns the
     PRE-softmax logits as "attention" (:108-110) and ignores ``edge_weight`` (:91-96 are commented out).

@@ -465,6 +465,12 @@ int bliss_gat_chunk_edges(void);
 int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
                      int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
                      void* stream);
+/* bliss_gat_logits without the intermediate bf16 roundings, float result (the north star's 1e-4 check against fp32 math);
+ * likewise bliss_gat_edge_softmax with backward == 2 (float logits in, float out) and bliss_gat_rows with which == 4 (the
+ * forward aggregation with float coefficients and float output rows, out_stride in floats). */
+int bliss_gat_logits_f32(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
+                         int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, float* e_out,
+                         void* stream);
 int bliss_gat_edge_dot(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
                        int64_t feat_stride, const void* g, int64_t g_stride, int32_t heads, int32_t head_dim, void* out, void* stream);
 int bliss_gat_edge_softmax(const int32_t* indptr, int32_t n_dst, const void* x, const void* a_or_null, int32_t heads, int backward,

@@ -205,6 +205,11 @@ def keyed_uniform(seed: int, step: int, layer: int, nid: torch.Tensor) -> torch.
     counterpart (the reference is single-device); single-GPU sampling keeps torch's stream."""
     M = (1 << 64) - 1
     key = ((int(seed) * 0x9E3779B97F4A7C15) + int(step)) & M
+    # finalise the (seed, step) key BEFORE the node id is mixed in: otherwise the step sits in the low bits beside the id and
+    # an aligned block of 2^k ids sees the same 2^k uniforms, permuted, on consecutive steps (round-2 advice)
+    key = ((key ^ (key >> 30)) * 0xBF58476D1CE4E5B9) & M
+    key = ((key ^ (key >> 27)) * 0x94D049BB133111EB) & M
+    key ^= key >> 31
     key ^= (int(layer) & 0xFF) << 56
     z = (np.uint64(key) ^ nid.numpy().astype(np.uint64))
     with np.errstate(over="ignore"):
@@ -442,6 +447,58 @@ def sage_conv_ref(blk: OBlock, h, W_self, b_self, W_neigh, edge_weight):
     else:
         neigh = spmm_mean_ref(blk, h, edge_weight) @ W_neigh.float().t()
     return h_self @ W_self.float().t() + b_self.float() + neigh
+
+
+# --------------------------------------------------------------------------
+# a19  GATv2 forward in the reference's own arithmetic (bf16 tensors, torch CPU ops)
+# --------------------------------------------------------------------------
+def edge_softmax_ref(blk: OBlock, e: torch.Tensor):
+    """[DGL-recalled] dglnn.functional.edge_softmax (model.py:89) = four ops in the dtype of ``e`` [B, H]: per-destination
+    max, exp(e - max), per-destination sum (exact sum of the rounded terms, one rounding: the copy_e_sum contract of
+    numerics.py), division."""
+    S, H = blk.n_dst, e.shape[1]
+    mx = torch.full((S, H), -float("inf")).scatter_reduce(0, blk.dst[:, None].expand(-1, H), e.float(), "amax").to(e.dtype)
+    score = torch.exp(e - mx[blk.dst])
+    ssum = torch.stack([nx.exact_segment_sum_rel(score[:, h].contiguous(), blk.dst, S, nx.FRAC_DST)[0] for h in range(H)], 1)
+    return score / ssum[blk.dst]
+
+
+def gatv2_conv(blk: OBlock, h: torch.Tensor, p: dict, slope: float):
+    """custom_GATv2Conv.forward, model.py:63-112, as the reference builds it (share_weights=True, bias=False, :152-153):
+    ``p`` = dict(fc_src [H*D, in], attn [1,H,D], res_fc [H*D, in] or None, res_kind 0 none / 1 Linear / 2 Identity, H, D,
+    act: F.elu or nothing).  Returns (rst [S,H,D], e [B,H] -- the PRE-softmax logits the reference hands back as
+    "attention", :108-110)."""
+    H, D, S = p["H"], p["D"], blk.n_dst
+    feat_src = torch.nn.functional.linear(h, p["fc_src"]).view(-1, H, D)                   # :70
+    feat_dst = feat_src[:S]                                                                # :72, :78
+    e = torch.nn.functional.leaky_relu(feat_src[blk.src] + feat_dst[blk.dst], slope)       # :82-85 u_add_v, leaky_relu
+    e = (e * p["attn"]).sum(dim=-1)                                                        # :86   [B, H]
+    a = edge_softmax_ref(blk, e)                                                           # :88-90
+    # :98 update_all(u_mul_e('el','a','m'), sum('m','ft')): fp32 products and sums in edge order, one rounding
+    # ([DGL-recalled]: the message tensor is not materialised; see dgl_standin.Graph.update_all)
+    m = feat_src.float()[blk.src] * a.float()[:, :, None]
+    rst = torch.zeros(S, H, D, dtype=torch.float32).index_add_(0, blk.dst, m).to(h.dtype)  # :99
+    if p["res_kind"] == 1:
+        rst = rst + torch.nn.functional.linear(h[:S], p["res_fc"]).view(S, -1, D)          # :101-103
+    elif p["res_kind"] == 2:
+        rst = rst + h[:S].view(S, -1, D)
+    if p["act"]:
+        rst = torch.nn.functional.elu(rst)                                                 # :105-106 (train_lightning.py:587)
+    return rst, e
+
+
+def gatv2_forward(blocks: List[OBlock], x: torch.Tensor, params: List[dict], slope: float = 0.2):
+    """GATv2.forward, model.py:207-234 (no dropout): per layer embed_norm (:211-213), the layer, a_ij = mean of the logits
+    over the heads (:224-227), flatten / mean over the heads (:228-232).  Returns (logits [S, classes], per-layer traces)."""
+    h = x.bfloat16()                                                                       # :208
+    traces = []
+    for l, (blk, p) in enumerate(zip(blocks, params)):
+        en = torch.reshape(torch.norm(h, dim=1, keepdim=True), (-1,))                      # :211-213
+        rst, e = gatv2_conv(blk, h, p, slope)                                              # :214-223
+        a_ij = torch.mean(e, dim=1)                                                        # :224-227
+        traces.append(dict(embed_norm=en, rst=rst, e=e, a_ij=a_ij, h_in=h))
+        h = rst.flatten(1) if l < len(blocks) - 1 else rst.mean(1)                         # :228-232
+    return h, traces
 
 
 def prepare_graph(src, dst, num_nodes, undirected=False):

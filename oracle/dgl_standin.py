@@ -16,6 +16,13 @@ v_add_e,e_mul_v,u_div_e,e_dot_v} (:67-73,:129-137,:150-154,:186-189,:240-242,:31
 dgl.function.{copy_e,sum} + update_all/apply_edges/local_scope (:21-27),
 DGLGraph.{subgraph,edges,in_degrees,out_degrees,num_nodes,num_edges,idtype,device,
 ndata,edata,srcdata,dstdata}.
+
+Round 3, for the MODEL side (/root/reference/model.py run unmodified by make_golden.py): dgl.nn.GATv2Conv as the base
+class ``custom_GATv2Conv`` derives from (model.py:13; only its constructor state is used: fc_src, fc_dst, attn, feat_drop,
+attn_drop, leaky_relu, res_fc, activation, share_weights -- the forward is the reference's own, model.py:48-112),
+dgl.nn.SAGEConv('mean') (model.py:303-308), dgl.nn.functional.edge_softmax (:89), dgl.function.{u_add_v,u_mul_e,copy_u,
+sum,mean} with DGLBlock.apply_edges / update_all (:82, :98), dgl.base.DGLError (:10).  [DGL-recalled] numerics of those
+primitives, stated where they are implemented below.
 """
 import contextlib
 import sys
@@ -29,11 +36,14 @@ EID = "_ID"
 
 # ------------------------------------------------------------------ exact sums
 def _bf16_to_int(x, frac=150):
+    """bf16 -> Python int scaled by 2**frac (exact, subnormals included); None for a non-finite term."""
     bits = x.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
     out = []
     for b in bits.tolist():
         s, e, m = b >> 15, (b >> 7) & 0xFF, b & 0x7F
-        assert e != 255, "non-finite term"
+        if e == 255:
+            out.append(None)
+            continue
         if e == 0:
             v = m << (frac - 133)
         else:
@@ -43,11 +53,18 @@ def _bf16_to_int(x, frac=150):
 
 
 def _int_to_bf16_bits(n, frac=150):
+    """exact Python int * 2**-frac -> bf16 bits, round to nearest even; subnormal results and overflow to inf like IEEE."""
     if n == 0:
         return 0
     s = 1 if n < 0 else 0
     n = abs(n)
     msb = n.bit_length() - 1
+    if msb - frac + 127 <= 0:                      # below the normal range: units of 2**-133 (the subnormal spacing)
+        sh = frac - 133
+        q, rem, half = n >> sh, n & ((1 << sh) - 1), 1 << (sh - 1)
+        if rem > half or (rem == half and (q & 1)):
+            q += 1
+        return (s << 15) | q                       # q == 128 is the smallest normal: same encoding
     if msb > 7:
         sh = msb - 7
         q, rem, half = n >> sh, n & ((1 << sh) - 1), 1 << (sh - 1)
@@ -59,17 +76,27 @@ def _int_to_bf16_bits(n, frac=150):
     if q >= 256:
         q >>= 1
         e += 1
-    assert 0 < e < 255
+    if e >= 255:
+        return (s << 15) | 0x7F80
     return (s << 15) | (e << 7) | (q & 0x7F)
 
 
 def _segment_sum(values, seg, nseg):
-    """Exact per-segment sum of bf16 (or any float) values, rounded once to bf16."""
+    """Exact per-segment sum of bf16 (or any float) values, rounded once to bf16; non-finite terms follow IEEE addition
+    (NaN, or +inf and -inf together -> NaN; else the infinity)."""
     values = values.bfloat16() if values.dtype != torch.bfloat16 else values
     acc = [0] * nseg
-    for v, k in zip(_bf16_to_int(values), seg.tolist()):
-        acc[k] += v
-    bits = torch.tensor([_int_to_bf16_bits(a) for a in acc], dtype=torch.int64)
+    special = {}
+    for v, k, raw in zip(_bf16_to_int(values), seg.tolist(), values.float().tolist()):
+        if v is None:
+            special.setdefault(k, []).append(raw)
+        else:
+            acc[k] += v
+    bits = [_int_to_bf16_bits(a) for a in acc]
+    for k, raws in special.items():
+        nan = any(r != r for r in raws) or (any(r > 0 for r in raws) and any(r < 0 for r in raws))
+        bits[k] = 0x7FC0 if nan else (0x7F80 if raws[0] > 0 else 0xFF80)
+    bits = torch.tensor(bits, dtype=torch.int64)
     bits = torch.where(bits >= 32768, bits - 65536, bits).to(torch.int16)
     return bits.view(torch.bfloat16)
 
@@ -149,19 +176,49 @@ class Graph:
     @contextlib.contextmanager
     def local_scope(self):
         saved_e, saved_n = dict(self.edata), dict(self.srcdata)
+        saved_d = dict(self.dstdata) if self.dstdata is not self.srcdata else None
         try:
             yield
         finally:
             self.edata.clear(); self.edata.update(saved_e)
             self.srcdata.clear(); self.srcdata.update(saved_n)
+            if saved_d is not None:
+                self.dstdata.clear(); self.dstdata.update(saved_d)
 
     def update_all(self, msg, red):
+        """[DGL-recalled] g-SpMM.  copy_e: the edge values; u_mul_e / copy_u: message = src row (x edge value), computed
+        and accumulated in fp32 from the stored (bf16) operands in edge order of each destination, ONE rounding to the
+        operand dtype at the end (DGL's kernels do not materialise the message tensor; their accumulation type for bf16 is
+        not knowable offline -- see oracle/bliss_oracle.py header).  sum / mean."""
         kind_m, a, b = msg
         kind_r, c, out = red
-        assert kind_m == "copy_e" and kind_r == "sum"
-        self.dstdata[out] = _segment_sum(self.edata[a], self._dst, self._nd)
+        if kind_m == "copy_e":
+            assert kind_r == "sum"
+            self.dstdata[out] = _segment_sum(self.edata[a], self._dst, self._nd)
+            return
+        assert kind_m in ("u_mul_e", "copy_u") and kind_r in ("sum", "mean")
+        x = self.srcdata[a]
+        m = x.float()[self._src]
+        if kind_m == "u_mul_e":
+            e = self.edata[b].float()
+            while e.dim() < m.dim():
+                e = e.unsqueeze(-1)
+            m = m * e
+        acc = torch.zeros((self._nd,) + tuple(m.shape[1:]), dtype=torch.float32).index_add_(0, self._dst, m)
+        acc = acc.to(x.dtype)
+        if kind_r == "mean":
+            # [DGL-recalled] dgl/ops/spmm.py:gspmm: 'mean' = the 'sum' result (already in the operand dtype) divided by
+            # clamp(in_degrees, 1) cast to that dtype -- two roundings for bf16
+            deg = torch.zeros(self._nd, dtype=torch.float32).index_add_(0, self._dst, torch.ones(self._dst.numel()))
+            acc = acc / deg.clamp(min=1).to(x.dtype).view((-1,) + (1,) * (acc.dim() - 1))
+        self.dstdata[out] = acc
 
     def apply_edges(self, fn):
+        if isinstance(fn, tuple):                      # built-in message function: element-wise in the operand dtype
+            kind, a, b, out = fn
+            assert kind == "u_add_v"
+            self.edata[out] = self.srcdata[a][self._src] + self.dstdata[b][self._dst]
+            return
         edges = types.SimpleNamespace(dst={k: v[self._dst] for k, v in self.dstdata.items() if v.shape[0] == self._nd},
                                       src={k: v[self._src] for k, v in self.srcdata.items() if v.shape[0] == self._ns},
                                       data=self.edata)
@@ -285,6 +342,106 @@ def _ops():
     return m
 
 
+# ------------------------------------------------------------------ dgl.nn (constructor state only; [DGL-recalled])
+def edge_softmax(graph, e):
+    """[DGL-recalled] dgl.nn.functional.edge_softmax (dgl/backend/pytorch/sparse.py: EdgeSoftmax.forward): four ops, each
+    in the dtype of ``e``:  max over the in-edges of a destination; exp(e - max); sum over the in-edges (exact sum of the
+    rounded terms, rounded once: the stand-in's copy_e_sum contract); out = score / sum."""
+    shape = e.shape
+    x = e.reshape(shape[0], -1)
+    nd, dst = graph._nd, graph._dst
+    mx = torch.full((nd, x.shape[1]), -float("inf"), dtype=torch.float32)
+    mx = mx.scatter_reduce(0, dst[:, None].expand(-1, x.shape[1]), x.float(), "amax").to(e.dtype)
+    score = torch.exp(x - mx[dst])
+    ssum = torch.stack([_segment_sum(score[:, h].contiguous(), dst, nd) for h in range(x.shape[1])], 1) if e.dtype == torch.bfloat16 \
+        else torch.zeros(nd, x.shape[1], dtype=e.dtype).index_add_(0, dst, score)
+    return (score / ssum[dst]).reshape(shape)
+
+
+def _nn():
+    import torch.nn as tnn
+
+    class GATv2Conv(tnn.Module):
+        """[DGL-recalled] dgl.nn.GATv2Conv.__init__ / reset_parameters (dgl 2.2.1): field names as the reference's forward reads them."""
+
+        def __init__(self, in_feats, out_feats, num_heads, feat_drop=0.0, attn_drop=0.0, negative_slope=0.2, residual=False,
+                     activation=None, allow_zero_in_degree=False, bias=True, share_weights=False):
+            super().__init__()
+            self._num_heads = num_heads
+            self._in_src_feats = self._in_dst_feats = in_feats
+            self._out_feats = out_feats
+            self._allow_zero_in_degree = allow_zero_in_degree
+            self.fc_src = tnn.Linear(in_feats, out_feats * num_heads, bias=bias)
+            self.fc_dst = self.fc_src if share_weights else tnn.Linear(in_feats, out_feats * num_heads, bias=bias)
+            self.attn = tnn.Parameter(torch.empty(1, num_heads, out_feats))
+            self.feat_drop = tnn.Dropout(feat_drop)
+            self.attn_drop = tnn.Dropout(attn_drop)
+            self.leaky_relu = tnn.LeakyReLU(negative_slope)
+            if residual:
+                self.res_fc = tnn.Linear(in_feats, num_heads * out_feats, bias=bias) if in_feats != out_feats * num_heads else tnn.Identity()
+            else:
+                self.register_buffer("res_fc", None)
+            self.activation = activation
+            self.share_weights = share_weights
+            self.bias = bias
+            gain = tnn.init.calculate_gain("relu")
+            tnn.init.xavier_normal_(self.fc_src.weight, gain=gain)
+            if bias:
+                tnn.init.constant_(self.fc_src.bias, 0)
+            if not share_weights:
+                tnn.init.xavier_normal_(self.fc_dst.weight, gain=gain)
+                if bias:
+                    tnn.init.constant_(self.fc_dst.bias, 0)
+            tnn.init.xavier_normal_(self.attn, gain=gain)
+            if isinstance(self.res_fc, tnn.Linear):
+                tnn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+                if bias:
+                    tnn.init.constant_(self.res_fc.bias, 0)
+
+    class SAGEConv(tnn.Module):
+        """[DGL-recalled] dgl.nn.SAGEConv(in, out, 'mean').forward(graph, feat, edge_weight): fc_neigh (bias-free) BEFORE the
+        aggregation iff in > out; update_all(u_mul_e('h','_edge_weight','m'), mean('m','neigh')); rst = fc_self(h_dst) + h_neigh."""
+
+        def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0.0, bias=True, norm=None, activation=None):
+            super().__init__()
+            assert aggregator_type == "mean"
+            self._in_src_feats = self._in_dst_feats = in_feats
+            self._out_feats = out_feats
+            self.fc_neigh = tnn.Linear(in_feats, out_feats, bias=False)
+            self.fc_self = tnn.Linear(in_feats, out_feats, bias=bias)
+            gain = tnn.init.calculate_gain("relu")
+            tnn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+            tnn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+        def forward(self, graph, feat, edge_weight=None):
+            with graph.local_scope():
+                feat_src = feat
+                feat_dst = feat[: graph.number_of_dst_nodes()]
+                msg = ("copy_u", "h", "m")
+                if edge_weight is not None:
+                    graph.edata["_edge_weight"] = edge_weight
+                    msg = ("u_mul_e", "h", "_edge_weight", "m")
+                lin_before_mp = self._in_src_feats > self._out_feats
+                graph.srcdata["h"] = self.fc_neigh(feat_src) if lin_before_mp else feat_src
+                graph.update_all(msg[:3], ("mean", "m", "neigh"))
+                h_neigh = graph.dstdata["neigh"]
+                if not lin_before_mp:
+                    h_neigh = self.fc_neigh(h_neigh)
+                return self.fc_self(feat_dst) + h_neigh
+
+    m = types.ModuleType("dgl.nn")
+    m.GATv2Conv, m.SAGEConv = GATv2Conv, SAGEConv
+    m.GraphConv = None                                     # model.py:397-417 only runs if a GCN is built (never from the CLI)
+    f = types.ModuleType("dgl.nn.functional")
+    f.edge_softmax = edge_softmax
+    m.functional = f
+    return m, f
+
+
+class DGLError(Exception):
+    pass
+
+
 class BlockSampler:
     def __init__(self, *a, **k):
         pass
@@ -305,10 +462,19 @@ def install():
     dgl.ops = _ops()
     fn = types.ModuleType("dgl.function")
     fn.copy_e = lambda a, b: ("copy_e", a, b)
+    fn.copy_u = lambda a, b: ("copy_u", a, b)
+    fn.u_mul_e = lambda a, b, c: ("u_mul_e", a, b)
+    fn.u_add_v = lambda a, b, c: ("u_add_v", a, b, c)
     fn.sum = lambda a, b: ("sum", a, b)
+    fn.mean = lambda a, b: ("mean", a, b)
     dgl.function = fn
+    dgl.nn, nnf = _nn()
+    base = types.ModuleType("dgl.base")
+    base.DGLError = DGLError
+    dgl.base = base
     dl = types.ModuleType("dgl.dataloading")
     dl.BlockSampler = BlockSampler
     dgl.dataloading = dl
-    sys.modules.update({"dgl": dgl, "dgl.ops": dgl.ops, "dgl.function": fn, "dgl.dataloading": dl})
+    sys.modules.update({"dgl": dgl, "dgl.ops": dgl.ops, "dgl.function": fn, "dgl.dataloading": dl, "dgl.nn": dgl.nn,
+                        "dgl.nn.functional": nnf, "dgl.base": base})
     return dgl

@@ -92,9 +92,22 @@ def fixed_to_bf16(n: torch.Tensor, frac) -> torch.Tensor:
     carry = q >= 256
     q = torch.where(carry, q >> 1, q)
     e = msb - frac + carry.to(torch.int64) + 127
-    if bool(((e <= 0) & (mag != 0)).any()) or bool((e >= 255).any()):
-        raise OverflowError("fixed-point sum outside the bf16 normal range")
+    if bool((e >= 255).any()):
+        raise OverflowError("fixed-point sum above the bf16 range")
     bits = (sign << 15) | (e << 7) | (q & 0x7F)
+    # below the normal range (block-floating sums only: frac > 126): round at the subnormal spacing 2**-133 like IEEE --
+    # torch's CPU kernels do not flush, and the reference runs on into this regime before a bandit row dies
+    sub = (msb - frac + 127 <= 0) & (mag != 0)
+    if bool(sub.any()):
+        fr = frac if isinstance(frac, torch.Tensor) else torch.full_like(mag, int(frac))
+        sh = (fr - 133)
+        shr = sh.clamp(min=1, max=62)
+        qs = torch.where(sh > 62, torch.zeros_like(mag), mag >> shr)
+        rem = mag & ((torch.ones_like(mag) << shr) - 1)
+        half_s = torch.ones_like(mag) << (shr - 1)
+        qs = qs + ((sh <= 62) & ((rem > half_s) | ((rem == half_s) & ((qs & 1) == 1)))).to(torch.int64)
+        qs = torch.where(sh <= 0, mag << (-sh).clamp(min=0, max=62), qs)
+        bits = torch.where(sub, (sign << 15) | qs, bits)
     bits = torch.where(mag == 0, torch.zeros_like(bits), bits)
     return bits_to_bf16(bits)
 
@@ -112,20 +125,64 @@ def exact_segment_sum(values: torch.Tensor, seg: torch.Tensor, nseg: int, frac: 
 def exact_segment_sum_rel(values: torch.Tensor, seg: torch.Tensor, nseg: int, frac: int) -> torch.Tensor:
     """exact_segment_sum in block-floating form, for sums whose terms may sit anywhere in bf16's range (the EXP3 weights
     of a seed column, bandit_sampler.py:129, once the bandit has concentrated a row): every segment's terms are scaled
-    by 2**s, s = max(0, 126 - largest biased exponent in the segment), before the exact integer addition, so the sum is
-    exact relative to the segment's largest term.  Identical to exact_segment_sum wherever that one truncates nothing.
-    (csrc/common.cuh: rel_frac; csrc/sampler.hip: k_col_sums.)"""
+    by 2**s, s = max(0, 126 - largest biased exponent in the segment), before the exact integer addition.  Bits a term
+    loses below the accumulator's unit go to a second accumulator 40 bits finer, and what falls below even that sets a
+    sticky flag that breaks rounding ties upward (all terms >= 0) -- so the rounded sum is the rounding of the EXACT sum
+    (found by the long reference run tests/golden/collapse0_*: tiny weights beside two large ones turned a "just above the
+    tie" into a tie).  Subnormal results are produced like IEEE.  (csrc/common.cuh: rel_frac, bf_to_fixed_wide,
+    fixed_wide_to_bf; csrc/sampler.hip: k_col_sums.)  Returns (bf16 sums, the int64 main accumulators)."""
     bits = bf16_bits(values)
     exp = (bits >> 7) & 0xFF
-    exp = torch.where(exp == 0, torch.ones_like(exp), exp)
+    man = bits & 0x7F
+    if bool((exp == 255).any()):
+        raise FloatingPointError("non-finite bf16 term in an exact reduction")
+    if bool(((bits >> 15) == 1).any() & (values != 0).any() & (values < 0).any()):
+        raise FloatingPointError("negative weight in a block-floating sum")
+    m = torch.where(exp == 0, man, man | 0x80)
+    e = torch.where(exp == 0, torch.ones_like(exp), exp)
     seg = seg.to(torch.int64)
     emax = torch.ones(nseg, dtype=torch.int64)
-    emax.scatter_reduce_(0, seg, exp, reduce="amax", include_self=True)
+    emax.scatter_reduce_(0, seg, e, reduce="amax", include_self=True)
     fr = frac + (126 - emax).clamp(min=0)
-    fx = bf16_to_fixed(values, fr[seg])
-    acc = torch.zeros(nseg, dtype=torch.int64)
-    acc.index_add_(0, seg, fx)
-    return fixed_to_bf16(acc, fr), acc
+    shift = e - 134 + fr[seg]
+    if bool((shift > 55).any()):
+        raise OverflowError("bf16 term too large for the fixed-point format")
+    rs = (-shift).clamp(min=0)
+    top = torch.where(shift >= 0, m << shift.clamp(min=0), torch.where(rs >= 8, torch.zeros_like(m), m >> rs.clamp(max=62)))
+    r = torch.where(shift >= 0, torch.zeros_like(m), torch.where(rs >= 8, m, m & ((torch.ones_like(m) << rs.clamp(max=62)) - 1)))
+    d = (rs - 40).clamp(min=0)
+    lo = torch.where(rs <= 40, r << (40 - rs).clamp(min=0), torch.where(d >= 8, torch.zeros_like(r), r >> d.clamp(max=62)))
+    lost = (rs > 40) & ((d >= 8) & (r != 0) | ((r & ((torch.ones_like(r) << d.clamp(max=62)) - 1)) != 0))
+    acc = torch.zeros(nseg, dtype=torch.int64).index_add_(0, seg, top)
+    acc_lo = torch.zeros(nseg, dtype=torch.int64).index_add_(0, seg, lo)
+    sticky = torch.zeros(nseg, dtype=torch.int64).index_add_(0, seg, lost.to(torch.int64)) > 0
+    out = fixed_to_bf16(acc, fr)
+    for k in torch.nonzero((acc_lo != 0) | sticky).flatten().tolist():       # rare: Python ints, exact
+        out[k] = _int_to_bf16_sticky((int(acc[k]) << 40) + int(acc_lo[k]), int(fr[k]) + 40, bool(sticky[k]))
+    return out, acc
+
+
+def _int_to_bf16_sticky(total: int, frac: int, sticky: bool) -> torch.Tensor:
+    """exact non-negative Python int * 2**-frac (+ a positive remainder below the last bit if ``sticky``) -> bf16, RNE."""
+    if total == 0:
+        return torch.zeros((), dtype=torch.bfloat16)
+    msb = total.bit_length() - 1
+
+    def rshift(sh):
+        if sh <= 0:
+            return total << (-sh)
+        q, rem, half = total >> sh, total & ((1 << sh) - 1), 1 << (sh - 1)
+        return q + 1 if (rem > half or (rem == half and (sticky or (q & 1)))) else q
+
+    if msb - frac + 127 <= 0:
+        return bits_to_bf16(torch.tensor(rshift(frac - 133), dtype=torch.int64))
+    q, e = rshift(msb - 7), msb - frac + 127
+    if q >= 256:
+        q >>= 1
+        e += 1
+    if e >= 255:
+        raise OverflowError("fixed-point sum above the bf16 range")
+    return bits_to_bf16(torch.tensor((e << 7) | (q & 0x7F), dtype=torch.int64))
 
 
 # ----------------------------------------------------------------------------

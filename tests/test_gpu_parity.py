@@ -89,6 +89,7 @@ def test_poisson_ladies_golden(cuda, name):
     (5000, 15000, [4096, 2048, 1024], 64, 0.4, 2),       # fanout > candidates: the C <= fanout early-out
     (50000, 2000000, [2048, 1024, 512], 256, 0.1, 3),    # long columns, many waves per destination
     (19717, 88651, [512, 256, 128], 32, 0.1, 4),         # BASELINE config 2 at full size (Pubmed-like); the scale loop hits its 50-iteration cap
+    (2708, 10556, [512, 256, 128], 32, 0.1, 5),          # BASELINE config 1 at full size (Cora-like: 2,708 nodes, 10,556 edges + self loops)
 ])
 def test_bandit_vs_oracle_random_graphs(cuda, V, E, fan, batch, eta, seed):
     """Three consecutive train steps on seeded graphs the oracle finishes in seconds: ids, probabilities,

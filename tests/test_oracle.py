@@ -176,3 +176,147 @@ def test_block_floating_segment_sum():
         exact = sum((Fraction(float(v)) for v in tiny[seg == k]), Fraction(0))
         want = torch.tensor(float(exact), dtype=torch.float64).to(torch.bfloat16)     # one rounding of the exact value
         assert float(r[k]) == float(want), k
+
+
+def _ulp_distance(a_bits, b_bits):
+    """Distance in bf16 units-in-the-last-place between two uint16 bit-pattern arrays (monotone integer mapping)."""
+    def key(x):
+        x = x.astype(np.int32)
+        return np.where(x & 0x8000, -(x & 0x7FFF), x & 0x7FFF)
+    return np.abs(key(a_bits) - key(b_bits))
+
+
+def _gat_params(z, n_layers):
+    heads, hidden, classes = z["heads"].tolist(), int(z["hidden"]), int(z["classes"])
+    params = []
+    for l in range(n_layers):
+        D = hidden if l < n_layers - 1 else classes
+        kind = int(z[f"p{l}_res_kind"])
+        fc = bits_to_bf16(z[f"p{l}_fc_src"])
+        params.append(dict(fc_src=fc, attn=bits_to_bf16(z[f"p{l}_attn"]).view(1, heads[l], D),
+                           res_fc=bits_to_bf16(z[f"p{l}_res_fc"]) if kind == 1 else None, res_kind=kind, H=heads[l], D=D,
+                           act=l < n_layers - 1))
+    return params
+
+
+@pytest.mark.parametrize("name", golden_cases("gat"))
+def test_gat_model_and_exp3_match_reference_run(name):
+    """a19 + the GAT branch of a13: the reference's own model.GATv2 / custom_GATv2Conv.forward and exp3(model='gat'), run by
+    tests/golden/make_golden.py, against the oracle's restatement.  Everything element-wise or integer is bit-exact; the
+    tensors behind a bf16 Linear (library GEMM of the host's torch: its fp32 summation order may differ between CPUs) are
+    allowed one bf16 ulp, checked layer by layer from the fixture's own layer inputs."""
+    z = load_golden(name)
+    g = _graph(z)
+    fanouts, eta, seed = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"])
+    feats = bits_to_bf16(z["features"])
+    params = _gat_params(z, len(fanouts))
+    edge_w = bits_to_bf16(z["edge_w"])
+    w = torch.ones(len(fanouts), g.num_edges, dtype=torch.bfloat16)
+    for step in range(int(z["n_steps"])):
+        seeds = torch.from_numpy(z[f"s{step}_seeds"])
+        torch.manual_seed(seed + 10 + step)
+        inp, _, blocks = bo.sample_blocks_bandit(g, seeds, fanouts, w, eta)
+        embed, aij = [], []
+        for l, blk in enumerate(blocks):
+            pre = f"s{step}_l{l}_"
+            _check_block(z, pre, blk, True)
+            h_in = bits_to_bf16(z[pre + "h_in"])
+            if l == 0:
+                assert torch.equal(h_in.view(torch.int16), feats[inp].view(torch.int16))           # train_lightning.py:138
+            rst, e = bo.gatv2_conv(blk, h_in, params[l], 0.2)
+            assert _ulp_distance(bf16_bits(e), z[pre + "e"]).max() <= 1
+            assert _ulp_distance(bf16_bits(rst), z[pre + "rst"]).max() <= 1
+            en = torch.reshape(torch.norm(h_in, dim=1, keepdim=True), (-1,))
+            assert _ulp_distance(bf16_bits(en), z[pre + "embed_norm"]).max() <= 1
+            e_fix = bits_to_bf16(z[pre + "e"])
+            assert np.array_equal(bf16_bits(torch.mean(e_fix, dim=1)), z[pre + "a_ij"])              # model.py:224-227
+            a_fix, en_fix = bits_to_bf16(z[pre + "a_ij"]), bits_to_bf16(z[pre + "embed_norm"])
+            assert np.array_equal(bf16_bits(bo.gat_alpha(blk, a_fix)), z[pre + "alpha"])             # bandit_sampler.py:146-154
+            embed.append(en_fix); aij.append(a_fix)
+        w, traces = bo.exp3(g, blocks, w, edge_w, embed, a_ij=aij)
+        for l, tr in enumerate(traces):
+            assert np.array_equal(z[f"s{step}_l{l}_rewards"], bf16_bits(tr["rewards"]))
+        assert np.array_equal(z[f"s{step}_exp3_weights"], bf16_bits(w))
+
+
+def test_sage_model_matches_reference_run():
+    """a17: the reference's SAGE.forward (model.py:312-333) over the stand-in's SAGEConv, bf16 on the CPU, vs the oracle's fp32
+    restatement (bf16 rounding of the layer outputs) and the bandit update fed with the model's own row norms (bit-exact)."""
+    z = load_golden("sage0_model_exp3")
+    g = _graph(z)
+    fanouts, eta, seed = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"])
+    feats, edge_w = bits_to_bf16(z["features"]), bits_to_bf16(z["edge_w"])
+    w = torch.ones(len(fanouts), g.num_edges, dtype=torch.bfloat16)
+    torch.manual_seed(seed + 10)
+    inp, _, blocks = bo.sample_blocks_bandit(g, torch.from_numpy(z["seeds"]), fanouts, w, eta)
+    embed = []
+    for l, blk in enumerate(blocks):
+        _check_block(z, f"l{l}_", blk, True)
+        h_in = bits_to_bf16(z[f"l{l}_h_in"])
+        ref = bo.sage_conv_ref(blk, h_in, bits_to_bf16(z[f"p{l}_w_self"]), bits_to_bf16(z[f"p{l}_b_self"]),
+                               bits_to_bf16(z[f"p{l}_w_neigh"]), blk.edge_weights)
+        out = bits_to_bf16(z[f"l{l}_out"]).float()
+        assert (out - ref).abs().max() <= 3 * ref.abs().max() * 2 ** -8
+        en = bits_to_bf16(z[f"l{l}_embed_norm"])
+        assert (en.float() - bo.embed_norm_ref(h_in)).abs().max() <= bo.embed_norm_ref(h_in).max() * 2 ** -8
+        embed.append(en)
+    w, traces = bo.exp3(g, blocks, w, edge_w, embed)
+    for l, tr in enumerate(traces):
+        assert np.array_equal(z[f"l{l}_rewards"], bf16_bits(tr["rewards"]))
+    assert np.array_equal(z["exp3_weights"], bf16_bits(w))
+
+
+def _row_checksum(w):
+    b = bf16_bits(w).astype(np.uint64).reshape(-1)
+    idx = np.arange(1, b.size + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return np.uint64(((b + np.uint64(1)) * (idx * np.uint64(0x9E3779B97F4A7C15))).sum())
+
+
+def test_collapse_on_normal_features_is_the_references_arithmetic():
+    """ADVICE r2 / VERDICT r2 1(c): on N(0,1) features the REFERENCE's bandit drives a row's untouched weights out of bf16's
+    range and its own torch.bernoulli raises on the resulting NaN (fixture: step 616 of a reference run on a 400-node graph,
+    tests/golden/make_golden.py:collapse_case).  The oracle follows that run bit for bit -- a checksum of the EXP3 rows after
+    every one of the 616 updates, through subnormal column sums -- and fails at the same step."""
+    z = load_golden("collapse0_normal_features")
+    g = _graph(z)
+    fanouts, eta, seed, batch = z["fanouts"].tolist(), float(z["eta"]), int(z["torch_seed"]), int(z["batch"])
+    T = int(z["failed_at"])
+    assert T >= 200 and "p_in" in str(z["how"])
+    norm0, norm1 = bits_to_bf16(z["norm0"]), bits_to_bf16(z["norm1"])
+    edge_w = bo.normalized_edata(g)
+    w = torch.ones(len(fanouts), g.num_edges, dtype=torch.bfloat16)
+    gen = torch.Generator().manual_seed(seed + 3)
+    V = g.num_nodes
+    for step in range(T + 1):
+        seeds = torch.randperm(V, generator=gen)[:batch].to(torch.int32)
+        torch.manual_seed(seed + 1000 + step)
+        if step == T:
+            with pytest.raises((FloatingPointError, RuntimeError)):
+                bo.sample_blocks_bandit(g, seeds, fanouts, w, eta)
+            break
+        _, _, blocks = bo.sample_blocks_bandit(g, seeds, fanouts, w, eta)
+        assert [b.n_src for b in blocks] == z["kept"][step].tolist()
+        if step == T - 1:
+            assert np.array_equal(bf16_bits(w), z["weights_before_last_update"])
+        w, _ = bo.exp3(g, blocks, w, edge_w, [(norm0 if l == 0 else norm1)[b.src_nid] for l, b in enumerate(blocks)])
+        assert _row_checksum(w) == z["checksums"][step], f"EXP3 rows left the reference's trajectory at step {step}"
+    assert np.array_equal(bf16_bits(w), z["last_weights"])
+
+
+def test_keyed_uniforms_are_independent_across_steps():
+    """Round-2 advice: the sharded sampler's counter-based uniforms (oracle.keyed_uniform == csrc/shard.hip:keyed_u24) must
+    not hand an aligned block of node ids the same multiset of uniforms on consecutive steps."""
+    for k in (1, 4, 8):
+        base = 3 << 12
+        nid = torch.arange(base, base + (1 << k))
+        for step in (0, 7, 1023):
+            a = bo.keyed_uniform(1234, step, 2, nid).numpy()
+            b = bo.keyed_uniform(1234, step + 1, 2, nid).numpy()
+            assert not np.array_equal(np.sort(a), np.sort(b))
+            if k == 8:
+                assert len(np.intersect1d(a, b)) <= 2                         # 24-bit values: chance collisions only
+    # kept counts of a block over a window of steps are binomial, not constant: mean and variance of #(u < 0.3) over 256 ids
+    nid = torch.arange(1 << 14, (1 << 14) + 256)
+    cnt = np.array([(bo.keyed_uniform(9, s, 0, nid).numpy() < 0.3).sum() for s in range(256)])
+    assert abs(cnt.mean() - 76.8) < 2.0 and 25 < cnt.var() < 90               # 256 * 0.3 * 0.7 = 53.8
