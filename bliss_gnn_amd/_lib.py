@@ -86,6 +86,20 @@ class TileGemm(C.Structure):                           # bliss_tile_gemm_t
                 ("relu", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_ctr", C.c_void_p)]
 
 
+class DGrad(C.Structure):                              # bliss_dgrad_t
+    _fields_ = [("a1", C.c_void_p), ("a1_stride", C.c_int64), ("w1", C.c_void_p), ("w1_stride", C.c_int64), ("k1", C.c_int32),
+                ("a2", C.c_void_p), ("a2_stride", C.c_int64), ("w2", C.c_void_p), ("w2_stride", C.c_int64), ("k2", C.c_int32),
+                ("m2_bound", C.c_int32), ("m2_dev", C.c_void_p),
+                ("m_bound", C.c_int32), ("m_dev", C.c_void_p), ("n", C.c_int32), ("out", C.c_void_p), ("out_stride", C.c_int64)]
+
+
+class WGrad(C.Structure):                              # bliss_wgrad_t
+    _fields_ = [("d", C.c_void_p), ("d_stride", C.c_int64), ("n_out", C.c_int32),
+                ("x", C.c_void_p), ("x_stride", C.c_int64), ("k_in", C.c_int32),
+                ("rows_bound", C.c_int32), ("rows_dev", C.c_void_p),
+                ("dw", C.c_void_p), ("dw_stride", C.c_int64), ("db", C.c_void_p)]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -149,6 +163,8 @@ SIGNATURES = {
     "bliss_exp3_normalize": [_P, _I64, _P, _P, _P, _P],
     "bliss_row_sum": [_P, _I64, _P, _P],
     "bliss_gat_logits": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
+    "bliss_sage_dgrad": [C.POINTER(DGrad), _P],
+    "bliss_sage_wgrad": [C.POINTER(WGrad), _I32, _P, _I64, _P],
     "bliss_gat_logits_f32": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
     "bliss_gat_edge_dot": [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _P, _P],
     "bliss_gat_edge_softmax": [_P, _I32, _P, _P, _I32, C.c_int, _P, _P],
@@ -162,7 +178,7 @@ SIGNATURES = {
 
 
 SPECIAL_SIGNATURES = ("bliss_prof_kernel_name", "bliss_block_transpose_temp_bytes", "bliss_graph_prepare_capacity",
-                      "bliss_graph_prepare_temp_bytes", "bliss_rng_stream_handle")   # non-int return types, set in _load()
+                      "bliss_graph_prepare_temp_bytes", "bliss_rng_stream_handle", "bliss_sage_wgrad_workspace")   # non-int return types, set in _load()
 
 
 def _load():
@@ -177,6 +193,8 @@ def _load():
         fn.restype = C.c_int
     lib.bliss_block_transpose_temp_bytes.argtypes = [_I32, _I32]
     lib.bliss_block_transpose_temp_bytes.restype = C.c_int64
+    lib.bliss_sage_wgrad_workspace.argtypes = [C.POINTER(WGrad), _I32]
+    lib.bliss_sage_wgrad_workspace.restype = C.c_int64
     for name in ("bliss_graph_prepare_capacity", "bliss_graph_prepare_temp_bytes"):
         getattr(lib, name).argtypes = [_I64, _I32, C.c_int]
         getattr(lib, name).restype = C.c_int64

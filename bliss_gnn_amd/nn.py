@@ -228,6 +228,59 @@ def _bf16c(t):
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
+
+# ------------------------------------------------------------------------------------------------ backward products (csrc/sage_bwd.hip)
+def _mfma_bwd_on():
+    """The hand-written MFMA backward (round 3).  BLISS_SAGE_MFMA_BWD=0 restores the library GEMMs of round 2."""
+    import os
+    return os.environ.get("BLISS_SAGE_MFMA_BWD", "1") != "0"
+
+
+def _bwd_ok(*mats):
+    return all(m is None or (m.is_cuda and m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1) for m in mats)
+
+
+def sage_dgrad(a1, w1, m_bound, m_dev=0, a2=None, w2=None, m2_bound=0, m2_dev=0):
+    """out[r] = a1[r] @ w1 (+ a2[r] @ w2 for r < m2): the gradient w.r.t. a layer's input rows; w = nn.Linear weights [out, in]."""
+    import ctypes as C
+    out = torch.empty(m_bound, w1.shape[1], dtype=torch.bfloat16, device=a1.device)
+    t = _lib.DGrad()
+    t.a1, t.a1_stride, t.w1, t.w1_stride, t.k1 = a1.data_ptr(), a1.stride(0), w1.data_ptr(), w1.stride(0), w1.shape[0]
+    if a2 is not None:
+        t.a2, t.a2_stride, t.w2, t.w2_stride, t.k2 = a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), w2.shape[0]
+        t.m2_bound, t.m2_dev = int(m2_bound), int(m2_dev)
+    t.m_bound, t.m_dev, t.n = int(m_bound), int(m_dev), w1.shape[1]
+    t.out, t.out_stride = out.data_ptr(), out.stride(0)
+    _lib.check(_lib.lib.bliss_sage_dgrad(C.byref(t), _stream()), "bliss_sage_dgrad")
+    return out
+
+
+def sage_wgrad(problems):
+    """[(d [R, n_out], x [R, k_in], rows_bound, rows_dev, want_bias)] (one or two) -> [(dW [n_out, k_in], db or None)]: the weight
+    (and bias) gradients of Linear layers, dW = d^T x over the block's rows, one launch pair for all of them."""
+    import ctypes as C
+    n = len(problems)
+    arr = (_lib.WGrad * n)()
+    outs = []
+    for i, (d, x, rb, rdev, want_b) in enumerate(problems):
+        dw = torch.empty(d.shape[1], x.shape[1], dtype=torch.bfloat16, device=d.device)
+        db = torch.empty(d.shape[1], dtype=torch.bfloat16, device=d.device) if want_b else None
+        a = arr[i]
+        a.d, a.d_stride, a.n_out = d.data_ptr(), d.stride(0), d.shape[1]
+        a.x, a.x_stride, a.k_in = x.data_ptr(), x.stride(0), x.shape[1]
+        a.rows_bound, a.rows_dev = int(rb), int(rdev)
+        a.dw, a.dw_stride, a.db = dw.data_ptr(), dw.stride(0), 0 if db is None else db.data_ptr()
+        outs.append((dw, db))
+    need = int(_lib.lib.bliss_sage_wgrad_workspace(arr, n))
+    if need < 0:
+        raise RuntimeError("bliss_sage_wgrad: invalid problem description")
+    # fp32 partial tiles: a scratch tensor of the caching allocator (inside a captured graph: of the graph's pool); the
+    # reduce kernel behind the product reads what the product wrote, in stream order, so nothing outlives the call
+    ws = torch.empty(max(need, 4), dtype=torch.float32, device=problems[0][0].device)
+    _lib.check(_lib.lib.bliss_sage_wgrad(arr, n, ws.data_ptr(), ws.numel(), _stream()), "bliss_sage_wgrad")
+    return outs
+
+
 class _SageLinearPair(torch.autograd.Function):
     """fc_neigh over all source rows and fc_self (+bias) over the destination rows of a W-first SAGEConv layer (in > out,
     [DGL-recalled] SURVEY.md m2/m4) in ONE launch; with ``ids`` the rows are gathered from ``x`` (a node-feature table) on
@@ -246,6 +299,7 @@ class _SageLinearPair(torch.autograd.Function):
                    _tg_args(x, ws, y, n_dst, ids=ids, bias=b_self, m_dev=dst_dev))
         ctx.save_for_backward(rows, wn, ws)
         ctx.gathered, ctx.n_dst, ctx.has_bias = ids is not None, n_dst, b_self is not None
+        ctx.n_src, ctx.src_dev, ctx.dst_dev = n_src, src_dev, dst_dev
         ctx.mark_non_differentiable(rows, norm) if ids is not None else ctx.mark_non_differentiable(norm)
         return z, y, rows, norm
 
@@ -254,6 +308,17 @@ class _SageLinearPair(torch.autograd.Function):
         rows, wn, ws = ctx.saved_tensors
         want_dx = not ctx.gathered and ctx.needs_input_grad[0]
         d_wn = d_ws = d_b = dx = None
+        if (_mfma_bwd_on() and dz is not None and dy is not None and wn.shape[0] <= 256 and _bwd_ok(rows, wn, ws)
+                and dz.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16):
+            # csrc/sage_bwd.hip: both weight gradients and the bias gradient in one launch pair, the input gradient
+            # (both Linears into one accumulator) in one launch
+            dz, dy = _bf16c(dz), _bf16c(dy)
+            (d_wn, _), (d_ws, d_b) = sage_wgrad([(dz, rows, ctx.n_src, ctx.src_dev, False), (dy, rows, ctx.n_dst, ctx.dst_dev, ctx.has_bias)])
+            if want_dx:
+                dx = sage_dgrad(dz, wn, ctx.n_src, ctx.src_dev, a2=dy, w2=ws, m2_bound=ctx.n_dst, m2_dev=ctx.dst_dev)
+                if _drows is not None:
+                    dx = dx + _drows
+            return dx, None, d_wn, d_ws, d_b, None, None, None, None
         if dz is not None:
             dz = _bf16c(dz)
             d_wn = _weight_grad(dz, rows)
@@ -313,7 +378,7 @@ class _SageDualLinear(torch.autograd.Function):
         norm = torch.empty(n_rows, dtype=torch.bfloat16, device=a1.device)
         _tile_gemm(_tg_args(a1, w1, out, n_rows, a2=a2, w2=w2, bias=bias, m_dev=rows_dev, out_norm=norm, relu=relu, p=p, seed=seed, ctr=ctr))
         ctx.save_for_backward(a1, a2, w1, w2, out)
-        ctx.relu, ctx.p, ctx.has_bias = relu, float(p), bias is not None
+        ctx.relu, ctx.p, ctx.has_bias, ctx.rows_dev = relu, float(p), bias is not None, rows_dev
         ctx.mark_non_differentiable(norm)
         return out, norm
 
@@ -329,6 +394,16 @@ class _SageDualLinear(torch.autograd.Function):
                                                         out.shape[1], ctx.p, din.data_ptr(), din.stride(0), _stream()),
                        "bliss_sage_epilogue_bwd")
             d = din
+        if _mfma_bwd_on() and w1.shape[0] <= 256 and _bwd_ok(d, a1, a2, w1, w2) and a1.shape[0] == d.shape[0] and a2.shape[0] >= d.shape[0]:
+            rd = ctx.rows_dev
+            (dw1, _), (dw2, db) = sage_wgrad([(d, a1, d.shape[0], rd, False), (d, a2, d.shape[0], rd, ctx.has_bias)])
+            da1 = sage_dgrad(d, w1, d.shape[0], rd) if ctx.needs_input_grad[0] else None
+            da2 = None
+            if ctx.needs_input_grad[1]:
+                da2 = sage_dgrad(d, w2, d.shape[0], rd)
+                if a2.shape[0] > d.shape[0]:
+                    da2 = torch.cat([da2, torch.zeros(a2.shape[0] - d.shape[0], da2.shape[1], dtype=da2.dtype, device=da2.device)])
+            return (da1, da2, dw1, dw2, db, None, None, None, None, None, None)
         return (d @ w1, d @ w2, d.t() @ a1, d.t() @ a2, _bias_grad(d) if ctx.has_bias else None, None, None, None, None, None, None)
 
 
@@ -347,7 +422,7 @@ class _SageAggDual(torch.autograd.Function):
         norm = torch.empty(n_dst, dtype=torch.bfloat16, device=h.device)
         _tile_gemm(_tg_args(agg, w1, out, n_dst, a2=h, w2=w2, bias=bias, m_dev=rows_dev, out_norm=norm, relu=relu, p=p, seed=seed, ctr=ctr))
         ctx.save_for_backward(agg, h, w1, w2, out, indptr, src, dst, w, counts, t_indptr, t_edge)
-        ctx.relu, ctx.p, ctx.has_bias, ctx.n_dst = relu, float(p), bias is not None, n_dst
+        ctx.relu, ctx.p, ctx.has_bias, ctx.n_dst, ctx.rows_dev = relu, float(p), bias is not None, n_dst, rows_dev
         ctx.mark_non_differentiable(norm)
         return out, norm
 
@@ -365,11 +440,22 @@ class _SageAggDual(torch.autograd.Function):
                        "bliss_sage_epilogue_bwd")
             d = din
         gh = None
+        mfma = _mfma_bwd_on() and w1.shape[0] <= 256 and _bwd_ok(d, agg, h, w1, w2)
         if ctx.needs_input_grad[0]:
             if t_indptr is None or t_edge is None:
                 raise RuntimeError("the block's by-source index (Block.transposed()) is needed to differentiate w.r.t. h")
-            gh = ops.spmm_t(t_indptr, t_edge, src, dst, indptr, w, d @ w1, h.shape[0], counts, True)
-            gh[: ctx.n_dst].addmm_(d, w2)
+            if mfma:
+                # A^T (d W_neigh) = (A^T d) W_neigh: the transposed aggregation first, then ONE launch for both Linears' input
+                # gradients -- gh = T W_neigh + (d W_self on the destination rows), fp32 accumulation, one rounding
+                t = ops.spmm_t(t_indptr, t_edge, src, dst, indptr, w, d, h.shape[0], counts, True)
+                src_dev = counts.data_ptr() + 12 if counts is not None else 0
+                gh = sage_dgrad(t, w1, h.shape[0], src_dev, a2=d, w2=w2, m2_bound=ctx.n_dst, m2_dev=ctx.rows_dev)
+            else:
+                gh = ops.spmm_t(t_indptr, t_edge, src, dst, indptr, w, d @ w1, h.shape[0], counts, True)
+                gh[: ctx.n_dst].addmm_(d, w2)
+        if mfma:
+            (dw1, _), (dw2, db) = sage_wgrad([(d, agg, ctx.n_dst, ctx.rows_dev, False), (d, h, ctx.n_dst, ctx.rows_dev, ctx.has_bias)])
+            return (gh, None, None, None, None, None, None, None, None, dw1, dw2, db, None, None, None, None, None)
         return (gh, None, None, None, None, None, None, None, None, d.t() @ agg, d.t() @ h[: ctx.n_dst],
                 _bias_grad(d) if ctx.has_bias else None, None, None, None, None, None)
 

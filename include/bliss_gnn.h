@@ -260,6 +260,32 @@ typedef struct {
 } bliss_tile_gemm_t;
 int bliss_tile_gemm(const bliss_tile_gemm_t* first, const bliss_tile_gemm_t* second_or_null, void* stream);
 
+/* The BACKWARD products of those Linear layers on the matrix cores (csrc/sage_bwd.hip) -- what autograd derives for
+ * fc_neigh / fc_self of dglnn.SAGEConv (model.py:303-308, 321-329); W = [out, in] as nn.Linear stores it.
+ *   bliss_sage_dgrad:  out[r, :] = A1[r, :] . W1 (+ A2[r, :] . W2 for r < min(m2_bound, *m2_dev)),  r < min(m_bound, *m_dev):
+ *                      the gradient w.r.t. a layer's input rows -- A = gradient rows [m, k], W = [k, n] (k = the layer's out
+ *                      features <= 256, n = its in features), fp32 accumulation over both products, one rounding to bf16;
+ *                      rows at or beyond *m_dev are written as zeros.
+ *   bliss_sage_wgrad:  for up to two problems in one launch pair:  dW[n, c] = sum_r D[r, n] X[r, c]  (bf16 [n_out, k_in]) and,
+ *                      with db != NULL, db[n] = sum_r D[r, n]; r < min(rows_bound, *rows_dev); n_out <= 256.  fp32 partial
+ *                      tiles per chunk of rows in `partials` (bliss_sage_wgrad_workspace floats, 16-byte aligned), summed in
+ *                      chunk order and rounded once: bitwise reproducible. */
+typedef struct {
+  const void* a1; int64_t a1_stride; const void* w1; int64_t w1_stride; int32_t k1;
+  const void* a2; int64_t a2_stride; const void* w2; int64_t w2_stride; int32_t k2; int32_t m2_bound; const int32_t* m2_dev;
+  int32_t m_bound; const int32_t* m_dev; int32_t n;
+  void* out; int64_t out_stride;
+} bliss_dgrad_t;
+int bliss_sage_dgrad(const bliss_dgrad_t* args, void* stream);
+typedef struct {
+  const void* d; int64_t d_stride; int32_t n_out;
+  const void* x; int64_t x_stride; int32_t k_in;
+  int32_t rows_bound; const int32_t* rows_dev;
+  void* dw; int64_t dw_stride; void* db;
+} bliss_wgrad_t;
+int64_t bliss_sage_wgrad_workspace(const bliss_wgrad_t* probs, int32_t n_probs);
+int bliss_sage_wgrad(const bliss_wgrad_t* probs, int32_t n_probs, float* partials, int64_t partial_floats, void* stream);
+
 /* nn.CrossEntropyLoss() (mean) on bf16 logits [n_rows, n_cls] and int64 labels (train_lightning.py:77-79, :142), forward and
  * gradient in one launch: *loss_out = mean_r (logsumexp(x_r) - x_r[y_r]) in fp32, dlogits = (softmax(x) - onehot(y)) / n_rows in
  * bf16.  row_loss: float[n_rows] scratch; ticket: zero-initialised uint32 (left zero); a label outside [0, n_cls) sets bit 2 in *err. */

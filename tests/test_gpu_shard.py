@@ -149,7 +149,10 @@ def test_sharded_train_step_two_shards_equal_one(cuda):
         n = 0
         for r in two:
             for nid, row in zip(r["preds"][s][0].tolist(), r["preds"][s][1]):
-                assert torch.allclose(row, ref[nid], rtol=3e-2, atol=3e-2)                 # bf16 rows; other GEMM tiles per row count
+                # bf16 rows after three bf16 layers (and, from step 1 on, parameters that have drifted by bf16 roundings): a few
+                # bf16 ulps of the ROW's scale -- the small logits of a row carry the absolute error of its large ones
+                tol = 4 * 2.0 ** -8 * max(1.0, float(ref[nid].abs().max()))
+                assert torch.allclose(row, ref[nid], rtol=3e-2, atol=tol)
                 n += 1
         assert n == len(ref)
         assert abs(two[0]["losses"][s] - one["losses"][s]) <= 2e-2 * max(1.0, abs(one["losses"][s]))
