@@ -384,6 +384,8 @@ __global__ void __launch_bounds__(TPB) k_frontier_pass3(const int64_t* __restric
 // reference evaluates sum_j min(c p_j, 1) up to 50 times over all C candidates with a host sync each
 // (bandit_sampler.py:396-401); with counts per distinct p the same sum costs 32 bins per thread.
 #define HIST_BINS 32768
+#define HWIN_LO 0x3000           // k_cand_number's LDS window of the histogram: bf16 patterns of [2^-31, 2)
+#define HWIN_N 4096
 #ifndef FIN_TPB
 #define FIN_TPB 1024             // (512: step 0.790 ms, 1024: 0.772, 256: 0.828 -- same box, Reddit-like loop)
 #endif
@@ -860,7 +862,12 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
                                                          const unsigned* __restrict__ bitmap, const int* __restrict__ word_prefix,
                                                          const int* __restrict__ tile_sum, bf16_t* __restrict__ p, int* hist,
                                                          int cap_c, int uniform_nodes, const FusedScale fs) {
-  __shared__ int lh[HIST_BINS];                       // 128 KiB static LDS (one workgroup per CU; gfx950 has 160 KiB)
+  // Histogram of p's bit patterns for the Poisson scale, privatised in LDS.  Round 2 kept all 32768 bins per workgroup
+  // (128 KiB: zeroing and flushing them was most of this kernel's 20-30 us); the importances of a frontier live in a narrow
+  // band -- sqrt of a sum of squared fractions: (2^-31, 2) covers them -- so the LDS copy is the 4096-bin window
+  // [HWIN_LO, HWIN_LO + HWIN_N) plus one counter for p == 0; anything else (never seen on the tested graphs) goes straight to
+  // the global histogram.  Same counts in `hist`, whatever the route.
+  __shared__ int lh[HWIN_N + 4];
   __shared__ int tile_off[MAX_TILES];
   __shared__ int sh[17];
   const int S = cnt->S;
@@ -876,9 +883,9 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
   if (C > cap_c) { C = cap_c; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, BLISS_ERR_CAP_CAND); }
   if (blockIdx.x == 0 && threadIdx.x == 0) cnt->C = C;
   if (blockIdx.x != 0 && (int)blockIdx.x * FIN_TPB >= C) return;      // surplus workgroups (workgroup 0 always takes part)
-  {                                                   // (16 bytes per LDS access: the 128 KiB are most of this kernel's work)
+  {
     int4* lh4 = reinterpret_cast<int4*>(lh);
-    for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) lh4[b] = make_int4(0, 0, 0, 0);
+    for (int b = threadIdx.x; b < (HWIN_N + 4) / 4; b += FIN_TPB) lh4[b] = make_int4(0, 0, 0, 0);
   }
   __syncthreads();
   int bad = 0;
@@ -900,20 +907,24 @@ __global__ void __launch_bounds__(FIN_TPB) k_cand_number(const int* __restrict__
     if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;            // :79-81 ones, 0 where out_degree == 0
     else pj = f2bf(sqrtf(bf2f(fixed_to_bf((int64_t)raw, FRAC_SRC, &bad))));   // :75 torch.sqrt(prob)
     p[id] = pj;
-    if (pj < HIST_BINS) atomicAdd(&lh[pj], 1); else bad |= BLISS_ERR_NONFINITE;
+    if (pj >= HIST_BINS) bad |= BLISS_ERR_NONFINITE;                     // sign bit set = negative / -0 cannot occur
+    else if ((unsigned)(pj - HWIN_LO) < (unsigned)HWIN_N) atomicAdd(&lh[pj - HWIN_LO], 1);
+    else if (pj == 0) atomicAdd(&lh[HWIN_N], 1);
+    else atomicAdd(hist + pj, 1);
   }
   __syncthreads();
   {
     const int4* lh4 = reinterpret_cast<const int4*>(lh);
-    for (int b = threadIdx.x; b < HIST_BINS / 4; b += FIN_TPB) {
+    for (int b = threadIdx.x; b < HWIN_N / 4; b += FIN_TPB) {
       const int4 v = lh4[b];
       if (v.x | v.y | v.z | v.w) {
-        if (v.x) atomicAdd(hist + 4 * b, v.x);
-        if (v.y) atomicAdd(hist + 4 * b + 1, v.y);
-        if (v.z) atomicAdd(hist + 4 * b + 2, v.z);
-        if (v.w) atomicAdd(hist + 4 * b + 3, v.w);
+        if (v.x) atomicAdd(hist + HWIN_LO + 4 * b, v.x);
+        if (v.y) atomicAdd(hist + HWIN_LO + 4 * b + 1, v.y);
+        if (v.z) atomicAdd(hist + HWIN_LO + 4 * b + 2, v.z);
+        if (v.w) atomicAdd(hist + HWIN_LO + 4 * b + 3, v.w);
       }
     }
+    if (threadIdx.x == 0 && lh[HWIN_N]) atomicAdd(hist, lh[HWIN_N]);
   }
   if (bad) atomicOr(&cnt->err, bad);
   if (fs.ticket) {
@@ -1474,9 +1485,9 @@ int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, cons
     int* tile_sum = ws->word_prefix;                     // [MAX_TILES] tile totals, then the word prefixes
     int* word_prefix = ws->word_prefix + MAX_TILES;
     PROF_LAUNCH(BK_BITMAP_SCAN, st, k_bitmap_tiles<<<grid_for(frontier_bound, (int64_t)BTILE * 32, MAX_TILES), 1024, 0, st>>>(ws->bitmap, word_prefix, tile_sum, cnt));
-    int gf = (ws->cap_c + FIN_TPB * 2 - 1) / (FIN_TPB * 2);          // one 128 KiB-LDS workgroup per CU: spread the latency-bound items
+    int gf = (ws->cap_c + FIN_TPB - 1) / FIN_TPB;                    // (24 KiB of LDS per workgroup since round 3: several per CU)
     if (gf < 1) gf = 1;
-    if (gf > 256) gf = 256;
+    if (gf > 512) gf = 512;
     PROF_LAUNCH(BK_CAND_NUMBER, st, k_cand_number<<<gf, FIN_TPB, 0, st>>>(
         seeds, cnt, ws->cand_nid, m->local_id, seed_p2, (const unsigned long long*)ws->touched_key,
         (const unsigned long long*)ws->touched_sum, ws->bitmap, word_prefix, tile_sum, (bf16_t*)ws->p, ws->hist, ws->cap_c, uniform_nodes,
