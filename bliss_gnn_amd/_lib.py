@@ -100,6 +100,16 @@ class WGrad(C.Structure):                              # bliss_wgrad_t
                 ("dw", C.c_void_p), ("dw_stride", C.c_int64), ("db", C.c_void_p)]
 
 
+class GatFused(C.Structure):                           # bliss_gat_fused_t
+    _fields_ = [("indptr", C.c_void_p), ("src", C.c_void_p), ("n_dst", C.c_int32), ("n_dst_dev", C.c_void_p),
+                ("feat", C.c_void_p), ("feat_stride", C.c_int64), ("attn", C.c_void_p), ("heads", C.c_int32), ("head_dim", C.c_int32),
+                ("negative_slope", C.c_float), ("e", C.c_void_p), ("a", C.c_void_p), ("a_drop", C.c_void_p),
+                ("rst", C.c_void_p), ("rst_stride", C.c_int64),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_ctr", C.c_void_p), ("drop_ctr_used", C.c_void_p),
+                ("g", C.c_void_p), ("g_stride", C.c_int64), ("de", C.c_void_p), ("d_er", C.c_void_p), ("d_er_stride", C.c_int64),
+                ("dattn_part", C.c_void_p)]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -165,6 +175,10 @@ SIGNATURES = {
     "bliss_gat_logits": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
     "bliss_sage_dgrad": [C.POINTER(DGrad), _P],
     "bliss_sage_wgrad": [C.POINTER(WGrad), _I32, _P, _I64, _P],
+    "bliss_gat_fused_supported": [_I32, _I32],
+    "bliss_gat_fused_fwd": [C.POINTER(GatFused), _P],
+    "bliss_gat_fused_bwd_dst": [C.POINTER(GatFused), _P, _P, _P, _P],
+    "bliss_gat_rows_src_fused": [_P, _I32, _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _F, _P, _I64, _P, _P],
     "bliss_gat_logits_f32": [_P, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _F, _P, _P],
     "bliss_gat_edge_dot": [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _P, _P],
     "bliss_gat_edge_softmax": [_P, _I32, _P, _P, _I32, C.c_int, _P, _P],

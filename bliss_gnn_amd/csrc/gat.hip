@@ -172,7 +172,11 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
                                                      const bf16_t* __restrict__ coef, const bf16_t* __restrict__ feat,
                                                      int64_t feat_stride, const bf16_t* __restrict__ attn, int H, int D,
                                                      float slope, bf16_t* __restrict__ out, int64_t out_stride,
-                                                     float* __restrict__ part, float* __restrict__ d_attn) {
+                                                     float* __restrict__ part, float* __restrict__ d_attn,
+                                                     const bf16_t* __restrict__ coef2 = nullptr, const bf16_t* __restrict__ g2 = nullptr,
+                                                     int64_t g2_stride = 0) {
+  // (LBWD && BY_SRC with g2: the aggregation's backward rides along -- val(e, col) += coef2[e, h] * g2[dst_e, col], so that
+  // d el_j = sum over out-edges of (d e attn lrelu' + a d rst_i) comes out of ONE pass over the source's edges)
   __shared__ float sh_attn[LBWD && !BY_SRC ? 2048 : 1];
   const int nnz = nnz_dev ? min(*nnz_dev, nnz_host) : nnz_host;
   const int lane = lane_id();
@@ -227,6 +231,13 @@ __global__ void __launch_bounds__(GAT_TPB) k_gat_rows(const int* __restrict__ ro
         if (r != cur) { flush(cur); cur = r; }
         if (act) {
           const float cf = F32 ? reinterpret_cast<const float*>(coef)[(int64_t)e * H + hd] : bf2f(coef[(int64_t)e * H + hd]);
+          if (LBWD && BY_SRC && g2) {
+            const float cf2 = bf2f(coef2[(int64_t)e * H + hd]);
+            if (VEC4) {
+              const g4 f = gload4(g2 + (int64_t)d_ * g2_stride + col);
+              acc[0] += cf2 * f.x; acc[1 % W] += cf2 * f.y; acc[2 % W] += cf2 * f.z; acc[3 % W] += cf2 * f.w;
+            } else acc[0] += cf2 * bf2f(g2[(int64_t)d_ * g2_stride + col]);
+          }
           if (LBWD) {
             float xs[W], xd[W];
             if (VEC4) {
@@ -439,6 +450,29 @@ int bliss_gat_rows(int which, const int32_t* row_ptr, int32_t n_rows, const int3
 #undef ARGS
   if (v4 && ((uintptr_t)partials) % 16 == 0) k_gat_fixup<true><<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
   else k_gat_fixup<false><<<(n_rows + 3) / 4, GAT_TPB, 0, st>>>(row_ptr, n_rows, HD, partials, (bf16_t*)out, out_stride);
+  return (int)hipGetLastError();
+}
+
+int bliss_gat_rows_src_fused(const int32_t* t_indptr, int32_t n_src, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
+                             const int32_t* nnz_dev, int32_t nnz, const void* de, const void* a_drop, const void* feat, int64_t feat_stride,
+                             const void* g, int64_t g_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope,
+                             void* out, int64_t out_stride, float* partials, void* stream) {
+  if (!t_indptr || !de || !a_drop || !feat || !g || !attn || !out || heads <= 0 || heads > GAT_MAXH || head_dim <= 0 || n_src <= 0 || nnz < 0)
+    return BLISS_EINVAL;
+  if (nnz > 0 && (!src || !dst || !partials || !t_edge)) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int HD = heads * head_dim;
+  const int chunks = nnz > 0 ? (nnz + GEC - 1) / GEC : 1;
+  const dim3 grid((chunks + 3) / 4), block(GAT_TPB);
+  const bool v4 = head_dim % 4 == 0 && feat_stride % 4 == 0 && out_stride % 4 == 0 && g_stride % 4 == 0 && ((uintptr_t)feat) % 8 == 0 &&
+                  ((uintptr_t)out) % 8 == 0 && ((uintptr_t)attn) % 8 == 0 && ((uintptr_t)g) % 8 == 0;
+#define SRCF(V) k_gat_rows<true, true, V><<<grid, block, 0, st>>>(t_indptr, t_edge, src, dst, nnz_dev, nnz, (const bf16_t*)de, (const bf16_t*)feat, \
+    feat_stride, (const bf16_t*)attn, heads, head_dim, negative_slope, (bf16_t*)out, out_stride, partials, nullptr, (const bf16_t*)a_drop, \
+    (const bf16_t*)g, g_stride)
+  if (v4) SRCF(true); else SRCF(false);
+#undef SRCF
+  if (v4 && ((uintptr_t)partials) % 16 == 0) k_gat_fixup<true><<<(n_src + 3) / 4, GAT_TPB, 0, st>>>(t_indptr, n_src, HD, partials, (bf16_t*)out, out_stride);
+  else k_gat_fixup<false><<<(n_src + 3) / 4, GAT_TPB, 0, st>>>(t_indptr, n_src, HD, partials, (bf16_t*)out, out_stride);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,431 @@
+// GATv2 message passing, one workgroup per DESTINATION row (round 3) -- custom_GATv2Conv.forward, model.py:82-99, and its
+// backward by destination.  csrc/gat.hip runs the same arithmetic as five launches per direction that each re-gather the
+// 2 KB feature rows of every edge (logits: source + destination row; aggregation: source row again; backward: seven row
+// gathers per edge) and pass [B, H] tensors through memory in between: 760 us forward and 1.2 ms backward per step on the
+// Reddit-like config (profiles/r03_d_gat_step_timeline.txt).  Here a workgroup of 8 waves owns one destination i:
+//   forward   er_i stays in registers; pass 1 gathers el_j per in-edge -> logits e_ij[h] (stored: the reference returns them
+//             as "attention", model.py:108-110) and the per-head maximum; pass 2 is the edge softmax over the stored logits
+//             (exact per-destination sum like every copy_e_sum), with attention dropout (model.py:88) folded in; pass 3
+//             gathers el_j again (L2-warm) and accumulates  sum_j a_ij el_j.  Two row gathers per edge instead of three, one
+//             launch instead of five, no partial/fix-up pass (a row never leaves its workgroup).
+//   backward  (by destination) g_i = d rst_i and er_i in registers; pass 1: d a_ij = g_i . el_j and t = sum a d a; pass 2:
+//             d e_ij = a (d a - t) (softmax backward); pass 3: d er_i = sum_j d e_ij attn lrelu'(el_j + er_i) and this row's
+//             share of d attn.  The by-SOURCE half (d el_j: out-degrees are far more skewed) stays on the merge-style
+//             kernel of gat.hip, now with the aggregation's backward folded in.
+// The forward rounds exactly where gat.hip's kernels round (= where the reference's bf16 tensor ops round): the golden
+// fixtures of tests/golden/gat*_model_exp3.npz hold for both paths.  bf16 conversions use the hardware's
+// v_cvt_pk_bf16_f32 (round to nearest even, like common.cuh:f2bf on every finite input).
+#include "common.cuh"
+#include "bliss_gnn.h"
+
+namespace {
+
+#define GF_TPB 512
+#define GF_WAVES (GF_TPB / 64)
+#define GF_MAXH 8
+#define GF_ITER 4                      // a lane owns up to 4 groups of W consecutive columns: H*D <= 64 * W * 4
+
+__device__ __forceinline__ float rbf_hw(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ bf16_t f2bf_hw(float f) { const __bf16 b = (__bf16)f; return __builtin_bit_cast(unsigned short, b); }
+__device__ __forceinline__ float lrelu_f(float x, float s) { return x > 0.f ? x : s * x; }
+
+struct g4f { float v[4]; };
+template <bool VEC4>
+__device__ __forceinline__ g4f ldrow(const bf16_t* p) {            // W consecutive elements of a row as floats
+  g4f r;
+  if (VEC4) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+  } else { r.v[0] = bf2f(p[0]); r.v[1] = r.v[2] = r.v[3] = 0.f; }
+  return r;
+}
+
+__device__ __forceinline__ uint32_t gf_drop_hash(uint32_t seed, uint32_t ctr, uint32_t idx) {      // = drop_hash of spmm.hip / sage.hip
+  uint32_t x = idx * 0x9e3779b1u + seed;
+  x ^= ctr * 0x85ebca77u + 0x165667b1u;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  x += ctr; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+  return x;
+}
+
+struct GatFused {
+  const int* indptr; const int* src; int n_dst; const int* n_dst_dev;
+  const bf16_t* feat; long long feat_stride; const bf16_t* attn; int H, D; float slope;
+  bf16_t* e; bf16_t* a; bf16_t* ad;                    // [nnz, H]: logits, softmax, softmax after dropout (== a when p == 0)
+  bf16_t* rst; long long rst_stride;                   // forward output [n_dst, H*D]
+  unsigned drop_thresh; float drop_scale; unsigned seed; unsigned long long* ctr; unsigned* ctr_used;
+  // backward
+  const bf16_t* g; long long g_stride;                 // d rst [n_dst, H*D]
+  bf16_t* de;                                          // [nnz, H] out: d e (softmax backward), scratch for d a before that
+  bf16_t* d_er; long long der_stride;                  // [n_dst, H*D] out
+  float* dattn_part;                                   // [n_dst, H*D] out: this row's share of d attn
+};
+
+// per-head sums of a lane's partial values: part[h] over the wave (all lanes get the totals)
+__device__ __forceinline__ void wave_sum_heads(float* part, int H) {
+#pragma unroll
+  for (int h = 0; h < GF_MAXH; ++h)
+    if (h < H) { float s = part[h]; for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d); part[h] = s; }
+}
+
+template <bool VEC4>
+__global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
+  constexpr int W = VEC4 ? 4 : 1;
+  __shared__ float sh_acc[GF_WAVES][GF_ITER * 64 * W];          // cross-wave reduction of the output row (32 KiB when VEC4)
+  __shared__ float sh_max[GF_WAVES][GF_MAXH];
+  __shared__ unsigned long long sh_sum[GF_MAXH];
+  __shared__ int sh_bad;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row = blockIdx.x;
+  int S = p.n_dst;
+  if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
+  const int H = p.H, D = p.D, HD = H * D;
+  const uint32_t ctr = p.drop_thresh ? (uint32_t)__hip_atomic_load(p.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  if (row == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
+  if (row >= S) {                                      // capacity padding: finite zeros (and its ticket for the dropout counter)
+    for (int c = tid; c < HD; c += GF_TPB) p.rst[(long long)row * p.rst_stride + c] = 0;
+    if (p.drop_thresh && tid == 0 && atomicAdd(p.ctr + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
+      __hip_atomic_store(p.ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(p.ctr, 1ull);
+    }
+    return;
+  }
+  const int beg = p.indptr[row], end = p.indptr[row + 1];
+  // this lane's columns: group c covers columns c*64*W + lane*W .. +W-1 (one head per group when VEC4: D % 4 == 0)
+  float er[GF_ITER][W], at[GF_ITER][W], acc[GF_ITER][W];
+  int hd[GF_ITER];
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c) {
+    const int col = c * 64 * W + lane * W;
+    hd[c] = col < HD ? col / D : -1;
+    const g4f x = col < HD ? ldrow<VEC4>(p.feat + (long long)row * p.feat_stride + col) : g4f{{0.f, 0.f, 0.f, 0.f}};
+    const g4f t = col < HD ? ldrow<VEC4>(p.attn + col) : g4f{{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < W; ++j) { er[c][j] = x.v[j]; at[c][j] = t.v[j]; acc[c][j] = 0.f; }
+  }
+  if (tid < GF_MAXH) sh_sum[tid] = 0ull;
+  if (tid == 0) sh_bad = 0;
+  // ---- pass 1: logits (model.py:82-86, op by op like k_gat_edge_dot<0>) and the per-head maximum
+  float mx[GF_MAXH];
+#pragma unroll
+  for (int h = 0; h < GF_MAXH; ++h) mx[h] = -__builtin_inff();
+  for (int e = beg + wave; e < end; e += GF_WAVES) {
+    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+    float part[GF_MAXH];
+#pragma unroll
+    for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
+#pragma unroll
+    for (int c = 0; c < GF_ITER; ++c) {
+      if (hd[c] >= 0) {
+        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < W; ++j) v += rbf_hw(at[c][j] * rbf_hw(lrelu_f(rbf_hw(x.v[j] + er[c][j]), p.slope)));
+#pragma unroll
+        for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
+      }
+    }
+    wave_sum_heads(part, H);
+#pragma unroll
+    for (int h = 0; h < GF_MAXH; ++h) {
+      if (h < H) {
+        const bf16_t eb = f2bf_hw(part[h]);
+        if (lane == h) p.e[(long long)e * H + h] = eb;
+        mx[h] = fmaxf(mx[h], bf2f(eb));
+      }
+    }
+  }
+  if (lane < GF_MAXH) {
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int h = 0; h < GF_MAXH; ++h) if (h == lane) m = mx[h];
+    sh_max[wave][lane] = m;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's logits have left for L2 (write-through) before the barrier
+  __syncthreads();
+  // ---- pass 2: edge softmax over the stored logits (model.py:88-90; [DGL-recalled] four bf16 ops, exact sum), attention dropout
+  const int cnt = (end - beg) * H;
+  int bad = 0;
+  for (int i = tid; i < cnt; i += GF_TPB) {
+    const int h = i % H;
+    float m = sh_max[0][h];
+#pragma unroll
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) m = fmaxf(m, sh_max[w2][h]);
+    const bf16_t x = __hip_atomic_load(p.e + (long long)beg * H + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bf16_t sc = f2bf((float)exp((double)rbf(bf2f(x) - m)));
+    p.a[(long long)beg * H + i] = sc;                  // (this thread reads it back below)
+    const long long fx = bf_to_fixed(sc, FRAC_DST, &bad);
+    if (fx) atomicAdd(&sh_sum[h], (unsigned long long)fx);
+  }
+  if (bad) atomicOr(&sh_bad, bad);
+  __syncthreads();
+  for (int i = tid; i < cnt; i += GF_TPB) {
+    const int h = i % H;
+    int b2 = 0;
+    float ssum = bf2f(fixed_to_bf((long long)sh_sum[h], FRAC_DST, &b2));
+    if (sh_bad) ssum = __builtin_nanf("");             // a non-finite logit: the reference's sum, and with it the row, is NaN
+    const long long o = (long long)beg * H + i;
+    const bf16_t av = f2bf(bf2f(p.a[o]) / ssum);
+    p.a[o] = av;
+    if (p.drop_thresh) {                               // nn.Dropout on a bf16 tensor: a * mask / (1 - p), one rounding
+      const bool keep = gf_drop_hash(p.seed, ctr, (uint32_t)o) >= p.drop_thresh;
+      p.ad[o] = keep ? f2bf(bf2f(av) * p.drop_scale) : (bf16_t)0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- pass 3: out = sum_j a_ij el_j (model.py:98), fp32 products and sums, one rounding
+  const bf16_t* aw = p.drop_thresh ? p.ad : p.a;
+  for (int e = beg + wave; e < end; e += GF_WAVES) {
+    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+#pragma unroll
+    for (int c = 0; c < GF_ITER; ++c) {
+      if (hd[c] >= 0) {
+        const float cf = bf2f(__hip_atomic_load(aw + (long long)e * H + hd[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[c][j] += cf * x.v[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c)
+#pragma unroll
+    for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = acc[c][j];
+  __syncthreads();
+  for (int col = tid; col < HD; col += GF_TPB) {
+    float s = sh_acc[0][col];
+#pragma unroll
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];   // fixed order: bitwise reproducible
+    p.rst[(long long)row * p.rst_stride + col] = f2bf(s);
+  }
+  // dropout stream: the last workgroup bumps the launch counter (everybody has read it)
+  if (p.drop_thresh) {
+    __syncthreads();
+    if (tid == 0 && atomicAdd(p.ctr + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
+      __hip_atomic_store(p.ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(p.ctr, 1ull);
+    }
+  }
+}
+
+// backward by destination: d a, softmax backward, d er and the row's share of d attn
+template <bool VEC4>
+__global__ void __launch_bounds__(GF_TPB) k_gat_bwd_dst(GatFused p) {
+  constexpr int W = VEC4 ? 4 : 1;
+  __shared__ float sh_acc[GF_WAVES][GF_ITER * 64 * W];
+  __shared__ float sh_t[GF_WAVES][GF_MAXH];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row = blockIdx.x;
+  int S = p.n_dst;
+  if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
+  const int H = p.H, D = p.D, HD = H * D;
+  if (row >= p.n_dst) return;
+  if (row >= S) {
+    for (int c = tid; c < HD; c += GF_TPB) { p.d_er[(long long)row * p.der_stride + c] = 0; p.dattn_part[(long long)row * HD + c] = 0.f; }
+    return;
+  }
+  const int beg = p.indptr[row], end = p.indptr[row + 1];
+  float er[GF_ITER][W], at[GF_ITER][W], gr[GF_ITER][W];
+  int hd[GF_ITER];
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c) {
+    const int col = c * 64 * W + lane * W;
+    hd[c] = col < HD ? col / D : -1;
+    const g4f z = g4f{{0.f, 0.f, 0.f, 0.f}};
+    const g4f x = col < HD ? ldrow<VEC4>(p.feat + (long long)row * p.feat_stride + col) : z;
+    const g4f t = col < HD ? ldrow<VEC4>(p.attn + col) : z;
+    const g4f gg = col < HD ? ldrow<VEC4>(p.g + (long long)row * p.g_stride + col) : z;
+#pragma unroll
+    for (int j = 0; j < W; ++j) { er[c][j] = x.v[j]; at[c][j] = t.v[j]; gr[c][j] = gg.v[j]; }
+  }
+  // ---- pass 1: d a_ij[h] = g_i[h,:] . el_j[h,:] (bf16, like k_gat_edge_dot<1>), through the dropout mask; t[h] = sum a d a
+  float tp[GF_MAXH];
+#pragma unroll
+  for (int h = 0; h < GF_MAXH; ++h) tp[h] = 0.f;
+  for (int e = beg + wave; e < end; e += GF_WAVES) {
+    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+    float part[GF_MAXH];
+#pragma unroll
+    for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
+#pragma unroll
+    for (int c = 0; c < GF_ITER; ++c) {
+      if (hd[c] >= 0) {
+        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < W; ++j) v += gr[c][j] * x.v[j];
+#pragma unroll
+        for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
+      }
+    }
+    wave_sum_heads(part, H);
+#pragma unroll
+    for (int h = 0; h < GF_MAXH; ++h) {
+      if (h < H) {
+        const long long o = (long long)e * H + h;
+        float da = rbf_hw(part[h]);
+        if (p.drop_thresh) da = (p.ad[o] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;     // dropout backward (mask = what the forward kept)
+        if (lane == h) p.de[o] = f2bf_hw(da);
+        tp[h] += bf2f(p.a[o]) * da;
+      }
+    }
+  }
+  if (lane < GF_MAXH) {
+    float t = 0.f;
+#pragma unroll
+    for (int h = 0; h < GF_MAXH; ++h) if (h == lane) t = tp[h];
+    sh_t[wave][lane] = t;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- pass 2: d e = a (d a - t)   (k_gat_softmax<true>)
+  const int cnt = (end - beg) * H;
+  for (int i = tid; i < cnt; i += GF_TPB) {
+    const int h = i % H;
+    float t = sh_t[0][h];
+#pragma unroll
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) t += sh_t[w2][h];
+    const long long o = (long long)beg * H + i;
+    const float da = bf2f(__hip_atomic_load(p.de + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    p.de[o] = f2bf(bf2f(p.a[o]) * (da - t));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- pass 3: d er_i = sum_j d e attn lrelu'(el_j + er_i);  d attn += d e lrelu(el_j + er_i)   (k_gat_rows<true, false>)
+  float dacc[GF_ITER][W], aacc[GF_ITER][W];
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c)
+#pragma unroll
+    for (int j = 0; j < W; ++j) { dacc[c][j] = 0.f; aacc[c][j] = 0.f; }
+  for (int e = beg + wave; e < end; e += GF_WAVES) {
+    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+#pragma unroll
+    for (int c = 0; c < GF_ITER; ++c) {
+      if (hd[c] >= 0) {
+        const float cf = bf2f(__hip_atomic_load(p.de + (long long)e * H + hd[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const float s = x.v[j] + er[c][j];
+          dacc[c][j] += cf * at[c][j] * (s > 0.f ? 1.f : p.slope);
+          aacc[c][j] += cf * lrelu_f(s, p.slope);
+        }
+      }
+    }
+  }
+  // two cross-wave reductions through the same LDS buffer
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c)
+#pragma unroll
+    for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = dacc[c][j];
+  __syncthreads();
+  for (int col = tid; col < HD; col += GF_TPB) {
+    float s = sh_acc[0][col];
+#pragma unroll
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
+    p.d_er[(long long)row * p.der_stride + col] = f2bf(s);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c)
+#pragma unroll
+    for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = aacc[c][j];
+  __syncthreads();
+  for (int col = tid; col < HD; col += GF_TPB) {
+    float s = sh_acc[0][col];
+#pragma unroll
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
+    p.dattn_part[(long long)row * HD + col] = s;
+  }
+}
+
+// d attn[col] = sum over the destination rows of their shares, in row order (deterministic): stage 1 sums blocks of 64 rows,
+// the workgroup that finishes last adds the block sums in block order
+#define DA_ROWS 64
+__global__ void __launch_bounds__(256) k_gat_dattn_reduce(const float* __restrict__ part, int n_rows, const int* __restrict__ n_rows_dev,
+                                                          int HD, float* __restrict__ blocks, float* __restrict__ d_attn, unsigned* ticket) {
+  int S = n_rows;
+  if (n_rows_dev) { const int t = *n_rows_dev; S = t < S ? t : S; }
+  const int nb = (S + DA_ROWS - 1) / DA_ROWS;
+  const int b = blockIdx.x;
+  if (b < nb) {
+    const int r0 = b * DA_ROWS, r1 = min(S, r0 + DA_ROWS);
+    for (int col = threadIdx.x; col < HD; col += 256) {
+      float s = 0.f;
+      for (int r = r0; r < r1; ++r) s += part[(long long)r * HD + col];
+      blocks[(long long)b * HD + col] = s;
+    }
+  }
+  __shared__ int last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (last) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+  }
+  __syncthreads();
+  if (!last) return;
+  for (int col = threadIdx.x; col < HD; col += 256) {
+    float s = 0.f;
+    for (int bb = 0; bb < nb; ++bb) s += __hip_atomic_load(blocks + (long long)bb * HD + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d_attn[col] = s;
+  }
+}
+
+bool gf_fill(const bliss_gat_fused_t* a, GatFused* p, bool* vec4) {
+  if (!a || !a->indptr || !a->feat || !a->attn || a->heads <= 0 || a->heads > GF_MAXH || a->head_dim <= 0 || a->n_dst <= 0) return false;
+  const int HD = a->heads * a->head_dim;
+  const bool v4 = a->head_dim % 4 == 0 && a->feat_stride % 4 == 0 && ((uintptr_t)a->feat) % 8 == 0 && ((uintptr_t)a->attn) % 8 == 0 &&
+                  (!a->g || (a->g_stride % 4 == 0 && ((uintptr_t)a->g) % 8 == 0));
+  if (HD > GF_ITER * 64 * (v4 ? 4 : 1)) return false;
+  p->indptr = a->indptr; p->src = a->src; p->n_dst = a->n_dst; p->n_dst_dev = a->n_dst_dev;
+  p->feat = (const bf16_t*)a->feat; p->feat_stride = a->feat_stride; p->attn = (const bf16_t*)a->attn; p->H = a->heads; p->D = a->head_dim;
+  p->slope = a->negative_slope;
+  p->e = (bf16_t*)a->e; p->a = (bf16_t*)a->a; p->ad = (bf16_t*)a->a_drop;
+  p->rst = (bf16_t*)a->rst; p->rst_stride = a->rst_stride;
+  p->drop_thresh = a->drop_p > 0.f ? (unsigned)((double)a->drop_p * 4294967296.0) : 0u;
+  p->drop_scale = a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f;
+  p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr; p->ctr_used = (unsigned*)a->drop_ctr_used;
+  p->g = (const bf16_t*)a->g; p->g_stride = a->g_stride; p->de = (bf16_t*)a->de;
+  p->d_er = (bf16_t*)a->d_er; p->der_stride = a->d_er_stride; p->dattn_part = a->dattn_part;
+  *vec4 = v4;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bliss_gat_fused_supported(int32_t heads, int32_t head_dim) {
+  if (heads <= 0 || heads > GF_MAXH || head_dim <= 0) return 0;
+  return heads * head_dim <= GF_ITER * 64 * (head_dim % 4 == 0 ? 4 : 1);
+}
+
+int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream) {
+  GatFused p;
+  bool v4;
+  if (!gf_fill(args, &p, &v4) || !p.src || !p.e || !p.a || !p.rst) return BLISS_EINVAL;
+  if (p.drop_thresh && (!p.ad || !p.ctr)) return BLISS_EINVAL;
+  if (args->drop_p < 0.f || args->drop_p >= 1.f) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (v4) k_gat_fwd<true><<<p.n_dst, GF_TPB, 0, st>>>(p); else k_gat_fwd<false><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  return (int)hipGetLastError();
+}
+
+int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, float* d_attn, uint32_t* ticket, void* stream) {
+  GatFused p;
+  bool v4;
+  if (!gf_fill(args, &p, &v4) || !p.src || !p.a || !p.g || !p.de || !p.d_er || !p.dattn_part || !block_sums || !d_attn || !ticket) return BLISS_EINVAL;
+  if (p.drop_thresh && !p.ad) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (v4) k_gat_bwd_dst<true><<<p.n_dst, GF_TPB, 0, st>>>(p); else k_gat_bwd_dst<false><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  const int nb = (p.n_dst + DA_ROWS - 1) / DA_ROWS;
+  k_gat_dattn_reduce<<<nb, 256, 0, st>>>(p.dattn_part, p.n_dst, p.n_dst_dev, p.H * p.D, block_sums, d_attn, ticket);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -658,6 +658,78 @@ class _GatAggregate(torch.autograd.Function):
         return da, d_feat, None, None, None
 
 
+def _gat_fused_on(H, D):
+    import os
+    return os.environ.get("BLISS_GAT_FUSED", "1") != "0" and bool(_lib.lib.bliss_gat_fused_supported(int(H), int(D)))
+
+
+class _GatFusedMP(torch.autograd.Function):
+    """model.py:82-99 in ONE launch per direction and destination row (csrc/gat_fused.hip): (rst [S, H*D], e [B, H]) from
+    feat = fc_src(h) and attn, attention dropout inside (model.py:88; counter-hash stream like the SAGE epilogue's -- the same
+    Bernoulli(1-p)/scale law as nn.Dropout, not torch's Philox stream).  Backward: by destination in one launch pair (d a,
+    softmax backward, d er, d attn), by source in one merge-style pass (logits + aggregation backward together)."""
+
+    @staticmethod
+    def forward(ctx, feat, attn, block, H, D, slope, p_drop, state):
+        import ctypes as C
+        ctx.set_materialize_grads(False)
+        feat, attn_f = feat.contiguous(), attn.reshape(-1).contiguous()
+        nnz_ptr, B = _nnz(block)
+        S, HD, dev = block.num_dst_nodes(), H * D, feat.device
+        e = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
+        a = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
+        ad = torch.empty(B, H, dtype=torch.bfloat16, device=dev) if p_drop > 0 else a
+        rst = torch.empty(S, HD, dtype=torch.bfloat16, device=dev)
+        t = _lib.GatFused()
+        t.indptr, t.src, t.n_dst = block.indptr.data_ptr(), block.src.data_ptr(), S
+        t.n_dst_dev = block._counts_dev.data_ptr() if (block._nnz_ptr and getattr(block, "_counts_dev", None) is not None) else 0
+        t.feat, t.feat_stride, t.attn, t.heads, t.head_dim, t.negative_slope = feat.data_ptr(), feat.stride(0), attn_f.data_ptr(), H, D, float(slope)
+        t.e, t.a, t.a_drop, t.rst, t.rst_stride = e.data_ptr(), a.data_ptr(), ad.data_ptr(), rst.data_ptr(), rst.stride(0)
+        if p_drop > 0:
+            t.drop_p, t.drop_seed, t.drop_ctr = float(p_drop), int(state["seed"]) & 0xFFFFFFFF, state["ctr"].data_ptr()
+        _lib.check(_lib.lib.bliss_gat_fused_fwd(C.byref(t), _stream()), "bliss_gat_fused_fwd")
+        ctx.save_for_backward(feat, attn_f, a, ad)
+        ctx.block, ctx.H, ctx.D, ctx.slope, ctx.p, ctx.state, ctx.n_dst_dev = block, H, D, float(slope), float(p_drop), state, t.n_dst_dev
+        ctx.attn_shape, ctx.attn_dtype = attn.shape, attn.dtype
+        return rst, e
+
+    @staticmethod
+    def backward(ctx, d_rst, _d_e):
+        import ctypes as C
+        feat, attn_f, a, ad = ctx.saved_tensors
+        if _d_e is not None:
+            raise NotImplementedError("the returned logits are the bandit's a_ij (model.py:224-227): nothing differentiates through them")
+        if d_rst is None:
+            return (None,) * 8
+        block, H, D = ctx.block, ctx.H, ctx.D
+        nnz_ptr, B = _nnz(block)
+        K, S, HD, dev = feat.shape[0], block.num_dst_nodes(), H * D, feat.device
+        g = d_rst.reshape(S, HD)
+        g = (g if g.dtype == torch.bfloat16 else g.bfloat16()).contiguous()
+        de = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
+        d_er = torch.empty(S, HD, dtype=torch.bfloat16, device=dev)
+        dpart = torch.empty(S, HD, dtype=torch.float32, device=dev)
+        bsum = torch.empty(-(-S // 64), HD, dtype=torch.float32, device=dev)
+        d_attn = torch.empty(HD, dtype=torch.float32, device=dev)
+        t = _lib.GatFused()
+        t.indptr, t.src, t.n_dst, t.n_dst_dev = block.indptr.data_ptr(), block.src.data_ptr(), S, ctx.n_dst_dev
+        t.feat, t.feat_stride, t.attn, t.heads, t.head_dim, t.negative_slope = feat.data_ptr(), feat.stride(0), attn_f.data_ptr(), H, D, ctx.slope
+        t.a, t.a_drop = a.data_ptr(), ad.data_ptr()
+        t.drop_p = ctx.p
+        t.g, t.g_stride, t.de, t.d_er, t.d_er_stride, t.dattn_part = g.data_ptr(), g.stride(0), de.data_ptr(), d_er.data_ptr(), d_er.stride(0), dpart.data_ptr()
+        _lib.check(_lib.lib.bliss_gat_fused_bwd_dst(C.byref(t), bsum.data_ptr(), d_attn.data_ptr(), ctx.state["ticket"].data_ptr(), _stream()),
+                   "bliss_gat_fused_bwd_dst")
+        t_indptr, t_edge = block.transposed()
+        d_feat = torch.empty(K, HD, dtype=torch.bfloat16, device=dev)
+        part = torch.empty(max(2 * (-(-B // _lib.lib.bliss_gat_chunk_edges())) * HD, 4), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib.bliss_gat_rows_src_fused(t_indptr.data_ptr(), K, t_edge.data_ptr(), block.src.data_ptr(), block.dst.data_ptr(), nnz_ptr, B,
+                                                     de.data_ptr(), ad.data_ptr(), feat.data_ptr(), feat.stride(0), g.data_ptr(), g.stride(0),
+                                                     attn_f.data_ptr(), H, D, ctx.slope, d_feat.data_ptr(), d_feat.stride(0), part.data_ptr(),
+                                                     _stream()), "bliss_gat_rows_src_fused")
+        d_feat[:S] += d_er                                  # shared weights: the destinations are the first S source rows
+        return d_feat, d_attn.to(ctx.attn_dtype).view(ctx.attn_shape), None, None, None, None, None, None
+
+
 def edge_softmax(graph, logits):
     """``dglnn.functional.edge_softmax(graph, e)`` (model.py:88-90): softmax over the in-edges of every destination,
     per head; ``logits`` [B, H, 1] (or [B, H])."""
@@ -722,6 +794,15 @@ class GATv2Conv(nn.Module):
         if bias:
             nn.init.constant_(self.fc_src.bias, 0)
 
+    def _fused_state(self, device):
+        """Device state of the fused kernels: the attention-dropout launch counter (uint64[2]: counter, ticket), its seed, and
+        the ticket of the d attn reduction."""
+        st = getattr(self, "_fstate", None)
+        if st is None or st["ctr"].device != device:
+            st = self._fstate = dict(ctr=torch.zeros(2, dtype=torch.int64, device=device), ticket=torch.zeros(1, dtype=torch.int32, device=device),
+                                     seed=(torch.cuda.initial_seed() ^ (0x9E3779B1 * (id(self) & 0xFFFF))) & 0xFFFFFFFF)
+        return st
+
     def forward(self, graph, feat, edge_weight=None, get_attention=False):
         H, D, S = self._num_heads, self._out_feats, graph.num_dst_nodes()
         if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
@@ -729,9 +810,14 @@ class GATv2Conv(nn.Module):
                                "allow_zero_in_degree=True or add self loops")
         h_src = self.feat_drop(feat)
         feat_src = self.fc_src(h_src)                                            # :66-72, [K, H*D]; feat_dst = feat_src[:S]
-        e = _GatLogits.apply(feat_src, self.attn, graph, H, D, self.negative_slope)           # :82-86
-        a = self.attn_drop(_EdgeSoftmax.apply(e, graph, H))                      # :88-90
-        rst = _GatAggregate.apply(a, feat_src, graph, H, D).view(S, H, D)        # :98-99
+        if feat_src.is_cuda and feat_src.dtype == torch.bfloat16 and _gat_fused_on(H, D):
+            p_drop = float(self.attn_drop.p) if self.training else 0.0
+            rst, e = _GatFusedMP.apply(feat_src, self.attn, graph, H, D, self.negative_slope, p_drop, self._fused_state(feat_src.device))
+            rst = rst.view(S, H, D)                                              # :82-99 in one launch
+        else:
+            e = _GatLogits.apply(feat_src, self.attn, graph, H, D, self.negative_slope)           # :82-86
+            a = self.attn_drop(_EdgeSoftmax.apply(e, graph, H))                  # :88-90
+            rst = _GatAggregate.apply(a, feat_src, graph, H, D).view(S, H, D)    # :98-99
         if self.res_fc is not None:
             rst = rst + self.res_fc(h_src[:S]).view(S, -1, D)                    # :101-103
         if self.activation:

@@ -491,6 +491,32 @@ int bliss_gat_chunk_edges(void);
 int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_dev, int32_t nnz, const void* feat,
                      int64_t feat_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope, void* e_out,
                      void* stream);
+/* The same message passing with ONE workgroup per destination row (csrc/gat_fused.hip): bliss_gat_fused_fwd = logits + edge
+ * softmax (+ attention dropout, model.py:88) + aggregation in one launch -- e, a, a_drop [nnz, heads] bf16 and rst [n_dst,
+ * heads*head_dim] bf16 come out with the bits of the three separate kernels above; bliss_gat_fused_bwd_dst = d a, the softmax
+ * backward (de [nnz, heads]), d er [n_dst, heads*head_dim] and d attn (float [heads*head_dim], summed over the rows in row order:
+ * dattn_part float [n_dst, heads*head_dim], block_sums float [ceil(n_dst / 64), heads*head_dim], ticket zero-initialised) in
+ * one launch pair.  The by-source half of the backward is bliss_gat_rows(which = 3) with g / a_drop given (see below).
+ * n_dst_dev (optional) = the true row count of a capacity-padded block; drop_p > 0: drop_ctr = device uint64[2] (launch
+ * counter + ticket, zero-initialised), drop_ctr_used (optional uint32) receives the counter value this launch used.
+ * Supported when heads <= 8 and heads*head_dim <= 1024 (head_dim % 4 == 0) or <= 256: bliss_gat_fused_supported. */
+typedef struct {
+  const int32_t* indptr; const int32_t* src; int32_t n_dst; const int32_t* n_dst_dev;
+  const void* feat; int64_t feat_stride; const void* attn; int32_t heads; int32_t head_dim; float negative_slope;
+  void* e; void* a; void* a_drop;
+  void* rst; int64_t rst_stride;
+  float drop_p; uint32_t drop_seed; void* drop_ctr; void* drop_ctr_used;
+  const void* g; int64_t g_stride; void* de; void* d_er; int64_t d_er_stride; float* dattn_part;
+} bliss_gat_fused_t;
+int bliss_gat_fused_supported(int32_t heads, int32_t head_dim);
+/* d el[j, :] = sum over the out-edges e = (j -> i) of  de[e, h] attn lrelu'(feat[j] + feat[i])  +  a_drop[e, h] g[i, :]  -- the
+ * by-source half of the GATv2 backward (logits + aggregation) in one merge-style pass; partials as for bliss_gat_rows. */
+int bliss_gat_rows_src_fused(const int32_t* t_indptr, int32_t n_src, const int32_t* t_edge, const int32_t* src, const int32_t* dst,
+                             const int32_t* nnz_dev, int32_t nnz, const void* de, const void* a_drop, const void* feat, int64_t feat_stride,
+                             const void* g, int64_t g_stride, const void* attn, int32_t heads, int32_t head_dim, float negative_slope,
+                             void* out, int64_t out_stride, float* partials, void* stream);
+int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream);
+int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, float* d_attn, uint32_t* ticket, void* stream);
 /* bliss_gat_logits without the intermediate bf16 roundings, float result (the north star's 1e-4 check against fp32 math);
  * likewise bliss_gat_edge_softmax with backward == 2 (float logits in, float out) and bliss_gat_rows with which == 4 (the
  * forward aggregation with float coefficients and float output rows, out_stride in floats). */
