@@ -473,11 +473,29 @@ def bench_inference(args, g, cfg, hidden, dev, t_setup):
            "pass_ms_percentiles": percentiles(ms), "edges_per_sec": 3.0 * E / (mean_ms * 1e-3), "setup_s": t_setup}
     if spmm:
         achieved = total / (spmm["total_ms"] * 1e-3) / 1e9
+        # what the kernel actually moves into the CUs: one D-wide bf16 row per edge (|E| x 2 D bytes per layer), gathered from a
+        # [V, D] table of ~120 MB that lives in the 256 MiB Infinity Cache, not in the 4 MiB L2s.  MI355X_MICROARCH.md (section
+        # "Indexed rows: gather into LDS") measures 7.4-7.9 TB/s chip-wide for uniformly random rows of a 151 MB table: that,
+        # not the HBM peak, is this kernel's ceiling.
+        gather_bytes = float(sum(2 * E * d for d in dims))
+        gather_gbps = gather_bytes / (spmm["total_ms"] * 1e-3) / 1e9
+        traffic, pmc = None, None
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_inference_pmc.json")))
+        if pm:
+            pmc = json.load(open(pm[-1]))
+            if "fetch_bytes_per_pass_x2_corrected" in pmc:
+                traffic = pmc["fetch_bytes_per_pass_x2_corrected"] + pmc.get("write_bytes_per_pass", 0.0)
         out["roofline"] = {"bound": "hbm", "kernel": "k_spmm_fwd (mean over ALL in-edges, %d launches per pass)" % spmm["launches"],
                            "achieved": achieved, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / roofline.HBM_PEAK_GBPS,
-                           "traffic": None, "algorithmic_bytes_per_pass": total, "spmm_ms_per_pass": spmm["total_ms"],
-                           "note": "algorithmic bytes = 4(V+1) + 4|E| + 2 V D (in) + 2 V D (out) per layer; the gathered rows (|E| x 2D bytes) "
-                                   "are served by L2 / Infinity Cache and are not counted"}
+                           "traffic": traffic, "traffic_source": None if not pm else "profiles/%s (three rocprofv3 --pmc passes, bytes per inference pass)" % os.path.basename(pm[-1]),
+                           "algorithmic_bytes_per_pass": total, "spmm_ms_per_pass": spmm["total_ms"],
+                           "gather_bytes_per_pass": gather_bytes, "gather_GBps": gather_gbps,
+                           "gather_ceiling_GBps": [7400.0, 7900.0], "gather_frac_of_ceiling": gather_gbps / 7400.0,
+                           "pmc": pmc,
+                           "note": "algorithmic bytes = 4(V+1) + 4|E| + 2 V D (in) + 2 V D (out) per layer (what must cross HBM once); the kernel's "
+                                   "own bound is the row gather: |E| x 2D bytes per layer out of a cache-resident table, ceiling 7.4-7.9 TB/s "
+                                   "(MI355X_MICROARCH.md, 151 MB table, uniformly random rows)"}
     print(json.dumps(out), flush=True)
 
 

@@ -62,6 +62,40 @@ struct GatFused {
   float* dattn_part;                                   // [n_dst, H*D] out: this row's share of d attn
 };
 
+// A wave's share of a row's edges, SWEEP = 64 * GF_WAVES edges at a time: lane l of wave w holds the source id of edge
+// base + l * GF_WAVES + w, fetched with ONE coalesced load per sweep; the loop over the wave's edges then reads the id with
+// v_readlane (wave-uniform, no dependent global load per edge) and keeps the rows of TWO edges in flight.
+template <bool VEC4, int W>
+__device__ __forceinline__ void ld_edge_row(float (&x)[GF_ITER][W], const bf16_t* el, const int (&hd)[GF_ITER], int lane) {
+#pragma unroll
+  for (int c = 0; c < GF_ITER; ++c) {
+    if (hd[c] >= 0) {
+      const g4f t = ldrow<VEC4>(el + c * 64 * W + lane * W);
+#pragma unroll
+      for (int j = 0; j < W; ++j) x[c][j] = t.v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < W; ++j) x[c][j] = 0.f;
+    }
+  }
+}
+
+// per-edge, per-head coefficients ([nnz, H] bf16 arrays) of a sweep: lane l fetches those of ITS edge once (agent-scope loads:
+// another wave of the workgroup may have written them), the edge loop broadcasts them with v_readlane
+__device__ __forceinline__ void ld_edge_coefs(float (&cv)[GF_MAXH], const bf16_t* arr, long long e, int H, bool valid) {
+#pragma unroll
+  for (int h = 0; h < GF_MAXH; ++h)
+    cv[h] = (h < H && valid) ? bf2f(__hip_atomic_load(arr + e * H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
+}
+__device__ __forceinline__ float bcast_f32(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+// the coefficient of this lane's column group (head hd) out of the edge's H broadcast values
+__device__ __forceinline__ float pick_head(const float (&sv)[GF_MAXH], int hd) {
+  float r = 0.f;
+#pragma unroll
+  for (int h = 0; h < GF_MAXH; ++h) r = (h == hd) ? sv[h] : r;
+  return r;
+}
+
 // per-head sums of a lane's partial values: part[h] over the wave (all lanes get the totals)
 __device__ __forceinline__ void wave_sum_heads(float* part, int H) {
 #pragma unroll
@@ -110,18 +144,16 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   float mx[GF_MAXH];
 #pragma unroll
   for (int h = 0; h < GF_MAXH; ++h) mx[h] = -__builtin_inff();
-  for (int e = beg + wave; e < end; e += GF_WAVES) {
-    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+  auto logits_of = [&](const float (&x)[GF_ITER][W], int e) {
     float part[GF_MAXH];
 #pragma unroll
     for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
 #pragma unroll
     for (int c = 0; c < GF_ITER; ++c) {
       if (hd[c] >= 0) {
-        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
         float v = 0.f;
 #pragma unroll
-        for (int j = 0; j < W; ++j) v += rbf_hw(at[c][j] * rbf_hw(lrelu_f(rbf_hw(x.v[j] + er[c][j]), p.slope)));
+        for (int j = 0; j < W; ++j) v += rbf_hw(at[c][j] * rbf_hw(lrelu_f(rbf_hw(x[c][j] + er[c][j]), p.slope)));
 #pragma unroll
         for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
       }
@@ -134,6 +166,20 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
         if (lane == h) p.e[(long long)e * H + h] = eb;
         mx[h] = fmaxf(mx[h], bf2f(eb));
       }
+    }
+  };
+  for (int base = beg; base < end; base += 64 * GF_WAVES) {
+    const int my_e = base + lane * GF_WAVES + wave;
+    const int my_s = my_e < end ? p.src[my_e] : 0;
+    const int left = end - base - wave;
+    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
+    for (int j = 0; j < n_mine; j += 2) {
+      const bool two = j + 1 < n_mine;                  // (wave-uniform)
+      float x0[GF_ITER][W], x1[GF_ITER][W];
+      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
+      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      logits_of(x0, base + j * GF_WAVES + wave);
+      if (two) logits_of(x1, base + (j + 1) * GF_WAVES + wave);
     }
   }
   if (lane < GF_MAXH) {
@@ -177,16 +223,33 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   __syncthreads();
   // ---- pass 3: out = sum_j a_ij el_j (model.py:98), fp32 products and sums, one rounding
   const bf16_t* aw = p.drop_thresh ? p.ad : p.a;
-  for (int e = beg + wave; e < end; e += GF_WAVES) {
-    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+  for (int base = beg; base < end; base += 64 * GF_WAVES) {
+    const int my_e = base + lane * GF_WAVES + wave;
+    const int my_s = my_e < end ? p.src[my_e] : 0;
+    float my_a[GF_MAXH];
+    ld_edge_coefs(my_a, aw, my_e, H, my_e < end);
+    const int left = end - base - wave;
+    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
+    auto accumulate = [&](const float (&x)[GF_ITER][W], int j) {
+      float sv[GF_MAXH];
 #pragma unroll
-    for (int c = 0; c < GF_ITER; ++c) {
-      if (hd[c] >= 0) {
-        const float cf = bf2f(__hip_atomic_load(aw + (long long)e * H + hd[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
+      for (int h = 0; h < GF_MAXH; ++h) sv[h] = h < H ? bcast_f32(my_a[h], j) : 0.f;
 #pragma unroll
-        for (int j = 0; j < W; ++j) acc[c][j] += cf * x.v[j];
+      for (int c = 0; c < GF_ITER; ++c) {
+        if (hd[c] >= 0) {
+          const float cf = pick_head(sv, hd[c]);
+#pragma unroll
+          for (int jj = 0; jj < W; ++jj) acc[c][jj] += cf * x[c][jj];
+        }
       }
+    };
+    for (int j = 0; j < n_mine; j += 2) {
+      const bool two = j + 1 < n_mine;
+      float x0[GF_ITER][W], x1[GF_ITER][W];
+      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
+      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      accumulate(x0, j);
+      if (two) accumulate(x1, j + 1);
     }
   }
 #pragma unroll
@@ -212,7 +275,7 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
 
 // backward by destination: d a, softmax backward, d er and the row's share of d attn
 template <bool VEC4>
-__global__ void __launch_bounds__(GF_TPB) k_gat_bwd_dst(GatFused p) {
+__global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
   __shared__ float sh_acc[GF_WAVES][GF_ITER * 64 * W];
   __shared__ float sh_t[GF_WAVES][GF_MAXH];
@@ -244,32 +307,47 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_bwd_dst(GatFused p) {
   float tp[GF_MAXH];
 #pragma unroll
   for (int h = 0; h < GF_MAXH; ++h) tp[h] = 0.f;
-  for (int e = beg + wave; e < end; e += GF_WAVES) {
-    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
-    float part[GF_MAXH];
+  for (int base = beg; base < end; base += 64 * GF_WAVES) {
+    const int my_e = base + lane * GF_WAVES + wave;
+    const int my_s = my_e < end ? p.src[my_e] : 0;
+    float my_a[GF_MAXH], my_ad[GF_MAXH];
+    ld_edge_coefs(my_a, p.a, my_e, H, my_e < end);
+    if (p.drop_thresh) ld_edge_coefs(my_ad, p.ad, my_e, H, my_e < end);
+    const int left = end - base - wave;
+    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
+    auto da_of = [&](const float (&x)[GF_ITER][W], int j) {
+      const int e = base + j * GF_WAVES + wave;
+      float part[GF_MAXH];
 #pragma unroll
-    for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
+      for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
 #pragma unroll
-    for (int c = 0; c < GF_ITER; ++c) {
-      if (hd[c] >= 0) {
-        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
-        float v = 0.f;
+      for (int c = 0; c < GF_ITER; ++c) {
+        if (hd[c] >= 0) {
+          float v = 0.f;
 #pragma unroll
-        for (int j = 0; j < W; ++j) v += gr[c][j] * x.v[j];
+          for (int jj = 0; jj < W; ++jj) v += gr[c][jj] * x[c][jj];
 #pragma unroll
-        for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
+          for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
+        }
       }
-    }
-    wave_sum_heads(part, H);
+      wave_sum_heads(part, H);
 #pragma unroll
-    for (int h = 0; h < GF_MAXH; ++h) {
-      if (h < H) {
-        const long long o = (long long)e * H + h;
-        float da = rbf_hw(part[h]);
-        if (p.drop_thresh) da = (p.ad[o] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;     // dropout backward (mask = what the forward kept)
-        if (lane == h) p.de[o] = f2bf_hw(da);
-        tp[h] += bf2f(p.a[o]) * da;
+      for (int h = 0; h < GF_MAXH; ++h) {
+        if (h < H) {
+          float da = rbf_hw(part[h]);
+          if (p.drop_thresh) da = (bcast_f32(my_ad[h], j) != 0.f) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
+          if (lane == h) p.de[(long long)e * H + h] = f2bf_hw(da);
+          tp[h] += bcast_f32(my_a[h], j) * da;
+        }
       }
+    };
+    for (int j = 0; j < n_mine; j += 2) {
+      const bool two = j + 1 < n_mine;
+      float x0[GF_ITER][W], x1[GF_ITER][W];
+      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
+      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      da_of(x0, j);
+      if (two) da_of(x1, j + 1);
     }
   }
   if (lane < GF_MAXH) {
@@ -299,20 +377,37 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_bwd_dst(GatFused p) {
   for (int c = 0; c < GF_ITER; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) { dacc[c][j] = 0.f; aacc[c][j] = 0.f; }
-  for (int e = beg + wave; e < end; e += GF_WAVES) {
-    const bf16_t* el = p.feat + (long long)p.src[e] * p.feat_stride;
+  for (int base = beg; base < end; base += 64 * GF_WAVES) {
+    const int my_e = base + lane * GF_WAVES + wave;
+    const int my_s = my_e < end ? p.src[my_e] : 0;
+    float my_de[GF_MAXH];
+    ld_edge_coefs(my_de, p.de, my_e, H, my_e < end);
+    const int left = end - base - wave;
+    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
+    auto grads_of = [&](const float (&x)[GF_ITER][W], int j) {
+      float sv[GF_MAXH];
 #pragma unroll
-    for (int c = 0; c < GF_ITER; ++c) {
-      if (hd[c] >= 0) {
-        const float cf = bf2f(__hip_atomic_load(p.de + (long long)e * H + hd[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const g4f x = ldrow<VEC4>(el + c * 64 * W + lane * W);
+      for (int h = 0; h < GF_MAXH; ++h) sv[h] = h < H ? bcast_f32(my_de[h], j) : 0.f;
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const float s = x.v[j] + er[c][j];
-          dacc[c][j] += cf * at[c][j] * (s > 0.f ? 1.f : p.slope);
-          aacc[c][j] += cf * lrelu_f(s, p.slope);
+      for (int c = 0; c < GF_ITER; ++c) {
+        if (hd[c] >= 0) {
+          const float cf = pick_head(sv, hd[c]);
+#pragma unroll
+          for (int jj = 0; jj < W; ++jj) {
+            const float sx = x[c][jj] + er[c][jj];
+            dacc[c][jj] += cf * at[c][jj] * (sx > 0.f ? 1.f : p.slope);
+            aacc[c][jj] += cf * lrelu_f(sx, p.slope);
+          }
         }
       }
+    };
+    for (int j = 0; j < n_mine; j += 2) {
+      const bool two = j + 1 < n_mine;
+      float x0[GF_ITER][W], x1[GF_ITER][W];
+      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
+      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      grads_of(x0, j);
+      if (two) grads_of(x1, j + 1);
     }
   }
   // two cross-wave reductions through the same LDS buffer
@@ -341,39 +436,36 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_bwd_dst(GatFused p) {
   }
 }
 
-// d attn[col] = sum over the destination rows of their shares, in row order (deterministic): stage 1 sums blocks of 64 rows,
-// the workgroup that finishes last adds the block sums in block order
-#define DA_ROWS 64
-__global__ void __launch_bounds__(256) k_gat_dattn_reduce(const float* __restrict__ part, int n_rows, const int* __restrict__ n_rows_dev,
-                                                          int HD, float* __restrict__ blocks, float* __restrict__ d_attn, unsigned* ticket) {
+// d attn[col] = sum over the destination rows of their shares, in a fixed order (deterministic, no float atomics): stage 1 sums
+// blocks of DA_ROWS rows (one workgroup per block and 256 columns, 8 independent loads in flight per thread), stage 2 the block
+// sums (64 columns per workgroup, four row groups combined through LDS in group order)
+#define DA_ROWS 32
+__global__ void __launch_bounds__(256) k_gat_dattn_stage1(const float* __restrict__ part, int n_rows, const int* __restrict__ n_rows_dev,
+                                                          int HD, float* __restrict__ blocks) {
   int S = n_rows;
   if (n_rows_dev) { const int t = *n_rows_dev; S = t < S ? t : S; }
-  const int nb = (S + DA_ROWS - 1) / DA_ROWS;
-  const int b = blockIdx.x;
-  if (b < nb) {
-    const int r0 = b * DA_ROWS, r1 = min(S, r0 + DA_ROWS);
-    for (int col = threadIdx.x; col < HD; col += 256) {
-      float s = 0.f;
-      for (int r = r0; r < r1; ++r) s += part[(long long)r * HD + col];
-      blocks[(long long)b * HD + col] = s;
-    }
+  const int col = blockIdx.y * 256 + threadIdx.x, r0 = blockIdx.x * DA_ROWS, r1 = min(S, r0 + DA_ROWS);
+  if (col >= HD) return;
+  float s = 0.f;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = part[(long long)(r + i) * HD + col];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
   }
-  __shared__ int last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (; r < r1; ++r) s += part[(long long)r * HD + col];
+  blocks[(long long)blockIdx.x * HD + col] = s;          // (blocks beyond the true row count hold 0)
+}
+__global__ void __launch_bounds__(256) k_gat_dattn_stage2(const float* __restrict__ blocks, int nb, int HD, float* __restrict__ d_attn) {
+  __shared__ float sh[4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (col < HD) for (int b = grp; b < nb; b += 4) s += blocks[(long long)b * HD + col];
+  sh[grp][c] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    if (last) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-  }
-  __syncthreads();
-  if (!last) return;
-  for (int col = threadIdx.x; col < HD; col += 256) {
-    float s = 0.f;
-    for (int bb = 0; bb < nb; ++bb) s += __hip_atomic_load(blocks + (long long)bb * HD + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    d_attn[col] = s;
-  }
+  if (grp == 0 && col < HD) d_attn[col] = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
 }
 
 bool gf_fill(const bliss_gat_fused_t* a, GatFused* p, bool* vec4) {
@@ -423,8 +515,10 @@ int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, fl
   if (p.drop_thresh && !p.ad) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (v4) k_gat_bwd_dst<true><<<p.n_dst, GF_TPB, 0, st>>>(p); else k_gat_bwd_dst<false><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  const int nb = (p.n_dst + DA_ROWS - 1) / DA_ROWS;
-  k_gat_dattn_reduce<<<nb, 256, 0, st>>>(p.dattn_part, p.n_dst, p.n_dst_dev, p.H * p.D, block_sums, d_attn, ticket);
+  const int nb = (p.n_dst + DA_ROWS - 1) / DA_ROWS, HD = p.H * p.D;
+  k_gat_dattn_stage1<<<dim3(nb, (HD + 255) / 256), 256, 0, st>>>(p.dattn_part, p.n_dst, p.n_dst_dev, HD, block_sums);
+  k_gat_dattn_stage2<<<(HD + 63) / 64, 256, 0, st>>>(block_sums, nb, HD, d_attn);
+  (void)ticket;
   return (int)hipGetLastError();
 }
 

@@ -709,7 +709,7 @@ class _GatFusedMP(torch.autograd.Function):
         de = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
         d_er = torch.empty(S, HD, dtype=torch.bfloat16, device=dev)
         dpart = torch.empty(S, HD, dtype=torch.float32, device=dev)
-        bsum = torch.empty(-(-S // 64), HD, dtype=torch.float32, device=dev)
+        bsum = torch.empty(-(-S // 32), HD, dtype=torch.float32, device=dev)
         d_attn = torch.empty(HD, dtype=torch.float32, device=dev)
         t = _lib.GatFused()
         t.indptr, t.src, t.n_dst, t.n_dst_dev = block.indptr.data_ptr(), block.src.data_ptr(), S, ctx.n_dst_dev

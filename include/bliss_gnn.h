@@ -495,8 +495,8 @@ int bliss_gat_logits(const int32_t* src, const int32_t* dst, const int32_t* nnz_
  * softmax (+ attention dropout, model.py:88) + aggregation in one launch -- e, a, a_drop [nnz, heads] bf16 and rst [n_dst,
  * heads*head_dim] bf16 come out with the bits of the three separate kernels above; bliss_gat_fused_bwd_dst = d a, the softmax
  * backward (de [nnz, heads]), d er [n_dst, heads*head_dim] and d attn (float [heads*head_dim], summed over the rows in row order:
- * dattn_part float [n_dst, heads*head_dim], block_sums float [ceil(n_dst / 64), heads*head_dim], ticket zero-initialised) in
- * one launch pair.  The by-source half of the backward is bliss_gat_rows(which = 3) with g / a_drop given (see below).
+ * dattn_part float [n_dst, heads*head_dim], block_sums float [ceil(n_dst / 32), heads*head_dim], ticket unused) in
+ * three launches.  The by-source half of the backward is bliss_gat_rows(which = 3) with g / a_drop given (see below).
  * n_dst_dev (optional) = the true row count of a capacity-padded block; drop_p > 0: drop_ctr = device uint64[2] (launch
  * counter + ticket, zero-initialised), drop_ctr_used (optional uint32) receives the counter value this launch used.
  * Supported when heads <= 8 and heads*head_dim <= 1024 (head_dim % 4 == 0) or <= 256: bliss_gat_fused_supported. */
