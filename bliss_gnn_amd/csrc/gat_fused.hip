@@ -65,48 +65,72 @@ struct GatFused {
 // A wave's share of a row's edges, SWEEP = 64 * GF_WAVES edges at a time: lane l of wave w holds the source id of edge
 // base + l * GF_WAVES + w, fetched with ONE coalesced load per sweep; the loop over the wave's edges then reads the id with
 // v_readlane (wave-uniform, no dependent global load per edge) and keeps the rows of TWO edges in flight.
-template <bool VEC4, int W>
-__device__ __forceinline__ void ld_edge_row(float (&x)[GF_ITER][W], const bf16_t* el, const int (&hd)[GF_ITER], int lane) {
+template <bool VEC4, int W, int NG>
+__device__ __forceinline__ void ld_edge_row(float (&x)[NG][W], const bf16_t* el, const int (&coff)[NG]) {
+  // UNCONDITIONAL loads from clamped (always valid) column offsets: a load under a lane-dependent branch makes the compiler wait
+  // for everything outstanding (csrc/sage.hip found the same); columns beyond H*D are masked where the values are used
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c) {
-    if (hd[c] >= 0) {
-      const g4f t = ldrow<VEC4>(el + c * 64 * W + lane * W);
+  for (int c = 0; c < NG; ++c) {
+    const g4f t = ldrow<VEC4>(el + coff[c]);
 #pragma unroll
-      for (int j = 0; j < W; ++j) x[c][j] = t.v[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < W; ++j) x[c][j] = 0.f;
-    }
+    for (int j = 0; j < W; ++j) x[c][j] = t.v[j];
   }
 }
 
 // per-edge, per-head coefficients ([nnz, H] bf16 arrays) of a sweep: lane l fetches those of ITS edge once (agent-scope loads:
 // another wave of the workgroup may have written them), the edge loop broadcasts them with v_readlane
-__device__ __forceinline__ void ld_edge_coefs(float (&cv)[GF_MAXH], const bf16_t* arr, long long e, int H, bool valid) {
+template <int NH>
+__device__ __forceinline__ void ld_edge_coefs(float (&cv)[NH], const bf16_t* arr, long long e, int H, bool valid) {
+  // one agent-scope load per edge where the H values form an aligned 2 / 4 / 8 / 16-byte unit (each atomic load is waited for)
 #pragma unroll
-  for (int h = 0; h < GF_MAXH; ++h)
-    cv[h] = (h < H && valid) ? bf2f(__hip_atomic_load(arr + e * H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
+  for (int h = 0; h < NH; ++h) cv[h] = 0.f;
+  if (!valid) return;
+  const bf16_t* q = arr + e * H;
+  if (NH >= 4 && H == 4) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cv[0] = bf2f((bf16_t)(v & 0xffffu)); cv[1 % NH] = bf2f((bf16_t)((v >> 16) & 0xffffu));
+    cv[2 % NH] = bf2f((bf16_t)((v >> 32) & 0xffffu)); cv[3 % NH] = bf2f((bf16_t)(v >> 48));
+  } else if (NH >= 8 && H == 8) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cv[0] = bf2f((bf16_t)(v & 0xffffu)); cv[1 % NH] = bf2f((bf16_t)((v >> 16) & 0xffffu));
+    cv[2 % NH] = bf2f((bf16_t)((v >> 32) & 0xffffu)); cv[3 % NH] = bf2f((bf16_t)(v >> 48));
+    cv[4 % NH] = bf2f((bf16_t)(w & 0xffffu)); cv[5 % NH] = bf2f((bf16_t)((w >> 16) & 0xffffu));
+    cv[6 % NH] = bf2f((bf16_t)((w >> 32) & 0xffffu)); cv[7 % NH] = bf2f((bf16_t)(w >> 48));
+  } else if (NH >= 2 && H == 2) {
+    const unsigned v = __hip_atomic_load(reinterpret_cast<const unsigned*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cv[0] = bf2f((bf16_t)(v & 0xffffu)); cv[1 % NH] = bf2f((bf16_t)(v >> 16));
+  } else {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (h < H) cv[h] = bf2f(__hip_atomic_load(q + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
 }
 __device__ __forceinline__ float bcast_f32(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 // the coefficient of this lane's column group (head hd) out of the edge's H broadcast values
-__device__ __forceinline__ float pick_head(const float (&sv)[GF_MAXH], int hd) {
+template <int NH>
+__device__ __forceinline__ float pick_head(const float (&sv)[NH], int hd) {
   float r = 0.f;
 #pragma unroll
-  for (int h = 0; h < GF_MAXH; ++h) r = (h == hd) ? sv[h] : r;
+  for (int h = 0; h < NH; ++h) r = (h == hd) ? sv[h] : r;
   return r;
 }
 
 // per-head sums of a lane's partial values: part[h] over the wave (all lanes get the totals)
-__device__ __forceinline__ void wave_sum_heads(float* part, int H) {
+template <int NH>
+__device__ __forceinline__ void wave_sum_heads(float (&part)[NH], int H) {
 #pragma unroll
-  for (int h = 0; h < GF_MAXH; ++h)
+  for (int h = 0; h < NH; ++h)
     if (h < H) { float s = part[h]; for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d); part[h] = s; }
 }
 
-template <bool VEC4>
+template <bool VEC4, int HG>
 __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
-  __shared__ float sh_acc[GF_WAVES][GF_ITER * 64 * W];          // cross-wave reduction of the output row (32 KiB when VEC4)
+  // HG > 0: "a column group is a head" (VEC4, D == 256: group c of 64 lanes x 4 columns IS head c, H == HG <= 4) -- the Reddit
+  // config's 4 x 256; every per-head selection below is then a compile-time index.  HG == 0: any H <= 8, D (head by compare)
+  constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
+  __shared__ float sh_acc[GF_WAVES][NG * 64 * W];          // cross-wave reduction of the output row (32 KiB when VEC4)
   __shared__ float sh_max[GF_WAVES][GF_MAXH];
   __shared__ unsigned long long sh_sum[GF_MAXH];
   __shared__ int sh_bad;
@@ -114,7 +138,7 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   const int row = blockIdx.x;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
-  const int H = p.H, D = p.D, HD = H * D;
+  const int H = HG ? HG : p.H, D = p.D, HD = H * D;
   const uint32_t ctr = p.drop_thresh ? (uint32_t)__hip_atomic_load(p.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   if (row == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
   if (row >= S) {                                      // capacity padding: finite zeros (and its ticket for the dropout counter)
@@ -127,12 +151,13 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   }
   const int beg = p.indptr[row], end = p.indptr[row + 1];
   // this lane's columns: group c covers columns c*64*W + lane*W .. +W-1 (one head per group when VEC4: D % 4 == 0)
-  float er[GF_ITER][W], at[GF_ITER][W], acc[GF_ITER][W];
-  int hd[GF_ITER];
+  float er[NG][W], at[NG][W], acc[NG][W];
+  int hd[NG], coff[NG];
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c) {
+  for (int c = 0; c < NG; ++c) {
     const int col = c * 64 * W + lane * W;
     hd[c] = col < HD ? col / D : -1;
+    coff[c] = col < HD ? col : 0;                       // (masked columns re-read the row's first W elements; at = 0 there)
     const g4f x = col < HD ? ldrow<VEC4>(p.feat + (long long)row * p.feat_stride + col) : g4f{{0.f, 0.f, 0.f, 0.f}};
     const g4f t = col < HD ? ldrow<VEC4>(p.attn + col) : g4f{{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -141,26 +166,32 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   if (tid < GF_MAXH) sh_sum[tid] = 0ull;
   if (tid == 0) sh_bad = 0;
   // ---- pass 1: logits (model.py:82-86, op by op like k_gat_edge_dot<0>) and the per-head maximum
-  float mx[GF_MAXH];
+  float mx[NH];
 #pragma unroll
-  for (int h = 0; h < GF_MAXH; ++h) mx[h] = -__builtin_inff();
-  auto logits_of = [&](const float (&x)[GF_ITER][W], int e) {
-    float part[GF_MAXH];
+  for (int h = 0; h < NH; ++h) mx[h] = -__builtin_inff();
+  auto logits_of = [&](const float (&x)[NG][W], int e) {
+    float part[NH];
 #pragma unroll
-    for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
+    for (int h = 0; h < NH; ++h) part[h] = 0.f;
 #pragma unroll
-    for (int c = 0; c < GF_ITER; ++c) {
-      if (hd[c] >= 0) {
+    for (int c = 0; c < NG; ++c) {
+      if (HG || hd[c] >= 0) {
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < W; ++j) v += rbf_hw(at[c][j] * rbf_hw(lrelu_f(rbf_hw(x[c][j] + er[c][j]), p.slope)));
+        if (HG) part[c % NH] += v;
+        else {
+          if (HG) part[c % NH] += v;
+          else {
 #pragma unroll
-        for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
+            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+          }
+        }
       }
     }
     wave_sum_heads(part, H);
 #pragma unroll
-    for (int h = 0; h < GF_MAXH; ++h) {
+    for (int h = 0; h < NH; ++h) {
       if (h < H) {
         const bf16_t eb = f2bf_hw(part[h]);
         if (lane == h) p.e[(long long)e * H + h] = eb;
@@ -175,17 +206,17 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
     for (int j = 0; j < n_mine; j += 2) {
       const bool two = j + 1 < n_mine;                  // (wave-uniform)
-      float x0[GF_ITER][W], x1[GF_ITER][W];
-      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
-      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      float x0[NG][W], x1[NG][W];
+      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
+      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
       logits_of(x0, base + j * GF_WAVES + wave);
       if (two) logits_of(x1, base + (j + 1) * GF_WAVES + wave);
     }
   }
-  if (lane < GF_MAXH) {
+  if (lane < NH) {
     float m = -__builtin_inff();
 #pragma unroll
-    for (int h = 0; h < GF_MAXH; ++h) if (h == lane) m = mx[h];
+    for (int h = 0; h < NH; ++h) if (h == lane) m = mx[h];
     sh_max[wave][lane] = m;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's logits have left for L2 (write-through) before the barrier
@@ -226,18 +257,18 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   for (int base = beg; base < end; base += 64 * GF_WAVES) {
     const int my_e = base + lane * GF_WAVES + wave;
     const int my_s = my_e < end ? p.src[my_e] : 0;
-    float my_a[GF_MAXH];
+    float my_a[NH];
     ld_edge_coefs(my_a, aw, my_e, H, my_e < end);
     const int left = end - base - wave;
     const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    auto accumulate = [&](const float (&x)[GF_ITER][W], int j) {
-      float sv[GF_MAXH];
+    auto accumulate = [&](const float (&x)[NG][W], int j) {
+      float sv[NH];
 #pragma unroll
-      for (int h = 0; h < GF_MAXH; ++h) sv[h] = h < H ? bcast_f32(my_a[h], j) : 0.f;
+      for (int h = 0; h < NH; ++h) sv[h] = h < H ? bcast_f32(my_a[h], j) : 0.f;
 #pragma unroll
-      for (int c = 0; c < GF_ITER; ++c) {
-        if (hd[c] >= 0) {
-          const float cf = pick_head(sv, hd[c]);
+      for (int c = 0; c < NG; ++c) {
+        if (HG || hd[c] >= 0) {
+          const float cf = (HG ? sv[c % NH] : pick_head<NH>(sv, hd[c]));
 #pragma unroll
           for (int jj = 0; jj < W; ++jj) acc[c][jj] += cf * x[c][jj];
         }
@@ -245,15 +276,15 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     };
     for (int j = 0; j < n_mine; j += 2) {
       const bool two = j + 1 < n_mine;
-      float x0[GF_ITER][W], x1[GF_ITER][W];
-      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
-      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      float x0[NG][W], x1[NG][W];
+      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
+      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
       accumulate(x0, j);
       if (two) accumulate(x1, j + 1);
     }
   }
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c)
+  for (int c = 0; c < NG; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = acc[c][j];
   __syncthreads();
@@ -274,28 +305,32 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
 }
 
 // backward by destination: d a, softmax backward, d er and the row's share of d attn
-template <bool VEC4>
+template <bool VEC4, int HG>
 __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
-  __shared__ float sh_acc[GF_WAVES][GF_ITER * 64 * W];
+  // HG > 0: "a column group is a head" (VEC4, D == 256: group c of 64 lanes x 4 columns IS head c, H == HG <= 4) -- the Reddit
+  // config's 4 x 256; every per-head selection below is then a compile-time index.  HG == 0: any H <= 8, D (head by compare)
+  constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
+  __shared__ float sh_acc[GF_WAVES][NG * 64 * W];
   __shared__ float sh_t[GF_WAVES][GF_MAXH];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row = blockIdx.x;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
-  const int H = p.H, D = p.D, HD = H * D;
+  const int H = HG ? HG : p.H, D = p.D, HD = H * D;
   if (row >= p.n_dst) return;
   if (row >= S) {
     for (int c = tid; c < HD; c += GF_TPB) { p.d_er[(long long)row * p.der_stride + c] = 0; p.dattn_part[(long long)row * HD + c] = 0.f; }
     return;
   }
   const int beg = p.indptr[row], end = p.indptr[row + 1];
-  float er[GF_ITER][W], at[GF_ITER][W], gr[GF_ITER][W];
-  int hd[GF_ITER];
+  float er[NG][W], at[NG][W], gr[NG][W];
+  int hd[NG], coff[NG];
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c) {
+  for (int c = 0; c < NG; ++c) {
     const int col = c * 64 * W + lane * W;
     hd[c] = col < HD ? col / D : -1;
+    coff[c] = col < HD ? col : 0;
     const g4f z = g4f{{0.f, 0.f, 0.f, 0.f}};
     const g4f x = col < HD ? ldrow<VEC4>(p.feat + (long long)row * p.feat_stride + col) : z;
     const g4f t = col < HD ? ldrow<VEC4>(p.attn + col) : z;
@@ -304,35 +339,38 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     for (int j = 0; j < W; ++j) { er[c][j] = x.v[j]; at[c][j] = t.v[j]; gr[c][j] = gg.v[j]; }
   }
   // ---- pass 1: d a_ij[h] = g_i[h,:] . el_j[h,:] (bf16, like k_gat_edge_dot<1>), through the dropout mask; t[h] = sum a d a
-  float tp[GF_MAXH];
+  float tp[NH];
 #pragma unroll
-  for (int h = 0; h < GF_MAXH; ++h) tp[h] = 0.f;
+  for (int h = 0; h < NH; ++h) tp[h] = 0.f;
   for (int base = beg; base < end; base += 64 * GF_WAVES) {
     const int my_e = base + lane * GF_WAVES + wave;
     const int my_s = my_e < end ? p.src[my_e] : 0;
-    float my_a[GF_MAXH], my_ad[GF_MAXH];
+    float my_a[NH], my_ad[NH];
     ld_edge_coefs(my_a, p.a, my_e, H, my_e < end);
     if (p.drop_thresh) ld_edge_coefs(my_ad, p.ad, my_e, H, my_e < end);
     const int left = end - base - wave;
     const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    auto da_of = [&](const float (&x)[GF_ITER][W], int j) {
+    auto da_of = [&](const float (&x)[NG][W], int j) {
       const int e = base + j * GF_WAVES + wave;
-      float part[GF_MAXH];
+      float part[NH];
 #pragma unroll
-      for (int h = 0; h < GF_MAXH; ++h) part[h] = 0.f;
+      for (int h = 0; h < NH; ++h) part[h] = 0.f;
 #pragma unroll
-      for (int c = 0; c < GF_ITER; ++c) {
-        if (hd[c] >= 0) {
+      for (int c = 0; c < NG; ++c) {
+        if (HG || hd[c] >= 0) {
           float v = 0.f;
 #pragma unroll
           for (int jj = 0; jj < W; ++jj) v += gr[c][jj] * x[c][jj];
+          if (HG) part[c % NH] += v;
+          else {
 #pragma unroll
-          for (int h = 0; h < GF_MAXH; ++h) if (h == hd[c]) part[h] += v;
+            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+          }
         }
       }
       wave_sum_heads(part, H);
 #pragma unroll
-      for (int h = 0; h < GF_MAXH; ++h) {
+      for (int h = 0; h < NH; ++h) {
         if (h < H) {
           float da = rbf_hw(part[h]);
           if (p.drop_thresh) da = (bcast_f32(my_ad[h], j) != 0.f) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
@@ -343,17 +381,17 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     };
     for (int j = 0; j < n_mine; j += 2) {
       const bool two = j + 1 < n_mine;
-      float x0[GF_ITER][W], x1[GF_ITER][W];
-      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
-      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      float x0[NG][W], x1[NG][W];
+      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
+      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
       da_of(x0, j);
       if (two) da_of(x1, j + 1);
     }
   }
-  if (lane < GF_MAXH) {
+  if (lane < NH) {
     float t = 0.f;
 #pragma unroll
-    for (int h = 0; h < GF_MAXH; ++h) if (h == lane) t = tp[h];
+    for (int h = 0; h < NH; ++h) if (h == lane) t = tp[h];
     sh_t[wave][lane] = t;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -372,26 +410,26 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- pass 3: d er_i = sum_j d e attn lrelu'(el_j + er_i);  d attn += d e lrelu(el_j + er_i)   (k_gat_rows<true, false>)
-  float dacc[GF_ITER][W], aacc[GF_ITER][W];
+  float dacc[NG][W], aacc[NG][W];
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c)
+  for (int c = 0; c < NG; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) { dacc[c][j] = 0.f; aacc[c][j] = 0.f; }
   for (int base = beg; base < end; base += 64 * GF_WAVES) {
     const int my_e = base + lane * GF_WAVES + wave;
     const int my_s = my_e < end ? p.src[my_e] : 0;
-    float my_de[GF_MAXH];
+    float my_de[NH];
     ld_edge_coefs(my_de, p.de, my_e, H, my_e < end);
     const int left = end - base - wave;
     const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    auto grads_of = [&](const float (&x)[GF_ITER][W], int j) {
-      float sv[GF_MAXH];
+    auto grads_of = [&](const float (&x)[NG][W], int j) {
+      float sv[NH];
 #pragma unroll
-      for (int h = 0; h < GF_MAXH; ++h) sv[h] = h < H ? bcast_f32(my_de[h], j) : 0.f;
+      for (int h = 0; h < NH; ++h) sv[h] = h < H ? bcast_f32(my_de[h], j) : 0.f;
 #pragma unroll
-      for (int c = 0; c < GF_ITER; ++c) {
-        if (hd[c] >= 0) {
-          const float cf = pick_head(sv, hd[c]);
+      for (int c = 0; c < NG; ++c) {
+        if (HG || hd[c] >= 0) {
+          const float cf = (HG ? sv[c % NH] : pick_head<NH>(sv, hd[c]));
 #pragma unroll
           for (int jj = 0; jj < W; ++jj) {
             const float sx = x[c][jj] + er[c][jj];
@@ -403,16 +441,16 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     };
     for (int j = 0; j < n_mine; j += 2) {
       const bool two = j + 1 < n_mine;
-      float x0[GF_ITER][W], x1[GF_ITER][W];
-      ld_edge_row<VEC4, W>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, hd, lane);
-      ld_edge_row<VEC4, W>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, hd, lane);
+      float x0[NG][W], x1[NG][W];
+      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
+      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
       grads_of(x0, j);
       if (two) grads_of(x1, j + 1);
     }
   }
   // two cross-wave reductions through the same LDS buffer
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c)
+  for (int c = 0; c < NG; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = dacc[c][j];
   __syncthreads();
@@ -424,7 +462,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   }
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < GF_ITER; ++c)
+  for (int c = 0; c < NG; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = aacc[c][j];
   __syncthreads();
@@ -504,7 +542,12 @@ int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream) {
   if (p.drop_thresh && (!p.ad || !p.ctr)) return BLISS_EINVAL;
   if (args->drop_p < 0.f || args->drop_p >= 1.f) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (v4) k_gat_fwd<true><<<p.n_dst, GF_TPB, 0, st>>>(p); else k_gat_fwd<false><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  const int hg = (v4 && p.D == 256 && (p.H == 1 || p.H == 2 || p.H == 4)) ? p.H : 0;
+  if (hg == 4) k_gat_fwd<true, 4><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else if (hg == 2) k_gat_fwd<true, 2><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else if (hg == 1) k_gat_fwd<true, 1><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else if (v4) k_gat_fwd<true, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else k_gat_fwd<false, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
   return (int)hipGetLastError();
 }
 
@@ -514,7 +557,12 @@ int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, fl
   if (!gf_fill(args, &p, &v4) || !p.src || !p.a || !p.g || !p.de || !p.d_er || !p.dattn_part || !block_sums || !d_attn || !ticket) return BLISS_EINVAL;
   if (p.drop_thresh && !p.ad) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (v4) k_gat_bwd_dst<true><<<p.n_dst, GF_TPB, 0, st>>>(p); else k_gat_bwd_dst<false><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  const int hg = (v4 && p.D == 256 && (p.H == 1 || p.H == 2 || p.H == 4)) ? p.H : 0;
+  if (hg == 4) k_gat_bwd_dst<true, 4><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else if (hg == 2) k_gat_bwd_dst<true, 2><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else if (hg == 1) k_gat_bwd_dst<true, 1><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else if (v4) k_gat_bwd_dst<true, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  else k_gat_bwd_dst<false, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
   const int nb = (p.n_dst + DA_ROWS - 1) / DA_ROWS, HD = p.H * p.D;
   k_gat_dattn_stage1<<<dim3(nb, (HD + 255) / 256), 256, 0, st>>>(p.dattn_part, p.n_dst, p.n_dst_dev, HD, block_sums);
   k_gat_dattn_stage2<<<(HD + 63) / 64, 256, 0, st>>>(block_sums, nb, HD, d_attn);
