@@ -65,17 +65,30 @@ struct GatFused {
 // A wave's share of a row's edges, SWEEP = 64 * GF_WAVES edges at a time: lane l of wave w holds the source id of edge
 // base + l * GF_WAVES + w, fetched with ONE coalesced load per sweep; the loop over the wave's edges then reads the id with
 // v_readlane (wave-uniform, no dependent global load per edge) and keeps the rows of TWO edges in flight.
-template <bool VEC4, int W, int NG>
-__device__ __forceinline__ void ld_edge_row(float (&x)[NG][W], const bf16_t* el, const int (&coff)[NG]) {
+// a row of one edge as the lane's NG column groups, still packed (two registers per group of four bf16): FOUR edges' rows are
+// kept in flight per wave -- the loop is bound by the latency of these gathers, not by their bytes
+template <bool VEC4> struct RawGroup { uint2 u; };
+template <bool VEC4, int NG>
+__device__ __forceinline__ void ld_edge_raw(RawGroup<VEC4> (&r)[NG], const bf16_t* el, const int (&coff)[NG]) {
   // UNCONDITIONAL loads from clamped (always valid) column offsets: a load under a lane-dependent branch makes the compiler wait
   // for everything outstanding (csrc/sage.hip found the same); columns beyond H*D are masked where the values are used
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
-    const g4f t = ldrow<VEC4>(el + coff[c]);
-#pragma unroll
-    for (int j = 0; j < W; ++j) x[c][j] = t.v[j];
+    if (VEC4) r[c].u = *reinterpret_cast<const uint2*>(el + coff[c]);
+    else { r[c].u.x = el[coff[c]]; r[c].u.y = 0u; }
   }
 }
+template <bool VEC4, int W, int NG>
+__device__ __forceinline__ void unpack_row(float (&x)[NG][W], const RawGroup<VEC4> (&r)[NG]) {
+#pragma unroll
+  for (int c = 0; c < NG; ++c) {
+    if (VEC4) {
+      x[c][0] = __uint_as_float(r[c].u.x << 16); x[c][1 % W] = __uint_as_float(r[c].u.x & 0xffff0000u);
+      x[c][2 % W] = __uint_as_float(r[c].u.y << 16); x[c][3 % W] = __uint_as_float(r[c].u.y & 0xffff0000u);
+    } else x[c][0] = __uint_as_float(r[c].u.x << 16);
+  }
+}
+#define GF_FLIGHT 2
 
 // per-edge, per-head coefficients ([nnz, H] bf16 arrays) of a sweep: lane l fetches those of ITS edge once (agent-scope loads:
 // another wave of the workgroup may have written them), the edge loop broadcasts them with v_readlane
@@ -143,10 +156,6 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   if (row == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
   if (row >= S) {                                      // capacity padding: finite zeros (and its ticket for the dropout counter)
     for (int c = tid; c < HD; c += GF_TPB) p.rst[(long long)row * p.rst_stride + c] = 0;
-    if (p.drop_thresh && tid == 0 && atomicAdd(p.ctr + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
-      __hip_atomic_store(p.ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicAdd(p.ctr, 1ull);
-    }
     return;
   }
   const int beg = p.indptr[row], end = p.indptr[row + 1];
@@ -204,13 +213,19 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     const int my_s = my_e < end ? p.src[my_e] : 0;
     const int left = end - base - wave;
     const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    for (int j = 0; j < n_mine; j += 2) {
-      const bool two = j + 1 < n_mine;                  // (wave-uniform)
-      float x0[NG][W], x1[NG][W];
-      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
-      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
-      logits_of(x0, base + j * GF_WAVES + wave);
-      if (two) logits_of(x1, base + (j + 1) * GF_WAVES + wave);
+    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+      RawGroup<VEC4> raw[GF_FLIGHT][NG];
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
+        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q) {
+        if (j + q < n_mine) {                           // (wave-uniform)
+          float x[NG][W];
+          unpack_row<VEC4, W, NG>(x, raw[q]);
+          logits_of(x, base + (j + q) * GF_WAVES + wave);
+        }
+      }
     }
   }
   if (lane < NH) {
@@ -274,13 +289,19 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
         }
       }
     };
-    for (int j = 0; j < n_mine; j += 2) {
-      const bool two = j + 1 < n_mine;
-      float x0[NG][W], x1[NG][W];
-      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
-      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
-      accumulate(x0, j);
-      if (two) accumulate(x1, j + 1);
+    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+      RawGroup<VEC4> raw[GF_FLIGHT][NG];
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
+        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q) {
+        if (j + q < n_mine) {                           // (wave-uniform)
+          float x[NG][W];
+          unpack_row<VEC4, W, NG>(x, raw[q]);
+          accumulate(x, j + q);
+        }
+      }
     }
   }
 #pragma unroll
@@ -294,15 +315,12 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];   // fixed order: bitwise reproducible
     p.rst[(long long)row * p.rst_stride + col] = f2bf(s);
   }
-  // dropout stream: the last workgroup bumps the launch counter (everybody has read it)
-  if (p.drop_thresh) {
-    __syncthreads();
-    if (tid == 0 && atomicAdd(p.ctr + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
-      __hip_atomic_store(p.ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicAdd(p.ctr, 1ull);
-    }
-  }
 }
+
+// the dropout stream's launch counter moves on behind the forward kernel (every workgroup has read it by then).  A ticket taken
+// by each of the ~5 K workgroups on the counter's own cache line cost 40-70 us per launch (scratch/gatbench.py): every
+// workgroup's first load queued behind the other workgroups' atomics
+__global__ void k_gat_bump(unsigned long long* ctr) { if (threadIdx.x == 0) *ctr += 1ull; }
 
 // backward by destination: d a, softmax backward, d er and the row's share of d attn
 template <bool VEC4, int HG>
@@ -379,13 +397,19 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
         }
       }
     };
-    for (int j = 0; j < n_mine; j += 2) {
-      const bool two = j + 1 < n_mine;
-      float x0[NG][W], x1[NG][W];
-      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
-      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
-      da_of(x0, j);
-      if (two) da_of(x1, j + 1);
+    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+      RawGroup<VEC4> raw[GF_FLIGHT][NG];
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
+        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q) {
+        if (j + q < n_mine) {                           // (wave-uniform)
+          float x[NG][W];
+          unpack_row<VEC4, W, NG>(x, raw[q]);
+          da_of(x, j + q);
+        }
+      }
     }
   }
   if (lane < NH) {
@@ -439,13 +463,19 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
         }
       }
     };
-    for (int j = 0; j < n_mine; j += 2) {
-      const bool two = j + 1 < n_mine;
-      float x0[NG][W], x1[NG][W];
-      ld_edge_row<VEC4, W, NG>(x0, p.feat + (long long)__builtin_amdgcn_readlane(my_s, j) * p.feat_stride, coff);
-      ld_edge_row<VEC4, W, NG>(x1, p.feat + (long long)__builtin_amdgcn_readlane(my_s, two ? j + 1 : j) * p.feat_stride, coff);
-      grads_of(x0, j);
-      if (two) grads_of(x1, j + 1);
+    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+      RawGroup<VEC4> raw[GF_FLIGHT][NG];
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
+        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+#pragma unroll
+      for (int q = 0; q < GF_FLIGHT; ++q) {
+        if (j + q < n_mine) {                           // (wave-uniform)
+          float x[NG][W];
+          unpack_row<VEC4, W, NG>(x, raw[q]);
+          grads_of(x, j + q);
+        }
+      }
     }
   }
   // two cross-wave reductions through the same LDS buffer
@@ -548,6 +578,7 @@ int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream) {
   else if (hg == 1) k_gat_fwd<true, 1><<<p.n_dst, GF_TPB, 0, st>>>(p);
   else if (v4) k_gat_fwd<true, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
   else k_gat_fwd<false, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  if (p.drop_thresh) k_gat_bump<<<1, 64, 0, st>>>(p.ctr);
   return (int)hipGetLastError();
 }
 
