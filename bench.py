@@ -294,7 +294,14 @@ def main():
             tot = sum(roofline.algorithmic_bytes(k, s_, dims, l) for sz in calib_sizes for l, s_ in enumerate(sz))
             v["alg_bytes_per_launch"] = tot / max(v["launches"], 1)
             v["GBps"] = v["alg_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9
-        dominant = max(hbm_kernels, key=lambda k: hbm_kernels[k]["total_ms"])
+        # the dominant kernel = largest total time over the calibration steps.  Two kernels are listed in all_kernels but not
+        # eligible: the random-number generator (it runs BESIDE the chain on its own stream) and k_cand_number, whose last
+        # workgroup hosts the wait for those numbers -- launched kernel by kernel the generator is not ahead of the sampler as it
+        # is in the replayed loop, so that wait lands inside its timed duration.  Near-ties (within 5 %: k_col_sums and
+        # k_bin_scatter trade places from run to run) go to the kernel that moves more bytes, so the line is stable.
+        elig = {k: v for k, v in hbm_kernels.items() if k not in ("k_cand_number", "k_mt19937_uniform")} or hbm_kernels
+        top = max(v["total_ms"] for v in elig.values())
+        dominant = max((k for k, v in elig.items() if v["total_ms"] >= 0.95 * top), key=lambda k: elig[k]["alg_bytes_per_launch"])
         timer.enable(dominant)                       # only this kernel carries events now
         n_dom = min(args.steps, 30) // 2 * 2
         for sz in advance(n_dom, eager=True):

@@ -153,29 +153,47 @@ class EarlyStopping:
             self.best, self.bad = val_acc, 0
         else:
             self.bad += 1
-        return val_acc >= self.threshold or self.bad >= self.patience
+        # Lightning's stopping_threshold in mode='max' is STRICT: stop once the monitored value is better than the threshold
+        return val_acc > self.threshold or self.bad >= self.patience
 
 
 class ModelCheckpoint:
     """``ModelCheckpoint(monitor='val_acc', save_top_k=1, mode='max')`` (:620-625): keep the best parameters (in memory, and
-    on disk when a path is given; the EXP3 state is NOT part of it, as in the reference -- bandit_sampler.py:43)."""
+    on disk when a path is given; the EXP3 state is NOT part of it, as in the reference -- bandit_sampler.py:43).
+
+    On disk the file has the layout of the reference's Lightning ``.ckpt`` as far as its reload path reads it
+    (train_lightning.py:64, :671-682: ``load_from_checkpoint`` takes ``checkpoint['state_dict']``, whose keys carry the
+    ``module.`` prefix of ``ModelLightning.module``): ``{'state_dict': {'module.<name>': tensor}, 'epoch', 'monitor', 'best'}``
+    -- tensors and plain numbers only, so ``torch.load(path, weights_only=True)`` reads it."""
+
+    PREFIX = "module."
 
     def __init__(self, path=None):
-        self.path, self.best, self.state = path, -math.inf, None
+        self.path, self.best, self.state, self.epoch = path, -math.inf, None, -1
 
-    def update(self, val_acc, model):
+    def update(self, val_acc, model, epoch=-1):
         if val_acc > self.best:
-            self.best = val_acc
+            self.best, self.epoch = val_acc, int(epoch)
             self.state = copy.deepcopy({k: v.detach().clone() for k, v in model.state_dict().items()})
             if self.path:
                 os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
-                torch.save(self.state, self.path)
+                torch.save({"state_dict": {self.PREFIX + k: v for k, v in self.state.items()}, "epoch": self.epoch,
+                            "monitor": "val_acc", "best": float(self.best)}, self.path)
             return True
         return False
 
     def restore(self, model):
         if self.state is not None:
             model.load_state_dict(self.state)
+
+    @classmethod
+    def load(cls, path, model, strict=True):
+        """Load a checkpoint written by ``update`` -- or a Lightning ``.ckpt`` of the reference whose tensors the safe loader
+        accepts -- into ``model`` (``strict=False`` like the reference's GCN reload, train_lightning.py:675-680)."""
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+        sd = {(k[len(cls.PREFIX):] if k.startswith(cls.PREFIX) else k): v for k, v in sd.items()}
+        return model.load_state_dict(sd, strict=strict)
 
 
 @torch.no_grad()
@@ -212,7 +230,7 @@ def fit(g, sampler, model, train_nid, val_nid, test_nid=None, batch_size=1024, l
             if max_steps is not None and n_steps >= max_steps:
                 break
         val_acc, val_loss = evaluate(g, sampler, model, val_nid, batch_size, multilabel, step.loss_fn)
-        ckpt.update(val_acc, model)
+        ckpt.update(val_acc, model, epoch)
         history.append(dict(epoch=epoch, train_loss=tot / max(cnt, 1), val_acc=val_acc, val_loss=val_loss, lr=step.opt.param_groups[0]["lr"]))
         if log:
             log(history[-1])

@@ -29,6 +29,22 @@ class Adam(torch.optim.Optimizer):
     def step_count(self):
         return int(self._state[0].item())
 
+    def state_dict(self):
+        """torch's layout plus the device-resident step count (``'bliss_step'``): without it a resumed run would restart the
+        bias correction at step 0."""
+        sd = super().state_dict()
+        sd["bliss_step"] = self.step_count
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        step = state_dict.pop("bliss_step", None)
+        super().load_state_dict(state_dict)
+        if step is not None:
+            self._state[0] = float(step)
+        self._state[1] = float(self.param_groups[0]["lr"])
+        self._lr_on_device = float(self.param_groups[0]["lr"])
+
     def sync_lr(self):
         """Push ``param_groups[0]['lr']`` (what a torch lr_scheduler rewrites) to the device; call outside graph capture."""
         lr = float(self.param_groups[0]["lr"])

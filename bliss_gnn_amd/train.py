@@ -784,6 +784,12 @@ class PipelinedTrainStep(GraphedTrainStep):
             t_in = time.perf_counter() if trace is not None else 0.0
             while pending and pending[0] <= k - ring:    # this pair reuses that pair's record
                 collect(pending.pop(0) % ring)
+            if bad:
+                # an error word came back with a pair's record (capacity overrun, non-finite weight, ...): every later step
+                # builds on invalid blocks / EXP3 rows, so stop enqueueing -- the error surfaces within `ring` pairs of the step
+                # that raised it, not at the end of the window (round-2 advice)
+                n_done = k
+                break
             if pair_events is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
@@ -829,6 +835,14 @@ class PipelinedTrainStep(GraphedTrainStep):
                     pair_events.append(ev)
                 self._ring_ev[k % ring].record(main)
                 pending.append(k)
+        else:
+            n_done = n_pairs
+        if n_done < n_pairs:                             # stopped early: let the device finish what is enqueued, then report
+            torch.cuda.synchronize()                     # (the loop object is not usable afterwards: results are invalid anyway)
+            for i in pending:
+                collect(i % ring)
+            raise RuntimeError(f"static-shape step exceeded its capacities or hit a kernel error 0x{bad:x} ({_lib.err_string(bad)}) "
+                               f"within the last {ring} pairs before pair {n_done} of {n_pairs}; results from there on are invalid")
         for i in pending:
             collect(i % ring)
         if n_pairs:

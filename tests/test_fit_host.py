@@ -26,7 +26,7 @@ def test_early_stopping_threshold_and_patience():
     es = fit.EarlyStopping(stopping_threshold=0.9, patience=3)
     assert [es.should_stop(v) for v in (0.1, 0.2, 0.15, 0.18, 0.19)] == [False, False, False, False, True]   # 3 epochs without a new best
     es = fit.EarlyStopping(stopping_threshold=0.9, patience=1000)
-    assert [es.should_stop(v) for v in (0.5, 0.95)] == [False, True]                                         # target reached
+    assert [es.should_stop(v) for v in (0.5, 0.9, 0.95)] == [False, False, True]                              # strictly above the target (Lightning: mode='max')
 
 
 def test_checkpoint_keeps_the_best_parameters(tmp_path):
@@ -40,7 +40,13 @@ def test_checkpoint_keeps_the_best_parameters(tmp_path):
     assert not ck.update(0.4, m)                                  # worse: not saved
     ck.restore(m)
     assert bool((m.weight == 1.0).all()) and ck.best == 0.5
-    assert bool((torch.load(str(tmp_path / "best.pt"), weights_only=True)["weight"] == 1.0).all())
+    # on disk: the layout the reference's reload path reads (train_lightning.py:64, :671-682) -- 'state_dict' with the
+    # 'module.' prefix of ModelLightning.module -- readable by the safe loader
+    raw = torch.load(str(tmp_path / "best.pt"), weights_only=True)
+    assert set(raw["state_dict"]) == {"module.weight", "module.bias"} and bool((raw["state_dict"]["module.weight"] == 1.0).all())
+    m2 = torch.nn.Linear(3, 2)
+    fit.ModelCheckpoint.load(str(tmp_path / "best.pt"), m2)
+    assert torch.equal(m2.weight, m.weight) and torch.equal(m2.bias, m.bias)
 
 
 def test_micro_f1_and_k_runs_reduction():

@@ -320,3 +320,29 @@ def test_keyed_uniforms_are_independent_across_steps():
     nid = torch.arange(1 << 14, (1 << 14) + 256)
     cnt = np.array([(bo.keyed_uniform(9, s, 0, nid).numpy() < 0.3).sum() for s in range(256)])
     assert abs(cnt.mean() - 76.8) < 2.0 and 25 < cnt.var() < 90               # 256 * 0.3 * 0.7 = 53.8
+
+
+def test_multinomial_draw_cannot_be_restated_as_an_index_ordered_top_k():
+    """Why the multinomial samplers' draw (bandit_sampler.py:98, ladies_sampler.py:68) stays torch.multinomial on the host
+    (row a9; VERDICT r2 item 7 asked for a device top-k of p / Exp(1)).  ATen computes q = p / Exp(1) IN bf16 and takes
+    topk(q, k): at the sizes of a Reddit-like layer several candidates share the k-th value, only some of them are taken, and
+    WHICH is whatever libstdc++'s nth_element / partial_sort (heap select) leaves -- a function of the whole arrival sequence,
+    not of the tied elements' indices.  A device top-k can reproduce the values above the threshold, but not that choice
+    without replaying the serial selection, and the choice decides block membership."""
+    g = torch.Generator().manual_seed(0)
+    ties_seen = not_lowest = 0
+    for C, k in ((79000, 4096), (203000, 2048), (225000, 1024)):       # candidates / fanout of the three sampled layers
+        p = (torch.rand(C, generator=g) ** 3 * 0.05 + 1e-4).bfloat16()
+        torch.manual_seed(7)
+        idx = torch.multinomial(p, k, replacement=False)
+        torch.manual_seed(7)
+        q = torch.empty_like(p).exponential_(1)                          # the one generator draw ATen makes (MKL stream seed)
+        r = (p / q).float()
+        assert set(idx.tolist()) == set(torch.topk(p / q, k).indices.tolist())      # it IS topk of p / q in bf16 ...
+        t = r[idx].min()
+        tied = torch.nonzero(r == t).flatten()
+        taken = idx[r[idx] == t]
+        if tied.numel() > taken.numel():                                 # ... with a tie across the boundary
+            ties_seen += 1
+            not_lowest += int(set(taken.tolist()) != set(tied[: taken.numel()].tolist()))
+    assert ties_seen >= 2 and not_lowest >= 1
