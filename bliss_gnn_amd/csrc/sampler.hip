@@ -475,6 +475,21 @@ __device__ __forceinline__ int block_max_u31(int v, long long* sh) {
   return t;
 }
 
+// two sums through one pair of barriers (sh2: 2 * NT / 64 entries)
+template <int NT>
+__device__ __forceinline__ long long block_sum2_i64(long long a, long long b, long long* sh2, long long* b_out) {
+  a = wave_total_i64(a);
+  b = wave_total_i64(b);
+  __syncthreads();
+  if (lane_id() == 0) { sh2[threadIdx.x >> 6] = a; sh2[NT / 64 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  long long ta = 0, tb = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { ta += sh2[w]; tb += sh2[NT / 64 + w]; }
+  *b_out = tb;
+  return ta;
+}
+
 template <int NT>
 __device__ __forceinline__ long long block_sum_i64(long long v, long long* sh) {
   v = wave_total_i64(v);
@@ -517,6 +532,7 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
   const bf16_t* __restrict__ wq = norm_state_row(w, w_pend, &pend);
   const float pdenom = renorm_denom(pend ? pend : 0x3f80);
   __shared__ long long sh[COL_TPB / 64];
+  __shared__ long long sh2[2 * COL_TPB / 64];
   const int S = cnt->S, tid = threadIdx.x, lane = lane_id();
   if (cnt->E == 0) return;
   int bad = 0;
@@ -599,9 +615,9 @@ __global__ void __launch_bounds__(COL_TPB) k_col_sums(const int64_t* __restrict_
 #pragma unroll 8
     for (int i = tid + COL_RB * COL_TPB; i < n; i += COL_TPB)
       part += bf_to_fixed_wide(renorm_pending(wq[p0 + i], pend, pdenom), wfrac, &part_lo, &sticky, &bad);
-    const long long ws_fixed = block_sum_i64<COL_TPB>(part, sh);
-    // (lost bits anywhere in the column: block-uniform after the reduction -- the sticky count rides in the same sum)
-    const long long lost = block_sum_i64<COL_TPB>((part_lo != 0 || sticky) ? 1 : 0, sh);
+    // (lost bits anywhere in the column? the count rides through the SAME pair of barriers as the sum)
+    long long lost;
+    const long long ws_fixed = block_sum2_i64<COL_TPB>(part, (part_lo != 0 || sticky) ? 1 : 0, sh2, &lost);
     bf16_t wsum;
     if (lost == 0) wsum = fixed_to_bf(ws_fixed, wfrac, &bad);
     else {
