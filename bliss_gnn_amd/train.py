@@ -319,7 +319,10 @@ class PipelinedTrainStep(GraphedTrainStep):
         super().__init__(g, sampler, model, batch_size, lr, multilabel, distributed)
         self.seeds2 = [torch.zeros(self.bs, dtype=torch.int32, device=g.device) for _ in range(2)]
         self.mfgs = [None, None]
-        self.side = torch.cuda.Stream()          # backward pass + Adam (a high-priority stream measured no different)
+        # backward pass + Adam.  Measured and dropped: a high-priority stream (round 2: no different), a LOWEST-priority stream made
+        # through the HIP runtime (round 3: 1490.1 vs 1490.0 steps/s) and a CU-masked stream (hipExtStreamCreateWithCUMask, so that
+        # the backward pass leaves CUs to the sampler's latency-bound chain: 2.09 ms per step even with the full mask)
+        self.side = torch.cuda.Stream()
         self.third = torch.cuda.Stream()         # blocks of all but the last-sampled layer (flag mode)
         self._fwd_done, self._bwd_done, self._blk_done = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self._seed_ev = torch.cuda.Event()
