@@ -309,8 +309,13 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(WGradLaunch L, const float
   }
 }
 
+// How many workgroups a launch aims for.  NOT "as many as the chip holds": the weight gradients run on the backward stream
+// beside the sampler's latency-bound chain, which IS the step's critical path, and a launch that spreads over every CU slows
+// that chain down more than it gains itself -- measured on the Reddit-like step (same box, 400-step windows): 16 workgroups
+// 1231 steps/s (the backward stream becomes the longer chain), 32: 1467, 48: 1505, 64: 1510, 96: 1509, 128: 1493, 224: 1484,
+// 448: 1454.  Fewer chunks also mean fewer fp32 partial tiles (80 workgroups: ~7 MB for the input layer instead of 20).
 int wgrad_target_wgs() {
-  static const int t = []() { const char* e = getenv("BLISS_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 224; }();
+  static const int t = []() { const char* e = getenv("BLISS_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 80; }();
   return t;
 }
 
