@@ -107,7 +107,9 @@ class GatFused(C.Structure):                           # bliss_gat_fused_t
                 ("rst", C.c_void_p), ("rst_stride", C.c_int64),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("drop_ctr", C.c_void_p), ("drop_ctr_used", C.c_void_p),
                 ("g", C.c_void_p), ("g_stride", C.c_int64), ("de", C.c_void_p), ("d_er", C.c_void_p), ("d_er_stride", C.c_int64),
-                ("dattn_part", C.c_void_p)]
+                ("dattn_part", C.c_void_p),
+                ("wg_row", C.c_void_p), ("n_wg_dev", C.c_void_p), ("cap_wg", C.c_int32), ("row_ws", C.c_void_p), ("seg_part", C.c_void_p),
+                ("err", C.c_void_p)]
 
 
 ADAM_MAX_TENSORS = 32
@@ -176,6 +178,8 @@ SIGNATURES = {
     "bliss_sage_dgrad": [C.POINTER(DGrad), _P],
     "bliss_sage_wgrad": [C.POINTER(WGrad), _I32, _P, _I64, _P],
     "bliss_gat_fused_supported": [_I32, _I32],
+    "bliss_gat_segment_edges": [],
+    "bliss_gat_segments": [_P, _I32, _I32, _P, _P, _P, _P],
     "bliss_gat_fused_fwd": [C.POINTER(GatFused), _P],
     "bliss_gat_fused_bwd_dst": [C.POINTER(GatFused), _P, _P, _P, _P],
     "bliss_gat_rows_src_fused": [_P, _I32, _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _F, _P, _I64, _P, _P],

@@ -24,6 +24,10 @@ namespace {
 #define GF_WAVES (GF_TPB / 64)
 #define GF_MAXH 8
 #define GF_ITER 4                      // a lane owns up to 4 groups of W consecutive columns: H*D <= 64 * W * 4
+#define GF_SEG 128                     // in-edges per workgroup: longer rows are shared by ceil(deg / GF_SEG) workgroups
+#define GF_ROWWS 32                    // words of cross-workgroup state per destination row
+// rowws layout (uint32 words): [0..2] arrive counters of the three meeting points, [3] error bits, [4..11] per-head maximum
+// (order-preserving encoding of the float), [12..27] per-head exact sum (uint64 each)
 
 __device__ __forceinline__ float rbf_hw(float f) { return (float)(__bf16)f; }
 __device__ __forceinline__ bf16_t f2bf_hw(float f) { const __bf16 b = (__bf16)f; return __builtin_bit_cast(unsigned short, b); }
@@ -59,7 +63,12 @@ struct GatFused {
   const bf16_t* g; long long g_stride;                 // d rst [n_dst, H*D]
   bf16_t* de;                                          // [nnz, H] out: d e (softmax backward), scratch for d a before that
   bf16_t* d_er; long long der_stride;                  // [n_dst, H*D] out
-  float* dattn_part;                                   // [n_dst, H*D] out: this row's share of d attn
+  float* dattn_part;                                   // [n_wg, H*D] out: this workgroup's share of d attn
+  // heavy rows: a destination with more than GF_SEG in-edges is shared by several workgroups (segments of GF_SEG edges)
+  const int* wg_row; const int* n_wg_dev;              // virtual workgroup -> row (k_gat_segments); how many there are
+  unsigned* rowws;                                     // [n_dst, GF_ROWWS] zero-initialised, self-cleaning: arrive counters, max, sum
+  float* seg_part;                                     // [n_wg, H*D] partial rows of the segments; [n_wg, GF_MAXH] behind it for t
+  int* err;
 };
 
 // A wave's share of a row's edges, SWEEP = 64 * GF_WAVES edges at a time: lane l of wave w holds the source id of edge
@@ -129,6 +138,73 @@ __device__ __forceinline__ float pick_head(const float (&sv)[NH], int hd) {
   return r;
 }
 
+
+// ---- several workgroups on one destination row ---------------------------------------------------------------------------
+// The sampled blocks hold destinations with ~1000 in-edges beside a mean of ~50 (hubs of the lognormal degree law): one
+// workgroup walking such a row alone WAS the kernel's duration (scratch/gatbench.py: 250 us on the Reddit-like input layer with
+// a 980-edge row, whatever the other 3,376 rows cost).  A row is therefore cut into segments of GF_SEG edges, one workgroup
+// each (consecutive virtual workgroup ids: they are dispatched together).  The arithmetic does not change: the row's maximum is
+// an atomicMax over the segments' maxima, its softmax sum an integer atomicAdd of their exact partial sums (order-free), the
+// output row the sum of the segments' fp32 partial rows IN SEGMENT ORDER by whichever workgroup arrives last -- so the bits do
+// not depend on timing.  Meeting points are counters the segments' workgroups add to and poll (bounded: a row whose partners
+// never arrive sets BLISS_ERR_FLAG_TIMEOUT and goes on, the grid always drains); the last workgroup through the third one
+// returns the row's words to zero for the next launch.
+__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// all threads call; returns once every one of the row's G workgroups has arrived at meeting point `which` (0 or 1)
+__device__ __forceinline__ void row_meet(unsigned* ws, int which, int G, int* err) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores / atomics have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicAdd(ws + which, 1u);
+    long long spins = 0;
+    while (__hip_atomic_load(ws + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1ll << 21)) { if (err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+// the third meeting point only counts: true in the workgroup that arrived LAST (it then reads what the others left)
+__device__ __forceinline__ bool row_last(unsigned* ws, int G, int* sh_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool last = atomicAdd(ws + 2, 1u) == (unsigned)G - 1u;
+    if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    *sh_flag = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *sh_flag != 0;
+}
+
+// virtual workgroup -> destination row: row r gets max(1, ceil(deg_r / GF_SEG)) consecutive ids (rows of capacity padding have
+// no edges: one id each, their workgroup writes the zero row).  One workgroup scans the rows 1024 at a time.
+__global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ indptr, int n_dst, int cap_wg, int* __restrict__ wg_row,
+                                                        int* __restrict__ n_wg_dev, int* err) {
+  __shared__ int sh[17];
+  int run = 0;
+  for (int base = 0; base < n_dst; base += 1024) {
+    const int r = base + threadIdx.x;
+    int g = 0;
+    if (r < n_dst) { const int deg = indptr[r + 1] - indptr[r]; g = deg > GF_SEG ? (deg + GF_SEG - 1) / GF_SEG : 1; }
+    int tot, ex = block_excl_scan(g, sh, &tot);
+    for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = r;
+    run += tot;
+  }
+  if (threadIdx.x == 0) {
+    if (run > cap_wg) { if (err) atomicOr(err, BLISS_ERR_CAP_EDGES); run = cap_wg; }
+    *n_wg_dev = run;
+  }
+}
+
 // per-head sums of a lane's partial values: part[h] over the wave (all lanes get the totals)
 template <int NH>
 __device__ __forceinline__ void wave_sum_heads(float (&part)[NH], int H) {
@@ -147,18 +223,31 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   __shared__ float sh_max[GF_WAVES][GF_MAXH];
   __shared__ unsigned long long sh_sum[GF_MAXH];
   __shared__ int sh_bad;
+  __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int row = blockIdx.x;
+  const int vwg = blockIdx.x;
+  if (p.n_wg_dev && vwg >= *p.n_wg_dev) return;
+  const int row = p.wg_row ? p.wg_row[vwg] : vwg;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
   const int H = HG ? HG : p.H, D = p.D, HD = H * D;
   const uint32_t ctr = p.drop_thresh ? (uint32_t)__hip_atomic_load(p.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  if (row == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
-  if (row >= S) {                                      // capacity padding: finite zeros (and its ticket for the dropout counter)
+  if (vwg == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
+  if (row >= S) {                                      // capacity padding: finite zeros
     for (int c = tid; c < HD; c += GF_TPB) p.rst[(long long)row * p.rst_stride + c] = 0;
     return;
   }
-  const int beg = p.indptr[row], end = p.indptr[row + 1];
+  const int rbeg = p.indptr[row], rend = p.indptr[row + 1];
+  // this workgroup's segment of the row's edges (G workgroups share the row; G == 1 for all but the hubs)
+  const int G = (p.wg_row && rend - rbeg > GF_SEG) ? (rend - rbeg + GF_SEG - 1) / GF_SEG : 1;
+  int seg_i = 0;
+  if (G > 1) {                                         // segment index = distance to the row's first virtual workgroup
+    int first = vwg;
+    while (first > 0 && p.wg_row[first - 1] == row) --first;
+    seg_i = vwg - first;
+  }
+  const int beg = rbeg + seg_i * GF_SEG, end = G > 1 ? min(rend, beg + GF_SEG) : rend;
+  unsigned* ws = p.rowws ? p.rowws + (long long)row * GF_ROWWS : nullptr;
   // this lane's columns: group c covers columns c*64*W + lane*W .. +W-1 (one head per group when VEC4: D % 4 == 0)
   float er[NG][W], at[NG][W], acc[NG][W];
   int hd[NG], coff[NG];
@@ -236,6 +325,21 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's logits have left for L2 (write-through) before the barrier
   __syncthreads();
+  if (G > 1) {                                         // the row's maximum over all its segments
+    if (tid < H) {
+      float m = sh_max[0][tid];
+#pragma unroll
+      for (int w2 = 1; w2 < GF_WAVES; ++w2) m = fmaxf(m, sh_max[w2][tid]);
+      atomicMax(ws + 4 + tid, f2ord(m));
+    }
+    row_meet(ws, 0, G, p.err);
+    if (tid < H) {
+      const float m = ord2f(__hip_atomic_load(ws + 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+      for (int w2 = 0; w2 < GF_WAVES; ++w2) sh_max[w2][tid] = m;
+    }
+    __syncthreads();
+  }
   // ---- pass 2: edge softmax over the stored logits (model.py:88-90; [DGL-recalled] four bf16 ops, exact sum), attention dropout
   const int cnt = (end - beg) * H;
   int bad = 0;
@@ -252,6 +356,17 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   }
   if (bad) atomicOr(&sh_bad, bad);
   __syncthreads();
+  if (G > 1) {                                         // the row's exact sum: integer adds, any order
+    if (tid < H) {
+      const unsigned long long v = sh_sum[tid];
+      if (v) atomicAdd(reinterpret_cast<unsigned long long*>(ws + 12) + tid, v);
+    }
+    if (tid == 0 && sh_bad) atomicOr(ws + 3, (unsigned)sh_bad);
+    row_meet(ws, 1, G, p.err);
+    if (tid < H) sh_sum[tid] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(ws + 12) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) sh_bad |= (int)__hip_atomic_load(ws + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
   for (int i = tid; i < cnt; i += GF_TPB) {
     const int h = i % H;
     int b2 = 0;
@@ -309,11 +424,30 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
 #pragma unroll
     for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = acc[c][j];
   __syncthreads();
+  if (G == 1) {
+    for (int col = tid; col < HD; col += GF_TPB) {
+      float s = sh_acc[0][col];
+#pragma unroll
+      for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];   // fixed order: bitwise reproducible
+      p.rst[(long long)row * p.rst_stride + col] = f2bf(s);
+    }
+    return;
+  }
+  // a shared row: leave this segment's partial row; whoever arrives last adds the segments up in segment order
   for (int col = tid; col < HD; col += GF_TPB) {
     float s = sh_acc[0][col];
 #pragma unroll
-    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];   // fixed order: bitwise reproducible
-    p.rst[(long long)row * p.rst_stride + col] = f2bf(s);
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
+    p.seg_part[(long long)vwg * HD + col] = s;
+  }
+  if (row_last(ws, G, &sh_last)) {
+    const long long v0 = vwg - seg_i;
+    for (int col = tid; col < HD; col += GF_TPB) {
+      float s = 0.f;
+      for (int q = 0; q < G; ++q) s += __hip_atomic_load(p.seg_part + (v0 + q) * HD + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p.rst[(long long)row * p.rst_stride + col] = f2bf(s);
+    }
+    for (int i = tid; i < GF_ROWWS; i += GF_TPB) ws[i] = 0u;          // the row's words back to zero for the next launch
   }
 }
 
@@ -331,17 +465,29 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
   __shared__ float sh_acc[GF_WAVES][NG * 64 * W];
   __shared__ float sh_t[GF_WAVES][GF_MAXH];
+  __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int row = blockIdx.x;
+  const int vwg = blockIdx.x;
+  if (p.n_wg_dev && vwg >= *p.n_wg_dev) return;
+  const int row = p.wg_row ? p.wg_row[vwg] : vwg;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
   const int H = HG ? HG : p.H, D = p.D, HD = H * D;
   if (row >= p.n_dst) return;
   if (row >= S) {
-    for (int c = tid; c < HD; c += GF_TPB) { p.d_er[(long long)row * p.der_stride + c] = 0; p.dattn_part[(long long)row * HD + c] = 0.f; }
+    for (int c = tid; c < HD; c += GF_TPB) { p.d_er[(long long)row * p.der_stride + c] = 0; p.dattn_part[(long long)vwg * HD + c] = 0.f; }
     return;
   }
-  const int beg = p.indptr[row], end = p.indptr[row + 1];
+  const int rbeg = p.indptr[row], rend = p.indptr[row + 1];
+  const int G = (p.wg_row && rend - rbeg > GF_SEG) ? (rend - rbeg + GF_SEG - 1) / GF_SEG : 1;     // workgroups sharing this row
+  int seg_i = 0;
+  if (G > 1) {
+    int first = vwg;
+    while (first > 0 && p.wg_row[first - 1] == row) --first;
+    seg_i = vwg - first;
+  }
+  const int beg = rbeg + seg_i * GF_SEG, end = G > 1 ? min(rend, beg + GF_SEG) : rend;
+  unsigned* ws = p.rowws ? p.rowws + (long long)row * GF_ROWWS : nullptr;
   float er[NG][W], at[NG][W], gr[NG][W];
   int hd[NG], coff[NG];
 #pragma unroll
@@ -420,6 +566,25 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (G > 1) {                                         // t over the whole row: the segments' totals added in segment order
+    float* tseg = p.seg_part + (long long)(*p.n_wg_dev) * HD;         // [n_wg, GF_MAXH] behind the partial rows
+    if (tid < H) {
+      float t = sh_t[0][tid];
+#pragma unroll
+      for (int w2 = 1; w2 < GF_WAVES; ++w2) t += sh_t[w2][tid];
+      tseg[(long long)vwg * GF_MAXH + tid] = t;
+    }
+    row_meet(ws, 0, G, p.err);
+    if (tid < H) {
+      const long long v0 = vwg - seg_i;
+      float t = 0.f;
+      for (int q = 0; q < G; ++q) t += __hip_atomic_load(tseg + (v0 + q) * GF_MAXH + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh_t[0][tid] = t;
+#pragma unroll
+      for (int w2 = 1; w2 < GF_WAVES; ++w2) sh_t[w2][tid] = 0.f;
+    }
+    __syncthreads();
+  }
   // ---- pass 2: d e = a (d a - t)   (k_gat_softmax<true>)
   const int cnt = (end - beg) * H;
   for (int i = tid; i < cnt; i += GF_TPB) {
@@ -488,7 +653,8 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     float s = sh_acc[0][col];
 #pragma unroll
     for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
-    p.d_er[(long long)row * p.der_stride + col] = f2bf(s);
+    if (G == 1) p.d_er[(long long)row * p.der_stride + col] = f2bf(s);
+    else p.seg_part[(long long)vwg * HD + col] = s;
   }
   __syncthreads();
 #pragma unroll
@@ -500,7 +666,16 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     float s = sh_acc[0][col];
 #pragma unroll
     for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
-    p.dattn_part[(long long)row * HD + col] = s;
+    p.dattn_part[(long long)vwg * HD + col] = s;       // (one share per workgroup: the reduction adds them in workgroup order)
+  }
+  if (G > 1 && row_last(ws, G, &sh_last)) {            // d er of a shared row: the segments' partial rows in segment order
+    const long long v0 = vwg - seg_i;
+    for (int col = tid; col < HD; col += GF_TPB) {
+      float s = 0.f;
+      for (int q = 0; q < G; ++q) s += __hip_atomic_load(p.seg_part + (v0 + q) * HD + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p.d_er[(long long)row * p.der_stride + col] = f2bf(s);
+    }
+    for (int i = tid; i < GF_ROWWS; i += GF_TPB) ws[i] = 0u;
   }
 }
 
@@ -552,6 +727,8 @@ bool gf_fill(const bliss_gat_fused_t* a, GatFused* p, bool* vec4) {
   p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr; p->ctr_used = (unsigned*)a->drop_ctr_used;
   p->g = (const bf16_t*)a->g; p->g_stride = a->g_stride; p->de = (bf16_t*)a->de;
   p->d_er = (bf16_t*)a->d_er; p->der_stride = a->d_er_stride; p->dattn_part = a->dattn_part;
+  p->wg_row = a->wg_row; p->n_wg_dev = a->n_wg_dev; p->rowws = (unsigned*)a->row_ws; p->seg_part = a->seg_part; p->err = a->err;
+  if (a->wg_row && (!a->n_wg_dev || !a->row_ws || !a->seg_part || a->cap_wg < a->n_dst)) return false;
   *vec4 = v4;
   return true;
 }
@@ -565,6 +742,14 @@ int bliss_gat_fused_supported(int32_t heads, int32_t head_dim) {
   return heads * head_dim <= GF_ITER * 64 * (head_dim % 4 == 0 ? 4 : 1);
 }
 
+int bliss_gat_segment_edges(void) { return GF_SEG; }
+
+int bliss_gat_segments(const int32_t* indptr, int32_t n_dst, int32_t cap_wg, int32_t* wg_row, int32_t* n_wg_dev, int32_t* err, void* stream) {
+  if (!indptr || !wg_row || !n_wg_dev || n_dst <= 0 || cap_wg < n_dst) return BLISS_EINVAL;
+  k_gat_segments<<<1, 1024, 0, (hipStream_t)stream>>>(indptr, n_dst, cap_wg, wg_row, n_wg_dev, err);
+  return (int)hipGetLastError();
+}
+
 int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream) {
   GatFused p;
   bool v4;
@@ -573,11 +758,12 @@ int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream) {
   if (args->drop_p < 0.f || args->drop_p >= 1.f) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hg = (v4 && p.D == 256 && (p.H == 1 || p.H == 2 || p.H == 4)) ? p.H : 0;
-  if (hg == 4) k_gat_fwd<true, 4><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else if (hg == 2) k_gat_fwd<true, 2><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else if (hg == 1) k_gat_fwd<true, 1><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else if (v4) k_gat_fwd<true, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else k_gat_fwd<false, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
+  const int grid = p.wg_row ? args->cap_wg : p.n_dst;
+  if (hg == 4) k_gat_fwd<true, 4><<<grid, GF_TPB, 0, st>>>(p);
+  else if (hg == 2) k_gat_fwd<true, 2><<<grid, GF_TPB, 0, st>>>(p);
+  else if (hg == 1) k_gat_fwd<true, 1><<<grid, GF_TPB, 0, st>>>(p);
+  else if (v4) k_gat_fwd<true, 0><<<grid, GF_TPB, 0, st>>>(p);
+  else k_gat_fwd<false, 0><<<grid, GF_TPB, 0, st>>>(p);
   if (p.drop_thresh) k_gat_bump<<<1, 64, 0, st>>>(p.ctr);
   return (int)hipGetLastError();
 }
@@ -589,13 +775,15 @@ int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, fl
   if (p.drop_thresh && !p.ad) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hg = (v4 && p.D == 256 && (p.H == 1 || p.H == 2 || p.H == 4)) ? p.H : 0;
-  if (hg == 4) k_gat_bwd_dst<true, 4><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else if (hg == 2) k_gat_bwd_dst<true, 2><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else if (hg == 1) k_gat_bwd_dst<true, 1><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else if (v4) k_gat_bwd_dst<true, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  else k_gat_bwd_dst<false, 0><<<p.n_dst, GF_TPB, 0, st>>>(p);
-  const int nb = (p.n_dst + DA_ROWS - 1) / DA_ROWS, HD = p.H * p.D;
-  k_gat_dattn_stage1<<<dim3(nb, (HD + 255) / 256), 256, 0, st>>>(p.dattn_part, p.n_dst, p.n_dst_dev, HD, block_sums);
+  const int grid = p.wg_row ? args->cap_wg : p.n_dst;
+  if (hg == 4) k_gat_bwd_dst<true, 4><<<grid, GF_TPB, 0, st>>>(p);
+  else if (hg == 2) k_gat_bwd_dst<true, 2><<<grid, GF_TPB, 0, st>>>(p);
+  else if (hg == 1) k_gat_bwd_dst<true, 1><<<grid, GF_TPB, 0, st>>>(p);
+  else if (v4) k_gat_bwd_dst<true, 0><<<grid, GF_TPB, 0, st>>>(p);
+  else k_gat_bwd_dst<false, 0><<<grid, GF_TPB, 0, st>>>(p);
+  // the shares of d attn: one per (virtual) workgroup; rows of capacity padding wrote zeros
+  const int nb = (grid + DA_ROWS - 1) / DA_ROWS, HD = p.H * p.D;
+  k_gat_dattn_stage1<<<dim3(nb, (HD + 255) / 256), 256, 0, st>>>(p.dattn_part, grid, p.wg_row ? p.n_wg_dev : p.n_dst_dev, HD, block_sums);
   k_gat_dattn_stage2<<<(HD + 63) / 64, 256, 0, st>>>(block_sums, nb, HD, d_attn);
   (void)ticket;
   return (int)hipGetLastError();

@@ -658,6 +658,21 @@ class _GatAggregate(torch.autograd.Function):
         return da, d_feat, None, None, None
 
 
+def _gat_segments(block, S, B, state):
+    """wg_row int32 [cap_wg], n_wg int32 [1] for ``block`` (bliss_gat_segments) and the per-row words the sharing workgroups
+    meet on (zero-initialised once per layer and size; the kernels return them to zero)."""
+    import ctypes as C
+    dev = block.indptr.device
+    cap_wg = S + B // int(_lib.lib.bliss_gat_segment_edges()) + 1
+    if state["row_ws"] is None or state["row_ws"].numel() < S * 32:
+        state["row_ws"] = torch.zeros(max(S, 1) * 32, dtype=torch.int32, device=dev)
+    wg_row = torch.empty(cap_wg, dtype=torch.int32, device=dev)
+    n_wg = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib.bliss_gat_segments(block.indptr.data_ptr(), S, cap_wg, wg_row.data_ptr(), n_wg.data_ptr(), state["err"].data_ptr(),
+                                           _stream()), "bliss_gat_segments")
+    return dict(wg_row=wg_row, n_wg=n_wg, cap_wg=cap_wg)
+
+
 def _gat_fused_on(H, D):
     import os
     return os.environ.get("BLISS_GAT_FUSED", "1") != "0" and bool(_lib.lib.bliss_gat_fused_supported(int(H), int(D)))
@@ -687,8 +702,14 @@ class _GatFusedMP(torch.autograd.Function):
         t.e, t.a, t.a_drop, t.rst, t.rst_stride = e.data_ptr(), a.data_ptr(), ad.data_ptr(), rst.data_ptr(), rst.stride(0)
         if p_drop > 0:
             t.drop_p, t.drop_seed, t.drop_ctr = float(p_drop), int(state["seed"]) & 0xFFFFFFFF, state["ctr"].data_ptr()
+        # hub destinations are shared by several workgroups: virtual workgroup -> row map of THIS block (one small launch)
+        seg = _gat_segments(block, S, B, state)
+        seg_part = torch.empty(seg["cap_wg"] * (HD + 8), dtype=torch.float32, device=dev)
+        t.wg_row, t.n_wg_dev, t.cap_wg = seg["wg_row"].data_ptr(), seg["n_wg"].data_ptr(), seg["cap_wg"]
+        t.row_ws, t.seg_part, t.err = state["row_ws"].data_ptr(), seg_part.data_ptr(), state["err"].data_ptr()
         _lib.check(_lib.lib.bliss_gat_fused_fwd(C.byref(t), _stream()), "bliss_gat_fused_fwd")
-        ctx.save_for_backward(feat, attn_f, a, ad)
+        ctx.save_for_backward(feat, attn_f, a, ad, seg["wg_row"], seg["n_wg"])
+        ctx.cap_wg = seg["cap_wg"]
         ctx.block, ctx.H, ctx.D, ctx.slope, ctx.p, ctx.state, ctx.n_dst_dev = block, H, D, float(slope), float(p_drop), state, t.n_dst_dev
         ctx.attn_shape, ctx.attn_dtype = attn.shape, attn.dtype
         return rst, e
@@ -696,7 +717,7 @@ class _GatFusedMP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rst, _d_e):
         import ctypes as C
-        feat, attn_f, a, ad = ctx.saved_tensors
+        feat, attn_f, a, ad, wg_row, n_wg = ctx.saved_tensors
         if _d_e is not None:
             raise NotImplementedError("the returned logits are the bandit's a_ij (model.py:224-227): nothing differentiates through them")
         if d_rst is None:
@@ -708,8 +729,10 @@ class _GatFusedMP(torch.autograd.Function):
         g = (g if g.dtype == torch.bfloat16 else g.bfloat16()).contiguous()
         de = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
         d_er = torch.empty(S, HD, dtype=torch.bfloat16, device=dev)
-        dpart = torch.empty(S, HD, dtype=torch.float32, device=dev)
-        bsum = torch.empty(-(-S // 32), HD, dtype=torch.float32, device=dev)
+        cap_wg = ctx.cap_wg
+        dpart = torch.empty(cap_wg, HD, dtype=torch.float32, device=dev)
+        bsum = torch.empty(-(-cap_wg // 32), HD, dtype=torch.float32, device=dev)
+        seg_part = torch.empty(cap_wg * (HD + 8), dtype=torch.float32, device=dev)
         d_attn = torch.empty(HD, dtype=torch.float32, device=dev)
         t = _lib.GatFused()
         t.indptr, t.src, t.n_dst, t.n_dst_dev = block.indptr.data_ptr(), block.src.data_ptr(), S, ctx.n_dst_dev
@@ -717,6 +740,8 @@ class _GatFusedMP(torch.autograd.Function):
         t.a, t.a_drop = a.data_ptr(), ad.data_ptr()
         t.drop_p = ctx.p
         t.g, t.g_stride, t.de, t.d_er, t.d_er_stride, t.dattn_part = g.data_ptr(), g.stride(0), de.data_ptr(), d_er.data_ptr(), d_er.stride(0), dpart.data_ptr()
+        t.wg_row, t.n_wg_dev, t.cap_wg = wg_row.data_ptr(), n_wg.data_ptr(), cap_wg
+        t.row_ws, t.seg_part, t.err = ctx.state["row_ws"].data_ptr(), seg_part.data_ptr(), ctx.state["err"].data_ptr()
         _lib.check(_lib.lib.bliss_gat_fused_bwd_dst(C.byref(t), bsum.data_ptr(), d_attn.data_ptr(), ctx.state["ticket"].data_ptr(), _stream()),
                    "bliss_gat_fused_bwd_dst")
         t_indptr, t_edge = block.transposed()
@@ -800,8 +825,16 @@ class GATv2Conv(nn.Module):
         st = getattr(self, "_fstate", None)
         if st is None or st["ctr"].device != device:
             st = self._fstate = dict(ctr=torch.zeros(2, dtype=torch.int64, device=device), ticket=torch.zeros(1, dtype=torch.int32, device=device),
-                                     seed=(torch.cuda.initial_seed() ^ (0x9E3779B1 * (id(self) & 0xFFFF))) & 0xFFFFFFFF)
+                                     seed=(torch.cuda.initial_seed() ^ (0x9E3779B1 * (id(self) & 0xFFFF))) & 0xFFFFFFFF,
+                                     err=torch.zeros(1, dtype=torch.int32, device=device), row_ws=None)
         return st
+
+    def check_errors(self):
+        """A row shared by several workgroups whose partners failed to meet within the spin bound (never seen; the grid drains
+        and the word says so)."""
+        st = getattr(self, "_fstate", None)
+        if st is not None and int(st["err"].item()):
+            raise RuntimeError("GATv2 fused kernels: error 0x%x (%s)" % (int(st["err"].item()), _lib.err_string(int(st["err"].item()))))
 
     def forward(self, graph, feat, edge_weight=None, get_attention=False):
         H, D, S = self._num_heads, self._out_feats, graph.num_dst_nodes()
