@@ -213,6 +213,27 @@ __device__ __forceinline__ void wave_sum_heads(float (&part)[NH], int H) {
     if (h < H) { float s = part[h]; for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d); part[h] = s; }
 }
 
+// this workgroup's share of its destination row: all of it (G == 1: at most GF_SEG edges) or segment seg_i of G
+struct RowSeg { int row, beg, end, G, seg_i; };
+__device__ __forceinline__ RowSeg row_segment(const GatFused& p, int vwg) {
+  RowSeg r;
+  r.row = p.wg_row[vwg];
+  const int rbeg = p.indptr[r.row], rend = p.indptr[r.row + 1];
+  r.G = rend - rbeg > GF_SEG ? (rend - rbeg + GF_SEG - 1) / GF_SEG : 1;
+  r.seg_i = 0;
+  if (r.G > 1) {                                       // segment index = distance to the row's first virtual workgroup
+    int first = vwg;
+    while (first > 0 && p.wg_row[first - 1] == r.row) --first;
+    r.seg_i = vwg - first;
+  }
+  r.beg = rbeg + r.seg_i * GF_SEG;
+  r.end = r.G > 1 ? min(rend, r.beg + GF_SEG) : rend;
+  return r;
+}
+
+// Forward.  A workgroup holds at most GF_SEG = 128 edges (longer rows are shared), so the logits and the softmax coefficients of
+// its edges live in LDS between the passes (the global copies are outputs only: nothing is re-read from memory, no wait for a
+// store, no agent-scope load) and a wave's source ids are ONE coalesced load kept in registers for both gather passes.
 template <bool VEC4, int HG>
 __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
@@ -220,34 +241,31 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   // config's 4 x 256; every per-head selection below is then a compile-time index.  HG == 0: any H <= 8, D (head by compare)
   constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
   __shared__ float sh_acc[GF_WAVES][NG * 64 * W];          // cross-wave reduction of the output row (32 KiB when VEC4)
+  __shared__ float sh_e[GF_SEG][GF_MAXH];                  // logits of this workgroup's edges, then their softmax coefficients
   __shared__ float sh_max[GF_WAVES][GF_MAXH];
   __shared__ unsigned long long sh_sum[GF_MAXH];
   __shared__ int sh_bad;
   __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int vwg = blockIdx.x;
-  if (p.n_wg_dev && vwg >= *p.n_wg_dev) return;
-  const int row = p.wg_row ? p.wg_row[vwg] : vwg;
+  if (vwg >= *p.n_wg_dev) return;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
   const int H = HG ? HG : p.H, D = p.D, HD = H * D;
   const uint32_t ctr = p.drop_thresh ? (uint32_t)__hip_atomic_load(p.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   if (vwg == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
+  const RowSeg rs = row_segment(p, vwg);
+  const int row = rs.row, beg = rs.beg, end = rs.end, G = rs.G, seg_i = rs.seg_i;
   if (row >= S) {                                      // capacity padding: finite zeros
     for (int c = tid; c < HD; c += GF_TPB) p.rst[(long long)row * p.rst_stride + c] = 0;
     return;
   }
-  const int rbeg = p.indptr[row], rend = p.indptr[row + 1];
-  // this workgroup's segment of the row's edges (G workgroups share the row; G == 1 for all but the hubs)
-  const int G = (p.wg_row && rend - rbeg > GF_SEG) ? (rend - rbeg + GF_SEG - 1) / GF_SEG : 1;
-  int seg_i = 0;
-  if (G > 1) {                                         // segment index = distance to the row's first virtual workgroup
-    int first = vwg;
-    while (first > 0 && p.wg_row[first - 1] == row) --first;
-    seg_i = vwg - first;
-  }
-  const int beg = rbeg + seg_i * GF_SEG, end = G > 1 ? min(rend, beg + GF_SEG) : rend;
-  unsigned* ws = p.rowws ? p.rowws + (long long)row * GF_ROWWS : nullptr;
+  unsigned* ws = p.rowws + (long long)row * GF_ROWWS;
+  // this wave's edges: local index j * GF_WAVES + wave, j < n_mine <= 16; lane j holds the source id of the wave's j-th edge
+  const int my_e = beg + lane * GF_WAVES + wave;
+  const int my_s = my_e < end ? p.src[my_e] : 0;
+  const int left = end - beg - wave;
+  const int n_mine = left <= 0 ? 0 : (left + GF_WAVES - 1) / GF_WAVES;
   // this lane's columns: group c covers columns c*64*W + lane*W .. +W-1 (one head per group when VEC4: D % 4 == 0)
   float er[NG][W], at[NG][W], acc[NG][W];
   int hd[NG], coff[NG];
@@ -267,52 +285,41 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   float mx[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) mx[h] = -__builtin_inff();
-  auto logits_of = [&](const float (&x)[NG][W], int e) {
-    float part[NH];
+  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+    RawGroup<VEC4> raw[GF_FLIGHT][NG];
 #pragma unroll
-    for (int h = 0; h < NH; ++h) part[h] = 0.f;
+    for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
+      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
 #pragma unroll
-    for (int c = 0; c < NG; ++c) {
-      if (HG || hd[c] >= 0) {
-        float v = 0.f;
+    for (int q = 0; q < GF_FLIGHT; ++q) {
+      if (j + q < n_mine) {                           // (wave-uniform)
+        float x[NG][W];
+        unpack_row<VEC4, W, NG>(x, raw[q]);
+        const int eidx = (j + q) * GF_WAVES + wave;
+        float part[NH];
 #pragma unroll
-        for (int j = 0; j < W; ++j) v += rbf_hw(at[c][j] * rbf_hw(lrelu_f(rbf_hw(x[c][j] + er[c][j]), p.slope)));
-        if (HG) part[c % NH] += v;
-        else {
-          if (HG) part[c % NH] += v;
-          else {
+        for (int h = 0; h < NH; ++h) part[h] = 0.f;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+        for (int c = 0; c < NG; ++c) {
+          if (HG || hd[c] >= 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) v += rbf_hw(at[c][jj] * rbf_hw(lrelu_f(rbf_hw(x[c][jj] + er[c][jj]), p.slope)));
+            if (HG) part[c % NH] += v;
+            else {
+#pragma unroll
+              for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+            }
           }
         }
-      }
-    }
-    wave_sum_heads(part, H);
+        wave_sum_heads<NH>(part, H);
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (h < H) {
-        const bf16_t eb = f2bf_hw(part[h]);
-        if (lane == h) p.e[(long long)e * H + h] = eb;
-        mx[h] = fmaxf(mx[h], bf2f(eb));
-      }
-    }
-  };
-  for (int base = beg; base < end; base += 64 * GF_WAVES) {
-    const int my_e = base + lane * GF_WAVES + wave;
-    const int my_s = my_e < end ? p.src[my_e] : 0;
-    const int left = end - base - wave;
-    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-      RawGroup<VEC4> raw[GF_FLIGHT][NG];
-#pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
-        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
-#pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q) {
-        if (j + q < n_mine) {                           // (wave-uniform)
-          float x[NG][W];
-          unpack_row<VEC4, W, NG>(x, raw[q]);
-          logits_of(x, base + (j + q) * GF_WAVES + wave);
+        for (int h = 0; h < NH; ++h) {
+          if (h < H) {
+            const bf16_t eb = f2bf_hw(part[h]);
+            if (lane == h) { p.e[(long long)(beg + eidx) * H + h] = eb; sh_e[eidx][h] = bf2f(eb); }
+            mx[h] = fmaxf(mx[h], bf2f(eb));
+          }
         }
       }
     }
@@ -323,7 +330,6 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     for (int h = 0; h < NH; ++h) if (h == lane) m = mx[h];
     sh_max[wave][lane] = m;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's logits have left for L2 (write-through) before the barrier
   __syncthreads();
   if (G > 1) {                                         // the row's maximum over all its segments
     if (tid < H) {
@@ -340,17 +346,16 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     }
     __syncthreads();
   }
-  // ---- pass 2: edge softmax over the stored logits (model.py:88-90; [DGL-recalled] four bf16 ops, exact sum), attention dropout
+  // ---- pass 2: edge softmax over the logits in LDS (model.py:88-90; [DGL-recalled] four bf16 ops, exact sum), attention dropout
   const int cnt = (end - beg) * H;
   int bad = 0;
   for (int i = tid; i < cnt; i += GF_TPB) {
-    const int h = i % H;
+    const int eidx = i / H, h = i - eidx * H;
     float m = sh_max[0][h];
 #pragma unroll
     for (int w2 = 1; w2 < GF_WAVES; ++w2) m = fmaxf(m, sh_max[w2][h]);
-    const bf16_t x = __hip_atomic_load(p.e + (long long)beg * H + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bf16_t sc = f2bf((float)exp((double)rbf(bf2f(x) - m)));
-    p.a[(long long)beg * H + i] = sc;                  // (this thread reads it back below)
+    const bf16_t sc = f2bf((float)exp((double)rbf(sh_e[eidx][h] - m)));
+    sh_e[eidx][h] = bf2f(sc);                            // (this thread reads it back below)
     const long long fx = bf_to_fixed(sc, FRAC_DST, &bad);
     if (fx) atomicAdd(&sh_sum[h], (unsigned long long)fx);
   }
@@ -368,53 +373,41 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     __syncthreads();
   }
   for (int i = tid; i < cnt; i += GF_TPB) {
-    const int h = i % H;
+    const int eidx = i / H, h = i - eidx * H;
     int b2 = 0;
     float ssum = bf2f(fixed_to_bf((long long)sh_sum[h], FRAC_DST, &b2));
     if (sh_bad) ssum = __builtin_nanf("");             // a non-finite logit: the reference's sum, and with it the row, is NaN
     const long long o = (long long)beg * H + i;
-    const bf16_t av = f2bf(bf2f(p.a[o]) / ssum);
+    const bf16_t av = f2bf(sh_e[eidx][h] / ssum);
     p.a[o] = av;
+    bf16_t cv = av;
     if (p.drop_thresh) {                               // nn.Dropout on a bf16 tensor: a * mask / (1 - p), one rounding
       const bool keep = gf_drop_hash(p.seed, ctr, (uint32_t)o) >= p.drop_thresh;
-      p.ad[o] = keep ? f2bf(bf2f(av) * p.drop_scale) : (bf16_t)0;
+      cv = keep ? f2bf(bf2f(av) * p.drop_scale) : (bf16_t)0;
+      p.ad[o] = cv;
     }
+    sh_e[eidx][h] = bf2f(cv);                            // what multiplies el_j in pass 3
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- pass 3: out = sum_j a_ij el_j (model.py:98), fp32 products and sums, one rounding
-  const bf16_t* aw = p.drop_thresh ? p.ad : p.a;
-  for (int base = beg; base < end; base += 64 * GF_WAVES) {
-    const int my_e = base + lane * GF_WAVES + wave;
-    const int my_s = my_e < end ? p.src[my_e] : 0;
-    float my_a[NH];
-    ld_edge_coefs(my_a, aw, my_e, H, my_e < end);
-    const int left = end - base - wave;
-    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    auto accumulate = [&](const float (&x)[NG][W], int j) {
-      float sv[NH];
+  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+    RawGroup<VEC4> raw[GF_FLIGHT][NG];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) sv[h] = h < H ? bcast_f32(my_a[h], j) : 0.f;
+    for (int q = 0; q < GF_FLIGHT; ++q)
+      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
 #pragma unroll
-      for (int c = 0; c < NG; ++c) {
-        if (HG || hd[c] >= 0) {
-          const float cf = (HG ? sv[c % NH] : pick_head<NH>(sv, hd[c]));
+    for (int q = 0; q < GF_FLIGHT; ++q) {
+      if (j + q < n_mine) {
+        float x[NG][W];
+        unpack_row<VEC4, W, NG>(x, raw[q]);
+        const int eidx = (j + q) * GF_WAVES + wave;
 #pragma unroll
-          for (int jj = 0; jj < W; ++jj) acc[c][jj] += cf * x[c][jj];
-        }
-      }
-    };
-    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-      RawGroup<VEC4> raw[GF_FLIGHT][NG];
+        for (int c = 0; c < NG; ++c) {
+          if (HG || hd[c] >= 0) {
+            const float cf = sh_e[eidx][HG ? c : hd[c]];
 #pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
-        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
-#pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q) {
-        if (j + q < n_mine) {                           // (wave-uniform)
-          float x[NG][W];
-          unpack_row<VEC4, W, NG>(x, raw[q]);
-          accumulate(x, j + q);
+            for (int jj = 0; jj < W; ++jj) acc[c][jj] += cf * x[c][jj];
+          }
         }
       }
     }
@@ -456,38 +449,33 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
 // workgroup's first load queued behind the other workgroups' atomics
 __global__ void k_gat_bump(unsigned long long* ctr) { if (threadIdx.x == 0) *ctr += 1ull; }
 
-// backward by destination: d a, softmax backward, d er and the row's share of d attn
+// backward by destination: d a, softmax backward, d er and the workgroup's share of d attn (same structure: at most GF_SEG edges
+// per workgroup, d a / d e in LDS between the passes; a and a_drop are the forward's outputs: plain loads)
 template <bool VEC4, int HG>
 __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
-  // HG > 0: "a column group is a head" (VEC4, D == 256: group c of 64 lanes x 4 columns IS head c, H == HG <= 4) -- the Reddit
-  // config's 4 x 256; every per-head selection below is then a compile-time index.  HG == 0: any H <= 8, D (head by compare)
   constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
   __shared__ float sh_acc[GF_WAVES][NG * 64 * W];
+  __shared__ float sh_c[GF_SEG][GF_MAXH];                  // d a, then d e, of this workgroup's edges
   __shared__ float sh_t[GF_WAVES][GF_MAXH];
   __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int vwg = blockIdx.x;
-  if (p.n_wg_dev && vwg >= *p.n_wg_dev) return;
-  const int row = p.wg_row ? p.wg_row[vwg] : vwg;
+  if (vwg >= *p.n_wg_dev) return;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
   const int H = HG ? HG : p.H, D = p.D, HD = H * D;
-  if (row >= p.n_dst) return;
+  const RowSeg rs = row_segment(p, vwg);
+  const int row = rs.row, beg = rs.beg, end = rs.end, G = rs.G, seg_i = rs.seg_i;
   if (row >= S) {
     for (int c = tid; c < HD; c += GF_TPB) { p.d_er[(long long)row * p.der_stride + c] = 0; p.dattn_part[(long long)vwg * HD + c] = 0.f; }
     return;
   }
-  const int rbeg = p.indptr[row], rend = p.indptr[row + 1];
-  const int G = (p.wg_row && rend - rbeg > GF_SEG) ? (rend - rbeg + GF_SEG - 1) / GF_SEG : 1;     // workgroups sharing this row
-  int seg_i = 0;
-  if (G > 1) {
-    int first = vwg;
-    while (first > 0 && p.wg_row[first - 1] == row) --first;
-    seg_i = vwg - first;
-  }
-  const int beg = rbeg + seg_i * GF_SEG, end = G > 1 ? min(rend, beg + GF_SEG) : rend;
-  unsigned* ws = p.rowws ? p.rowws + (long long)row * GF_ROWWS : nullptr;
+  unsigned* ws = p.rowws + (long long)row * GF_ROWWS;
+  const int my_e = beg + lane * GF_WAVES + wave;
+  const int my_s = my_e < end ? p.src[my_e] : 0;
+  const int left = end - beg - wave;
+  const int n_mine = left <= 0 ? 0 : (left + GF_WAVES - 1) / GF_WAVES;
   float er[NG][W], at[NG][W], gr[NG][W];
   int hd[NG], coff[NG];
 #pragma unroll
@@ -506,65 +494,58 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   float tp[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) tp[h] = 0.f;
-  for (int base = beg; base < end; base += 64 * GF_WAVES) {
-    const int my_e = base + lane * GF_WAVES + wave;
-    const int my_s = my_e < end ? p.src[my_e] : 0;
-    float my_a[NH], my_ad[NH];
-    ld_edge_coefs(my_a, p.a, my_e, H, my_e < end);
-    if (p.drop_thresh) ld_edge_coefs(my_ad, p.ad, my_e, H, my_e < end);
-    const int left = end - base - wave;
-    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    auto da_of = [&](const float (&x)[NG][W], int j) {
-      const int e = base + j * GF_WAVES + wave;
-      float part[NH];
+  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+    RawGroup<VEC4> raw[GF_FLIGHT][NG];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) part[h] = 0.f;
+    for (int q = 0; q < GF_FLIGHT; ++q)
+      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
 #pragma unroll
-      for (int c = 0; c < NG; ++c) {
-        if (HG || hd[c] >= 0) {
-          float v = 0.f;
+    for (int q = 0; q < GF_FLIGHT; ++q) {
+      if (j + q < n_mine) {
+        float x[NG][W];
+        unpack_row<VEC4, W, NG>(x, raw[q]);
+        const int eidx = (j + q) * GF_WAVES + wave;
+        float part[NH];
 #pragma unroll
-          for (int jj = 0; jj < W; ++jj) v += gr[c][jj] * x[c][jj];
-          if (HG) part[c % NH] += v;
-          else {
+        for (int h = 0; h < NH; ++h) part[h] = 0.f;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+        for (int c = 0; c < NG; ++c) {
+          if (HG || hd[c] >= 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) v += gr[c][jj] * x[c][jj];
+            if (HG) part[c % NH] += v;
+            else {
+#pragma unroll
+              for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+            }
           }
         }
-      }
-      wave_sum_heads(part, H);
+        wave_sum_heads<NH>(part, H);
+        if (lane < H) {                                  // lane h finishes head h of this edge
+          const long long o = (long long)(beg + eidx) * H + lane;
+          float pv = 0.f;
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (h < H) {
-          float da = rbf_hw(part[h]);
-          if (p.drop_thresh) da = (bcast_f32(my_ad[h], j) != 0.f) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
-          if (lane == h) p.de[(long long)e * H + h] = f2bf_hw(da);
-          tp[h] += bcast_f32(my_a[h], j) * da;
-        }
-      }
-    };
-    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-      RawGroup<VEC4> raw[GF_FLIGHT][NG];
+          for (int h = 0; h < NH; ++h) if (h == lane) pv = part[h];
+          float da = rbf_hw(pv);
+          if (p.drop_thresh) da = (p.ad[o] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
+          sh_c[eidx][lane] = da;
+          float tl = 0.f;
 #pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
-        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+          for (int h = 0; h < NH; ++h) if (h == lane) tl = tp[h];
+          tl += bf2f(p.a[o]) * da;
 #pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q) {
-        if (j + q < n_mine) {                           // (wave-uniform)
-          float x[NG][W];
-          unpack_row<VEC4, W, NG>(x, raw[q]);
-          da_of(x, j + q);
+          for (int h = 0; h < NH; ++h) if (h == lane) tp[h] = tl;
         }
       }
     }
   }
-  if (lane < NH) {
+  if (lane < NH) {                                       // (lane h holds head h's share of t for this wave)
     float t = 0.f;
 #pragma unroll
     for (int h = 0; h < NH; ++h) if (h == lane) t = tp[h];
     sh_t[wave][lane] = t;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (G > 1) {                                         // t over the whole row: the segments' totals added in segment order
     float* tseg = p.seg_part + (long long)(*p.n_wg_dev) * HD;         // [n_wg, GF_MAXH] behind the partial rows
@@ -585,18 +566,18 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     }
     __syncthreads();
   }
-  // ---- pass 2: d e = a (d a - t)   (k_gat_softmax<true>)
+  // ---- pass 2: d e = a (d a - t)   (k_gat_softmax<true>); the by-source kernel reads it from memory, pass 3 from LDS
   const int cnt = (end - beg) * H;
   for (int i = tid; i < cnt; i += GF_TPB) {
-    const int h = i % H;
+    const int eidx = i / H, h = i - eidx * H;
     float t = sh_t[0][h];
 #pragma unroll
     for (int w2 = 1; w2 < GF_WAVES; ++w2) t += sh_t[w2][h];
     const long long o = (long long)beg * H + i;
-    const float da = bf2f(__hip_atomic_load(p.de + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    p.de[o] = f2bf(bf2f(p.a[o]) * (da - t));
+    const bf16_t de = f2bf(bf2f(p.a[o]) * (sh_c[eidx][h] - t));
+    p.de[o] = de;
+    sh_c[eidx][h] = bf2f(de);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- pass 3: d er_i = sum_j d e attn lrelu'(el_j + er_i);  d attn += d e lrelu(el_j + er_i)   (k_gat_rows<true, false>)
   float dacc[NG][W], aacc[NG][W];
@@ -604,41 +585,28 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   for (int c = 0; c < NG; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) { dacc[c][j] = 0.f; aacc[c][j] = 0.f; }
-  for (int base = beg; base < end; base += 64 * GF_WAVES) {
-    const int my_e = base + lane * GF_WAVES + wave;
-    const int my_s = my_e < end ? p.src[my_e] : 0;
-    float my_de[NH];
-    ld_edge_coefs(my_de, p.de, my_e, H, my_e < end);
-    const int left = end - base - wave;
-    const int n_mine = left <= 0 ? 0 : min(64, (left + GF_WAVES - 1) / GF_WAVES);
-    auto grads_of = [&](const float (&x)[NG][W], int j) {
-      float sv[NH];
+  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
+    RawGroup<VEC4> raw[GF_FLIGHT][NG];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) sv[h] = h < H ? bcast_f32(my_de[h], j) : 0.f;
+    for (int q = 0; q < GF_FLIGHT; ++q)
+      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
 #pragma unroll
-      for (int c = 0; c < NG; ++c) {
-        if (HG || hd[c] >= 0) {
-          const float cf = (HG ? sv[c % NH] : pick_head<NH>(sv, hd[c]));
+    for (int q = 0; q < GF_FLIGHT; ++q) {
+      if (j + q < n_mine) {
+        float x[NG][W];
+        unpack_row<VEC4, W, NG>(x, raw[q]);
+        const int eidx = (j + q) * GF_WAVES + wave;
 #pragma unroll
-          for (int jj = 0; jj < W; ++jj) {
-            const float sx = x[c][jj] + er[c][jj];
-            dacc[c][jj] += cf * at[c][jj] * (sx > 0.f ? 1.f : p.slope);
-            aacc[c][jj] += cf * lrelu_f(sx, p.slope);
+        for (int c = 0; c < NG; ++c) {
+          if (HG || hd[c] >= 0) {
+            const float cf = sh_c[eidx][HG ? c : hd[c]];
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) {
+              const float sx = x[c][jj] + er[c][jj];
+              dacc[c][jj] += cf * at[c][jj] * (sx > 0.f ? 1.f : p.slope);
+              aacc[c][jj] += cf * lrelu_f(sx, p.slope);
+            }
           }
-        }
-      }
-    };
-    for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-      RawGroup<VEC4> raw[GF_FLIGHT][NG];
-#pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
-        ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
-#pragma unroll
-      for (int q = 0; q < GF_FLIGHT; ++q) {
-        if (j + q < n_mine) {                           // (wave-uniform)
-          float x[NG][W];
-          unpack_row<VEC4, W, NG>(x, raw[q]);
-          grads_of(x, j + q);
         }
       }
     }
@@ -728,7 +696,7 @@ bool gf_fill(const bliss_gat_fused_t* a, GatFused* p, bool* vec4) {
   p->g = (const bf16_t*)a->g; p->g_stride = a->g_stride; p->de = (bf16_t*)a->de;
   p->d_er = (bf16_t*)a->d_er; p->der_stride = a->d_er_stride; p->dattn_part = a->dattn_part;
   p->wg_row = a->wg_row; p->n_wg_dev = a->n_wg_dev; p->rowws = (unsigned*)a->row_ws; p->seg_part = a->seg_part; p->err = a->err;
-  if (a->wg_row && (!a->n_wg_dev || !a->row_ws || !a->seg_part || a->cap_wg < a->n_dst)) return false;
+  if (!a->wg_row || !a->n_wg_dev || !a->row_ws || !a->seg_part || a->cap_wg < a->n_dst) return false;
   *vec4 = v4;
   return true;
 }
@@ -758,7 +726,7 @@ int bliss_gat_fused_fwd(const bliss_gat_fused_t* args, void* stream) {
   if (args->drop_p < 0.f || args->drop_p >= 1.f) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hg = (v4 && p.D == 256 && (p.H == 1 || p.H == 2 || p.H == 4)) ? p.H : 0;
-  const int grid = p.wg_row ? args->cap_wg : p.n_dst;
+  const int grid = args->cap_wg;
   if (hg == 4) k_gat_fwd<true, 4><<<grid, GF_TPB, 0, st>>>(p);
   else if (hg == 2) k_gat_fwd<true, 2><<<grid, GF_TPB, 0, st>>>(p);
   else if (hg == 1) k_gat_fwd<true, 1><<<grid, GF_TPB, 0, st>>>(p);
@@ -775,7 +743,7 @@ int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, fl
   if (p.drop_thresh && !p.ad) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hg = (v4 && p.D == 256 && (p.H == 1 || p.H == 2 || p.H == 4)) ? p.H : 0;
-  const int grid = p.wg_row ? args->cap_wg : p.n_dst;
+  const int grid = args->cap_wg;
   if (hg == 4) k_gat_bwd_dst<true, 4><<<grid, GF_TPB, 0, st>>>(p);
   else if (hg == 2) k_gat_bwd_dst<true, 2><<<grid, GF_TPB, 0, st>>>(p);
   else if (hg == 1) k_gat_bwd_dst<true, 1><<<grid, GF_TPB, 0, st>>>(p);
@@ -783,7 +751,7 @@ int bliss_gat_fused_bwd_dst(const bliss_gat_fused_t* args, float* block_sums, fl
   else k_gat_bwd_dst<false, 0><<<grid, GF_TPB, 0, st>>>(p);
   // the shares of d attn: one per (virtual) workgroup; rows of capacity padding wrote zeros
   const int nb = (grid + DA_ROWS - 1) / DA_ROWS, HD = p.H * p.D;
-  k_gat_dattn_stage1<<<dim3(nb, (HD + 255) / 256), 256, 0, st>>>(p.dattn_part, grid, p.wg_row ? p.n_wg_dev : p.n_dst_dev, HD, block_sums);
+  k_gat_dattn_stage1<<<dim3(nb, (HD + 255) / 256), 256, 0, st>>>(p.dattn_part, grid, p.n_wg_dev, HD, block_sums);
   k_gat_dattn_stage2<<<(HD + 63) / 64, 256, 0, st>>>(block_sums, nb, HD, d_attn);
   (void)ticket;
   return (int)hipGetLastError();
