@@ -24,7 +24,10 @@ namespace {
 #define GF_WAVES (GF_TPB / 64)
 #define GF_MAXH 8
 #define GF_ITER 4                      // a lane owns up to 4 groups of W consecutive columns: H*D <= 64 * W * 4
-#define GF_SEG 128                     // in-edges per workgroup: longer rows are shared by ceil(deg / GF_SEG) workgroups
+#define GF_EW 8                        // in-edges per wave and chunk: their gathered rows are all in flight / in registers together
+#define GF_CHUNK (GF_WAVES * GF_EW)    // in-edges per chunk of a workgroup (64)
+#define GF_NCH 4                       // chunks per workgroup
+#define GF_SEG (GF_CHUNK * GF_NCH)     // in-edges per workgroup (256): longer rows are shared by ceil(deg / GF_SEG) workgroups
 #define GF_ROWWS 32                    // words of cross-workgroup state per destination row
 // rowws layout (uint32 words): [0..2] arrive counters of the three meeting points, [3] error bits, [4..11] per-head maximum
 // (order-preserving encoding of the float), [12..27] per-head exact sum (uint64 each)
@@ -34,6 +37,7 @@ __device__ __forceinline__ bf16_t f2bf_hw(float f) { const __bf16 b = (__bf16)f;
 __device__ __forceinline__ float lrelu_f(float x, float s) { return x > 0.f ? x : s * x; }
 
 struct g4f { float v[4]; };
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <bool VEC4>
 __device__ __forceinline__ g4f ldrow(const bf16_t* p) {            // W consecutive elements of a row as floats
   g4f r;
@@ -52,6 +56,10 @@ __device__ __forceinline__ uint32_t gf_drop_hash(uint32_t seed, uint32_t ctr, ui
   x += ctr; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
   return x;
 }
+
+// phase stamps for scratch/gatbench.py (bliss_gat_fused_stamps): 8 x s_memrealtime (100 MHz) per virtual workgroup of the forward
+__device__ long long* g_gf_stamps = nullptr;
+#define GF_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(long long)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
 struct GatFused {
   const int* indptr; const int* src; int n_dst; const int* n_dst_dev;
@@ -97,7 +105,29 @@ __device__ __forceinline__ void unpack_row(float (&x)[NG][W], const RawGroup<VEC
     } else x[c][0] = __uint_as_float(r[c].u.x << 16);
   }
 }
-#define GF_FLIGHT 2
+// A workgroup's edges come in chunks of GF_CHUNK = 64: edge k * 64 + j * 8 + w of the workgroup is the j-th edge of wave w in chunk
+// k, and lane k * 8 + j of wave w holds its source id (my_s: ONE coalesced load per wave for the whole workgroup).
+// ld_wave_rows fetches ALL rows of the wave's (at most GF_EW) edges of one chunk, packed (8 VGPRs per edge when VEC4): every
+// gather of the chunk is in flight at the same time, and the rows of the workgroup's LAST chunk stay in registers from the first
+// pass to the last -- a row of at most 64 in-edges (most rows) is gathered once.  Slots beyond the wave's share re-read its last
+// edge (same cache lines, never used); the upper half of the slots is skipped altogether when the wave has at most four edges.
+__device__ __forceinline__ int wave_edges_in_chunk(int n, int k, int wave) {
+  const int left = min(n - k * GF_CHUNK, GF_CHUNK) - wave;
+  return left <= 0 ? 0 : (left + GF_WAVES - 1) / GF_WAVES;
+}
+template <bool VEC4, int NG>
+__device__ __forceinline__ void ld_wave_rows(RawGroup<VEC4> (&raw)[GF_EW][NG], const bf16_t* feat, long long stride, int my_s, int lane0,
+                                             int n_mine, const int (&coff)[NG]) {
+  const int last = n_mine > 0 ? n_mine - 1 : 0;
+#pragma unroll
+  for (int j = 0; j < GF_EW / 2; ++j)
+    ld_edge_raw<VEC4, NG>(raw[j], feat + (long long)__builtin_amdgcn_readlane(my_s, lane0 + (j < last ? j : last)) * stride, coff);
+  if (n_mine > GF_EW / 2) {                           // (wave-uniform)
+#pragma unroll
+    for (int j = GF_EW / 2; j < GF_EW; ++j)
+      ld_edge_raw<VEC4, NG>(raw[j], feat + (long long)__builtin_amdgcn_readlane(my_s, lane0 + (j < last ? j : last)) * stride, coff);
+  }
+}
 
 // per-edge, per-head coefficients ([nnz, H] bf16 arrays) of a sweep: lane l fetches those of ITS edge once (agent-scope loads:
 // another wave of the workgroup may have written them), the edge loop broadcasts them with v_readlane
@@ -186,18 +216,27 @@ __device__ __forceinline__ bool row_last(unsigned* ws, int G, int* sh_flag) {
 }
 
 // virtual workgroup -> destination row: row r gets max(1, ceil(deg_r / GF_SEG)) consecutive ids (rows of capacity padding have
-// no edges: one id each, their workgroup writes the zero row).  One workgroup scans the rows 1024 at a time.
+// no edges: one id each, their workgroup writes the zero row).  The shared rows get the LOWEST ids: their workgroups are the
+// long ones (four chunks and three meeting points) and the dispatcher hands out workgroups in id order.  One workgroup scans the
+// rows 1024 at a time, twice.
 __global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ indptr, int n_dst, int cap_wg, int* __restrict__ wg_row,
                                                         int* __restrict__ n_wg_dev, int* err) {
   __shared__ int sh[17];
   int run = 0;
-  for (int base = 0; base < n_dst; base += 1024) {
-    const int r = base + threadIdx.x;
-    int g = 0;
-    if (r < n_dst) { const int deg = indptr[r + 1] - indptr[r]; g = deg > GF_SEG ? (deg + GF_SEG - 1) / GF_SEG : 1; }
-    int tot, ex = block_excl_scan(g, sh, &tot);
-    for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = r;
-    run += tot;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int base = 0; base < n_dst; base += 1024) {
+      const int r = base + threadIdx.x;
+      int g = 0;
+      if (r < n_dst) {
+        const int deg = indptr[r + 1] - indptr[r];
+        g = deg > GF_SEG ? (deg + GF_SEG - 1) / GF_SEG : 1;
+        if ((g > 1) != (pass == 0)) g = 0;
+      }
+      int tot, ex = block_excl_scan(g, sh, &tot);
+      for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = r;
+      run += tot;
+      __syncthreads();
+    }
   }
   if (threadIdx.x == 0) {
     if (run > cap_wg) { if (err) atomicOr(err, BLISS_ERR_CAP_EDGES); run = cap_wg; }
@@ -205,12 +244,26 @@ __global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ i
   }
 }
 
-// per-head sums of a lane's partial values: part[h] over the wave (all lanes get the totals)
+// per-head sums of a lane's partial values: part[h] over the wave (all lanes get the totals).  The butterfly s += s[lane ^ d],
+// d = 32, 16, .. 1 (the order csrc/gat.hip's __shfl_xor loop adds in: same bits) on the VALU: gfx950's v_permlane32_swap /
+// v_permlane16_swap for d = 32 / 16 (both halves of the swapped pair added: fp32 addition commutes), DPP row_ror:8 and quad_perm
+// for d = 8, 2, 1, ds_swizzle for d = 4 -- no ds_bpermute address arithmetic, no LDS round trip per step
+__device__ __forceinline__ float wave_butterfly_sum(float s) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  s = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x128, 0xf, 0xf, false));          // row_ror:8  == lane ^ 8
+  s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x1f | (4 << 10)));                    // lane ^ 4
+  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4e, 0xf, 0xf, false));           // quad_perm [2,3,0,1]
+  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xb1, 0xf, 0xf, false));           // quad_perm [1,0,3,2]
+  return s;
+}
 template <int NH>
 __device__ __forceinline__ void wave_sum_heads(float (&part)[NH], int H) {
 #pragma unroll
   for (int h = 0; h < NH; ++h)
-    if (h < H) { float s = part[h]; for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d); part[h] = s; }
+    if (h < H) part[h] = wave_butterfly_sum(part[h]);
 }
 
 // this workgroup's share of its destination row: all of it (G == 1: at most GF_SEG edges) or segment seg_i of G
@@ -231,11 +284,11 @@ __device__ __forceinline__ RowSeg row_segment(const GatFused& p, int vwg) {
   return r;
 }
 
-// Forward.  A workgroup holds at most GF_SEG = 128 edges (longer rows are shared), so the logits and the softmax coefficients of
+// Forward.  A workgroup holds at most GF_SEG = 256 edges (longer rows are shared), so the logits and the softmax coefficients of
 // its edges live in LDS between the passes (the global copies are outputs only: nothing is re-read from memory, no wait for a
 // store, no agent-scope load) and a wave's source ids are ONE coalesced load kept in registers for both gather passes.
 template <bool VEC4, int HG>
-__global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
+__global__ void __launch_bounds__(GF_TPB, 4) k_gat_fwd(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
   // HG > 0: "a column group is a head" (VEC4, D == 256: group c of 64 lanes x 4 columns IS head c, H == HG <= 4) -- the Reddit
   // config's 4 x 256; every per-head selection below is then a compile-time index.  HG == 0: any H <= 8, D (head by compare)
@@ -248,6 +301,8 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int vwg = blockIdx.x;
+  long long* stamps = g_gf_stamps;
+  GF_STAMP(0);
   if (vwg >= *p.n_wg_dev) return;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
@@ -256,16 +311,15 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   if (vwg == 0 && tid == 0 && p.drop_thresh && p.ctr_used) *p.ctr_used = ctr;
   const RowSeg rs = row_segment(p, vwg);
   const int row = rs.row, beg = rs.beg, end = rs.end, G = rs.G, seg_i = rs.seg_i;
+  GF_STAMP(1);
   if (row >= S) {                                      // capacity padding: finite zeros
     for (int c = tid; c < HD; c += GF_TPB) p.rst[(long long)row * p.rst_stride + c] = 0;
     return;
   }
   unsigned* ws = p.rowws + (long long)row * GF_ROWWS;
-  // this wave's edges: local index j * GF_WAVES + wave, j < n_mine <= 16; lane j holds the source id of the wave's j-th edge
-  const int my_e = beg + lane * GF_WAVES + wave;
-  const int my_s = my_e < end ? p.src[my_e] : 0;
-  const int left = end - beg - wave;
-  const int n_mine = left <= 0 ? 0 : (left + GF_WAVES - 1) / GF_WAVES;
+  const int my_e = beg + (lane >> 3) * GF_CHUNK + (lane & 7) * GF_WAVES + wave;
+  const int my_s = (lane < GF_NCH * GF_EW && my_e < end) ? p.src[my_e] : 0;
+  const int n_edges = end - beg, n_chunks = (n_edges + GF_CHUNK - 1) / GF_CHUNK;
   // this lane's columns: group c covers columns c*64*W + lane*W .. +W-1 (one head per group when VEC4: D % 4 == 0)
   float er[NG][W], at[NG][W], acc[NG][W];
   int hd[NG], coff[NG];
@@ -285,52 +339,58 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
   float mx[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) mx[h] = -__builtin_inff();
-  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-    RawGroup<VEC4> raw[GF_FLIGHT][NG];
+  auto logits_of_chunk = [&](RawGroup<VEC4> (&raw)[GF_EW][NG], int k) {
+  const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
+  ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q)               // (edges beyond the wave's share re-read edge j: discarded below)
-      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+  for (int j = 0; j < GF_EW; ++j) {
+    if (j < n_mine) {                                 // (wave-uniform)
+      float x[NG][W];
+      unpack_row<VEC4, W, NG>(x, raw[j]);
+      const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
+      float part[NH];
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q) {
-      if (j + q < n_mine) {                           // (wave-uniform)
-        float x[NG][W];
-        unpack_row<VEC4, W, NG>(x, raw[q]);
-        const int eidx = (j + q) * GF_WAVES + wave;
-        float part[NH];
+      for (int h = 0; h < NH; ++h) part[h] = 0.f;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) part[h] = 0.f;
+      for (int c = 0; c < NG; ++c) {
+        if (HG || hd[c] >= 0) {
+          float v = 0.f;
 #pragma unroll
-        for (int c = 0; c < NG; ++c) {
-          if (HG || hd[c] >= 0) {
-            float v = 0.f;
+          for (int jj = 0; jj < W; ++jj) v += rbf_hw(at[c][jj] * rbf_hw(lrelu_f(rbf_hw(x[c][jj] + er[c][jj]), p.slope)));
+          if (HG) part[c % NH] += v;
+          else {
 #pragma unroll
-            for (int jj = 0; jj < W; ++jj) v += rbf_hw(at[c][jj] * rbf_hw(lrelu_f(rbf_hw(x[c][jj] + er[c][jj]), p.slope)));
-            if (HG) part[c % NH] += v;
-            else {
-#pragma unroll
-              for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
-            }
+            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
           }
         }
-        wave_sum_heads<NH>(part, H);
+      }
+      wave_sum_heads<NH>(part, H);
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          if (h < H) {
-            const bf16_t eb = f2bf_hw(part[h]);
-            if (lane == h) { p.e[(long long)(beg + eidx) * H + h] = eb; sh_e[eidx][h] = bf2f(eb); }
-            mx[h] = fmaxf(mx[h], bf2f(eb));
-          }
+      for (int h = 0; h < NH; ++h) {
+        if (h < H) {
+          const bf16_t eb = f2bf_hw(part[h]);
+          if (lane == h) { p.e[(long long)(beg + eidx) * H + h] = eb; sh_e[eidx][h] = bf2f(eb); }
+          mx[h] = fmaxf(mx[h], bf2f(eb));
         }
       }
     }
   }
+  };
+  for (int k = 0; k + 1 < n_chunks; ++k) {            // (rows of more than 64 in-edges only: these chunks are gathered again in pass 3)
+    RawGroup<VEC4> tmp[GF_EW][NG];
+    logits_of_chunk(tmp, k);
+  }
+  RawGroup<VEC4> raw[GF_EW][NG];                        // the last chunk's rows: kept to pass 3
+  if (n_chunks > 0) logits_of_chunk(raw, n_chunks - 1);
   if (lane < NH) {
     float m = -__builtin_inff();
 #pragma unroll
     for (int h = 0; h < NH; ++h) if (h == lane) m = mx[h];
     sh_max[wave][lane] = m;
   }
+  GF_STAMP(2);
   __syncthreads();
+  GF_STAMP(3);
   if (G > 1) {                                         // the row's maximum over all its segments
     if (tid < H) {
       float m = sh_max[0][tid];
@@ -346,6 +406,7 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     }
     __syncthreads();
   }
+  GF_STAMP(4);
   // ---- pass 2: edge softmax over the logits in LDS (model.py:88-90; [DGL-recalled] four bf16 ops, exact sum), attention dropout
   const int cnt = (end - beg) * H;
   int bad = 0;
@@ -389,18 +450,17 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     sh_e[eidx][h] = bf2f(cv);                            // what multiplies el_j in pass 3
   }
   __syncthreads();
-  // ---- pass 3: out = sum_j a_ij el_j (model.py:98), fp32 products and sums, one rounding
-  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-    RawGroup<VEC4> raw[GF_FLIGHT][NG];
+  GF_STAMP(5);
+  // ---- pass 3: out = sum_j a_ij el_j (model.py:98), fp32 products and sums, one rounding.  The last chunk first: its rows are
+  // still in registers; the others (rows of more than 64 in-edges only) are gathered a second time
+  auto aggregate_chunk = [&](const RawGroup<VEC4> (&rows)[GF_EW][NG], int k) {
+    const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q)
-      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
-#pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q) {
-      if (j + q < n_mine) {
+    for (int j = 0; j < GF_EW; ++j) {
+      if (j < n_mine) {
         float x[NG][W];
-        unpack_row<VEC4, W, NG>(x, raw[q]);
-        const int eidx = (j + q) * GF_WAVES + wave;
+        unpack_row<VEC4, W, NG>(x, rows[j]);
+        const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
           if (HG || hd[c] >= 0) {
@@ -411,12 +471,19 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
         }
       }
     }
+  };
+  if (n_chunks > 0) aggregate_chunk(raw, n_chunks - 1);
+  for (int k = 0; k + 1 < n_chunks; ++k) {
+    RawGroup<VEC4> tmp[GF_EW][NG];
+    ld_wave_rows<VEC4, NG>(tmp, p.feat, p.feat_stride, my_s, k * GF_EW, wave_edges_in_chunk(n_edges, k, wave), coff);
+    aggregate_chunk(tmp, k);
   }
 #pragma unroll
   for (int c = 0; c < NG; ++c)
 #pragma unroll
     for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = acc[c][j];
   __syncthreads();
+  GF_STAMP(6);
   if (G == 1) {
     for (int col = tid; col < HD; col += GF_TPB) {
       float s = sh_acc[0][col];
@@ -424,6 +491,7 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
       for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];   // fixed order: bitwise reproducible
       p.rst[(long long)row * p.rst_stride + col] = f2bf(s);
     }
+    GF_STAMP(7);
     return;
   }
   // a shared row: leave this segment's partial row; whoever arrives last adds the segments up in segment order
@@ -442,6 +510,7 @@ __global__ void __launch_bounds__(GF_TPB) k_gat_fwd(GatFused p) {
     }
     for (int i = tid; i < GF_ROWWS; i += GF_TPB) ws[i] = 0u;          // the row's words back to zero for the next launch
   }
+  GF_STAMP(7);
 }
 
 // the dropout stream's launch counter moves on behind the forward kernel (every workgroup has read it by then).  A ticket taken
@@ -455,9 +524,10 @@ template <bool VEC4, int HG>
 __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
   constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
-  __shared__ float sh_acc[GF_WAVES][NG * 64 * W];
+  __shared__ float sh_acc[GF_WAVES][NG * 64 * W], sh_acc2[GF_WAVES][NG * 64 * W];   // the waves' shares of d er_i / of d attn
   __shared__ float sh_c[GF_SEG][GF_MAXH];                  // d a, then d e, of this workgroup's edges
   __shared__ float sh_t[GF_WAVES][GF_MAXH];
+  __shared__ float sh_er[NG * 64 * W];                     // er_i (pass 3 reads it group by group)
   __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int vwg = blockIdx.x;
@@ -472,80 +542,65 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     return;
   }
   unsigned* ws = p.rowws + (long long)row * GF_ROWWS;
-  const int my_e = beg + lane * GF_WAVES + wave;
-  const int my_s = my_e < end ? p.src[my_e] : 0;
-  const int left = end - beg - wave;
-  const int n_mine = left <= 0 ? 0 : (left + GF_WAVES - 1) / GF_WAVES;
-  float er[NG][W], at[NG][W], gr[NG][W];
+  const int my_e = beg + (lane >> 3) * GF_CHUNK + (lane & 7) * GF_WAVES + wave;
+  const int my_s = (lane < GF_NCH * GF_EW && my_e < end) ? p.src[my_e] : 0;
+  const int n_edges = end - beg, n_chunks = (n_edges + GF_CHUNK - 1) / GF_CHUNK;
   int hd[NG], coff[NG];
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
     const int col = c * 64 * W + lane * W;
     hd[c] = col < HD ? col / D : -1;
     coff[c] = col < HD ? col : 0;
-    const g4f z = g4f{{0.f, 0.f, 0.f, 0.f}};
-    const g4f x = col < HD ? ldrow<VEC4>(p.feat + (long long)row * p.feat_stride + col) : z;
-    const g4f t = col < HD ? ldrow<VEC4>(p.attn + col) : z;
-    const g4f gg = col < HD ? ldrow<VEC4>(p.g + (long long)row * p.g_stride + col) : z;
-#pragma unroll
-    for (int j = 0; j < W; ++j) { er[c][j] = x.v[j]; at[c][j] = t.v[j]; gr[c][j] = gg.v[j]; }
   }
+  RawGroup<VEC4> graw[NG];                               // g_i, packed like the gathered rows (masked columns: hd < 0, never used)
+  ld_edge_raw<VEC4, NG>(graw, p.g + (long long)row * p.g_stride, coff);
+  for (int col = tid; col < NG * 64 * W; col += GF_TPB) sh_er[col] = col < HD ? bf2f(p.feat[(long long)row * p.feat_stride + col]) : 0.f;
   // ---- pass 1: d a_ij[h] = g_i[h,:] . el_j[h,:] (bf16, like k_gat_edge_dot<1>), through the dropout mask; t[h] = sum a d a
-  float tp[NH];
+  float tp = 0.f;                                        // lane h: head h's share of t over this wave's edges
+  auto dalpha_of_chunk = [&](RawGroup<VEC4> (&raw)[GF_EW][NG], int k) {
+  const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
+  ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
 #pragma unroll
-  for (int h = 0; h < NH; ++h) tp[h] = 0.f;
-  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-    RawGroup<VEC4> raw[GF_FLIGHT][NG];
+  for (int j = 0; j < GF_EW; ++j) {
+    if (j < n_mine) {
+      const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
+      float part[NH];
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q)
-      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+      for (int h = 0; h < NH; ++h) part[h] = 0.f;
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q) {
-      if (j + q < n_mine) {
-        float x[NG][W];
-        unpack_row<VEC4, W, NG>(x, raw[q]);
-        const int eidx = (j + q) * GF_WAVES + wave;
-        float part[NH];
+      for (int c = 0; c < NG; ++c) {
+        if (HG || hd[c] >= 0) {
+          // g . el on the packed pairs (v_dot2_f32_bf16: exact products, fp32 accumulation)
+          float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.x), __builtin_bit_cast(bf16x2_t, raw[j][c].u.x), 0.f, false);
+          if (VEC4) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.y), __builtin_bit_cast(bf16x2_t, raw[j][c].u.y), v, false);
+          if (HG) part[c % NH] += v;
+          else {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) part[h] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NG; ++c) {
-          if (HG || hd[c] >= 0) {
-            float v = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < W; ++jj) v += gr[c][jj] * x[c][jj];
-            if (HG) part[c % NH] += v;
-            else {
-#pragma unroll
-              for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
-            }
+            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
           }
         }
-        wave_sum_heads<NH>(part, H);
-        if (lane < H) {                                  // lane h finishes head h of this edge
-          const long long o = (long long)(beg + eidx) * H + lane;
-          float pv = 0.f;
+      }
+      wave_sum_heads<NH>(part, H);
+      if (lane < H) {                                  // lane h finishes head h of this edge
+        const long long o = (long long)(beg + eidx) * H + lane;
+        float pv = 0.f;
 #pragma unroll
-          for (int h = 0; h < NH; ++h) if (h == lane) pv = part[h];
-          float da = rbf_hw(pv);
-          if (p.drop_thresh) da = (p.ad[o] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
-          sh_c[eidx][lane] = da;
-          float tl = 0.f;
-#pragma unroll
-          for (int h = 0; h < NH; ++h) if (h == lane) tl = tp[h];
-          tl += bf2f(p.a[o]) * da;
-#pragma unroll
-          for (int h = 0; h < NH; ++h) if (h == lane) tp[h] = tl;
-        }
+        for (int h = 0; h < NH; ++h) if (h == lane) pv = part[h];
+        float da = rbf_hw(pv);
+        if (p.drop_thresh) da = (p.ad[o] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
+        sh_c[eidx][lane] = da;
+        tp += bf2f(p.a[o]) * da;
       }
     }
   }
-  if (lane < NH) {                                       // (lane h holds head h's share of t for this wave)
-    float t = 0.f;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) if (h == lane) t = tp[h];
-    sh_t[wave][lane] = t;
+  };
+  for (int k = 0; k + 1 < n_chunks; ++k) {
+    RawGroup<VEC4> tmp[GF_EW][NG];
+    dalpha_of_chunk(tmp, k);
   }
+  RawGroup<VEC4> raw[GF_EW][NG];
+  if (n_chunks > 0) dalpha_of_chunk(raw, n_chunks - 1);
+  if (lane < NH) sh_t[wave][lane] = tp;
   __syncthreads();
   if (G > 1) {                                         // t over the whole row: the segments' totals added in segment order
     float* tseg = p.seg_part + (long long)(*p.n_wg_dev) * HD;         // [n_wg, GF_MAXH] behind the partial rows
@@ -580,61 +635,57 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   }
   __syncthreads();
   // ---- pass 3: d er_i = sum_j d e attn lrelu'(el_j + er_i);  d attn += d e lrelu(el_j + er_i)   (k_gat_rows<true, false>)
-  float dacc[NG][W], aacc[NG][W];
+  // Chunk by chunk (the last one first: its rows are still in registers), column group by column group: one group's accumulators and
+  // er_i beside the packed rows keep the kernel under 128 registers; a wave adds each chunk's share to its own slice in LDS
 #pragma unroll
   for (int c = 0; c < NG; ++c)
 #pragma unroll
-    for (int j = 0; j < W; ++j) { dacc[c][j] = 0.f; aacc[c][j] = 0.f; }
-  for (int j = 0; j < n_mine; j += GF_FLIGHT) {
-    RawGroup<VEC4> raw[GF_FLIGHT][NG];
+    for (int jj = 0; jj < W; ++jj) { sh_acc[wave][c * 64 * W + lane * W + jj] = 0.f; sh_acc2[wave][c * 64 * W + lane * W + jj] = 0.f; }
+  auto rows_of_chunk = [&](const RawGroup<VEC4> (&raw)[GF_EW][NG], int k) {
+    const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q)
-      ld_edge_raw<VEC4, NG>(raw[q], p.feat + (long long)__builtin_amdgcn_readlane(my_s, j + q < n_mine ? j + q : j) * p.feat_stride, coff);
+    for (int c = 0; c < NG; ++c) {
+      float erc[W], da[W], aa[W];
 #pragma unroll
-    for (int q = 0; q < GF_FLIGHT; ++q) {
-      if (j + q < n_mine) {
-        float x[NG][W];
-        unpack_row<VEC4, W, NG>(x, raw[q]);
-        const int eidx = (j + q) * GF_WAVES + wave;
+      for (int jj = 0; jj < W; ++jj) { erc[jj] = sh_er[c * 64 * W + lane * W + jj]; da[jj] = 0.f; aa[jj] = 0.f; }
+      if (HG || hd[c] >= 0) {
 #pragma unroll
-        for (int c = 0; c < NG; ++c) {
-          if (HG || hd[c] >= 0) {
-            const float cf = sh_c[eidx][HG ? c : hd[c]];
+        for (int j = 0; j < GF_EW; ++j) {
+          if (j < n_mine) {
+            float x[W];
+            if (VEC4) {
+              x[0] = __uint_as_float(raw[j][c].u.x << 16); x[1 % W] = __uint_as_float(raw[j][c].u.x & 0xffff0000u);
+              x[2 % W] = __uint_as_float(raw[j][c].u.y << 16); x[3 % W] = __uint_as_float(raw[j][c].u.y & 0xffff0000u);
+            } else x[0] = __uint_as_float(raw[j][c].u.x << 16);
+            const float cf = sh_c[k * GF_CHUNK + j * GF_WAVES + wave][HG ? c : hd[c]];
 #pragma unroll
             for (int jj = 0; jj < W; ++jj) {
-              const float sx = x[c][jj] + er[c][jj];
-              dacc[c][jj] += cf * at[c][jj] * (sx > 0.f ? 1.f : p.slope);
-              aacc[c][jj] += cf * lrelu_f(sx, p.slope);
+              const float sx = x[jj] + erc[jj];
+              da[jj] += cf * (sx > 0.f ? 1.f : p.slope);
+              aa[jj] += cf * lrelu_f(sx, p.slope);
             }
           }
         }
       }
+#pragma unroll
+      for (int jj = 0; jj < W; ++jj) { sh_acc[wave][c * 64 * W + lane * W + jj] += da[jj]; sh_acc2[wave][c * 64 * W + lane * W + jj] += aa[jj]; }
     }
+  };
+  if (n_chunks > 0) rows_of_chunk(raw, n_chunks - 1);
+  for (int k = 0; k + 1 < n_chunks; ++k) {
+    RawGroup<VEC4> tmp[GF_EW][NG];
+    ld_wave_rows<VEC4, NG>(tmp, p.feat, p.feat_stride, my_s, k * GF_EW, wave_edges_in_chunk(n_edges, k, wave), coff);
+    rows_of_chunk(tmp, k);
   }
-  // two cross-wave reductions through the same LDS buffer
-#pragma unroll
-  for (int c = 0; c < NG; ++c)
-#pragma unroll
-    for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = dacc[c][j];
   __syncthreads();
-  for (int col = tid; col < HD; col += GF_TPB) {
-    float s = sh_acc[0][col];
+  for (int col = tid; col < HD; col += GF_TPB) {       // the waves' shares in wave order; d er carries attn as a common factor
+    float s = sh_acc[0][col], s2 = sh_acc2[0][col];
 #pragma unroll
-    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
+    for (int w2 = 1; w2 < GF_WAVES; ++w2) { s += sh_acc[w2][col]; s2 += sh_acc2[w2][col]; }
+    s *= bf2f(p.attn[col]);
     if (G == 1) p.d_er[(long long)row * p.der_stride + col] = f2bf(s);
     else p.seg_part[(long long)vwg * HD + col] = s;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < NG; ++c)
-#pragma unroll
-    for (int j = 0; j < W; ++j) sh_acc[wave][c * 64 * W + lane * W + j] = aacc[c][j];
-  __syncthreads();
-  for (int col = tid; col < HD; col += GF_TPB) {
-    float s = sh_acc[0][col];
-#pragma unroll
-    for (int w2 = 1; w2 < GF_WAVES; ++w2) s += sh_acc[w2][col];
-    p.dattn_part[(long long)vwg * HD + col] = s;       // (one share per workgroup: the reduction adds them in workgroup order)
+    p.dattn_part[(long long)vwg * HD + col] = s2;      // (one share per workgroup: the reduction adds them in workgroup order)
   }
   if (G > 1 && row_last(ws, G, &sh_last)) {            // d er of a shared row: the segments' partial rows in segment order
     const long long v0 = vwg - seg_i;
@@ -711,6 +762,10 @@ int bliss_gat_fused_supported(int32_t heads, int32_t head_dim) {
 }
 
 int bliss_gat_segment_edges(void) { return GF_SEG; }
+
+int bliss_gat_fused_stamps(long long* stamps) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gf_stamps), &stamps, sizeof(stamps));
+}
 
 int bliss_gat_segments(const int32_t* indptr, int32_t n_dst, int32_t cap_wg, int32_t* wg_row, int32_t* n_wg_dev, int32_t* err, void* stream) {
   if (!indptr || !wg_row || !n_wg_dev || n_dst <= 0 || cap_wg < n_dst) return BLISS_EINVAL;

@@ -515,6 +515,10 @@ typedef struct {
   const int32_t* wg_row; const int32_t* n_wg_dev; int32_t cap_wg; void* row_ws; float* seg_part; int32_t* err;
 } bliss_gat_fused_t;
 int bliss_gat_segment_edges(void);
+/* measurement hook (scratch/gatbench.py): while `stamps` is not NULL every virtual workgroup of bliss_gat_fused_fwd writes eight
+ * 100 MHz device timestamps (start, row resolved, pass 1 done, after its barrier, after the max exchange, pass 2 done, pass 3
+ * done, end) to stamps[8 * workgroup ..]; NULL switches it off again.  Not part of the data path. */
+int bliss_gat_fused_stamps(long long* stamps);
 /* virtual workgroup -> destination row for the two kernels below: row r gets max(1, ceil(deg_r / bliss_gat_segment_edges()))
  * consecutive ids; cap_wg >= n_dst + nnz_bound / bliss_gat_segment_edges() suffices. */
 int bliss_gat_segments(const int32_t* indptr, int32_t n_dst, int32_t cap_wg, int32_t* wg_row, int32_t* n_wg_dev, int32_t* err, void* stream);
