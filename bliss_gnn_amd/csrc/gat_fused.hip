@@ -35,6 +35,8 @@ namespace {
 __device__ __forceinline__ float rbf_hw(float f) { return (float)(__bf16)f; }
 __device__ __forceinline__ bf16_t f2bf_hw(float f) { const __bf16 b = (__bf16)f; return __builtin_bit_cast(unsigned short, b); }
 __device__ __forceinline__ float lrelu_f(float x, float s) { return x > 0.f ? x : s * x; }
+// v_max_f32 as it is (fmaxf adds a canonicalising v_max per operand); a NaN logit is caught by the exact sum's flag instead
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 struct g4f { float v[4]; };
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -219,23 +221,51 @@ __device__ __forceinline__ bool row_last(unsigned* ws, int G, int* sh_flag) {
 // no edges: one id each, their workgroup writes the zero row).  The shared rows get the LOWEST ids: their workgroups are the
 // long ones (four chunks and three meeting points) and the dispatcher hands out workgroups in id order.  One workgroup scans the
 // rows 1024 at a time, twice.
+#define GF_SEG_R 16                     // rows per thread of the one-sweep path
+__device__ __forceinline__ int gf_row_wgs(int deg) { return deg > GF_SEG ? (deg + GF_SEG - 1) / GF_SEG : 1; }
 __global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ indptr, int n_dst, int cap_wg, int* __restrict__ wg_row,
                                                         int* __restrict__ n_wg_dev, int* err) {
   __shared__ int sh[17];
   int run = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int base = 0; base < n_dst; base += 1024) {
-      const int r = base + threadIdx.x;
-      int g = 0;
-      if (r < n_dst) {
-        const int deg = indptr[r + 1] - indptr[r];
-        g = deg > GF_SEG ? (deg + GF_SEG - 1) / GF_SEG : 1;
-        if ((g > 1) != (pass == 0)) g = 0;
+  if (n_dst <= 1024 * GF_SEG_R) {
+    // one sweep: a thread owns R consecutive rows, all their degrees loaded up front (the launch sits on the forward's critical
+    // path: 15 us as two scanning loops over 9 K rows, a third of that like this)
+    const int R = (n_dst + 1023) / 1024, r0 = threadIdx.x * R;
+    int ip[GF_SEG_R + 1];
+#pragma unroll
+    for (int i = 0; i <= GF_SEG_R; ++i) ip[i] = (i <= R && r0 + i <= n_dst) ? indptr[r0 + i] : 0;
+    int n_sh = 0, n_1 = 0;
+#pragma unroll
+    for (int i = 0; i < GF_SEG_R; ++i) {
+      if (i < R && r0 + i < n_dst) { const int g = gf_row_wgs(ip[i + 1] - ip[i]); if (g > 1) n_sh += g; else ++n_1; }
+    }
+    int tot_sh, tot_1;
+    int at_sh = block_excl_scan(n_sh, sh, &tot_sh);
+    __syncthreads();
+    int at_1 = tot_sh + block_excl_scan(n_1, sh, &tot_1);
+#pragma unroll
+    for (int i = 0; i < GF_SEG_R; ++i) {
+      if (i < R && r0 + i < n_dst) {
+        const int g = gf_row_wgs(ip[i + 1] - ip[i]);
+        if (g > 1) { for (int q = 0; q < g; ++q) if (at_sh + q < cap_wg) wg_row[at_sh + q] = r0 + i; at_sh += g; }
+        else { if (at_1 < cap_wg) wg_row[at_1] = r0 + i; ++at_1; }
       }
-      int tot, ex = block_excl_scan(g, sh, &tot);
-      for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = r;
-      run += tot;
-      __syncthreads();
+    }
+    run = tot_sh + tot_1;
+  } else {
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int base = 0; base < n_dst; base += 1024) {
+        const int r = base + threadIdx.x;
+        int g = 0;
+        if (r < n_dst) {
+          g = gf_row_wgs(indptr[r + 1] - indptr[r]);
+          if ((g > 1) != (pass == 0)) g = 0;
+        }
+        int tot, ex = block_excl_scan(g, sh, &tot);
+        for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = r;
+        run += tot;
+        __syncthreads();
+      }
     }
   }
   if (threadIdx.x == 0) {
@@ -295,6 +325,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_fwd(GatFused p) {
   constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
   __shared__ float sh_acc[GF_WAVES][NG * 64 * W];          // cross-wave reduction of the output row (32 KiB when VEC4)
   __shared__ float sh_e[GF_SEG][GF_MAXH];                  // logits of this workgroup's edges, then their softmax coefficients
+  __shared__ float sh_er[NG * 64 * W], sh_at[NG * 64 * W]; // er_i, attn (zero beyond H*D)
   __shared__ float sh_max[GF_WAVES][GF_MAXH];
   __shared__ unsigned long long sh_sum[GF_MAXH];
   __shared__ int sh_bad;
@@ -321,17 +352,22 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_fwd(GatFused p) {
   const int my_s = (lane < GF_NCH * GF_EW && my_e < end) ? p.src[my_e] : 0;
   const int n_edges = end - beg, n_chunks = (n_edges + GF_CHUNK - 1) / GF_CHUNK;
   // this lane's columns: group c covers columns c*64*W + lane*W .. +W-1 (one head per group when VEC4: D % 4 == 0)
-  float er[NG][W], at[NG][W], acc[NG][W];
+  float acc[NG][W];
   int hd[NG], coff[NG];
 #pragma unroll
   for (int c = 0; c < NG; ++c) {
     const int col = c * 64 * W + lane * W;
     hd[c] = col < HD ? col / D : -1;
-    coff[c] = col < HD ? col : 0;                       // (masked columns re-read the row's first W elements; at = 0 there)
-    const g4f x = col < HD ? ldrow<VEC4>(p.feat + (long long)row * p.feat_stride + col) : g4f{{0.f, 0.f, 0.f, 0.f}};
-    const g4f t = col < HD ? ldrow<VEC4>(p.attn + col) : g4f{{0.f, 0.f, 0.f, 0.f}};
+    coff[c] = col < HD ? col : 0;                       // (masked columns re-read the row's first W elements; attn = 0 there)
 #pragma unroll
-    for (int j = 0; j < W; ++j) { er[c][j] = x.v[j]; at[c][j] = t.v[j]; acc[c][j] = 0.f; }
+    for (int jj = 0; jj < W; ++jj) acc[c][jj] = 0.f;
+  }
+  // er_i and attn go through LDS (pass 1 reads them one column group at a time: 32 registers less beside the packed rows);
+  // threads 0..255 fetch er_i, 256..511 attn, W columns each -- in flight together with the source ids and the row gathers
+  g4f er_at = g4f{{0.f, 0.f, 0.f, 0.f}};
+  {
+    const int col = (tid & 255) * W;
+    if (col < HD) er_at = ldrow<VEC4>((tid >> 8) ? p.attn + col : p.feat + (long long)row * p.feat_stride + col);
   }
   if (tid < GF_MAXH) sh_sum[tid] = 0ull;
   if (tid == 0) sh_bad = 0;
@@ -339,42 +375,93 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_fwd(GatFused p) {
   float mx[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) mx[h] = -__builtin_inff();
+  bool staged = false;
   auto logits_of_chunk = [&](RawGroup<VEC4> (&raw)[GF_EW][NG], int k) {
-  const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
-  ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
+    const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
+    ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
+    if (!staged) {                                    // (block-uniform; behind the first chunk's gathers, which stay in flight)
+      float* dstp = (tid >> 8) ? sh_at : sh_er;
 #pragma unroll
-  for (int j = 0; j < GF_EW; ++j) {
-    if (j < n_mine) {                                 // (wave-uniform)
-      float x[NG][W];
-      unpack_row<VEC4, W, NG>(x, raw[j]);
-      const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
-      float part[NH];
+      for (int jj = 0; jj < W; ++jj) dstp[(tid & 255) * W + jj] = er_at.v[jj];
+      __syncthreads();
+      staged = true;
+    }
+    if (HG) {
+      // a column group is a head: group by group (er_i / attn of ONE group in registers), the group's dot product of every edge
+      // finished by its own butterfly -- the same operations in the same order per (edge, head) as edge by edge
+      float mine[GF_EW];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) part[h] = 0.f;
+      for (int j = 0; j < GF_EW; ++j) mine[j] = 0.f;
 #pragma unroll
       for (int c = 0; c < NG; ++c) {
-        if (HG || hd[c] >= 0) {
-          float v = 0.f;
+        float erc[W], atc[W];
 #pragma unroll
-          for (int jj = 0; jj < W; ++jj) v += rbf_hw(at[c][jj] * rbf_hw(lrelu_f(rbf_hw(x[c][jj] + er[c][jj]), p.slope)));
-          if (HG) part[c % NH] += v;
-          else {
+        for (int jj = 0; jj < W; ++jj) { erc[jj] = sh_er[c * 64 * W + lane * W + jj]; atc[jj] = sh_at[c * 64 * W + lane * W + jj]; }
+#pragma unroll
+        for (int j = 0; j < GF_EW; ++j) {
+          if (j < n_mine) {                           // (wave-uniform)
+            float x[W];
+            if (VEC4) {
+              x[0] = __uint_as_float(raw[j][c].u.x << 16); x[1 % W] = __uint_as_float(raw[j][c].u.x & 0xffff0000u);
+              x[2 % W] = __uint_as_float(raw[j][c].u.y << 16); x[3 % W] = __uint_as_float(raw[j][c].u.y & 0xffff0000u);
+            } else x[0] = __uint_as_float(raw[j][c].u.x << 16);
+            float v = 0.f, part = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) v += rbf_hw(atc[jj] * rbf_hw(lrelu_f(rbf_hw(x[jj] + erc[jj]), p.slope)));
+            part += v;
+            const float eb = rbf_hw(wave_butterfly_sum(part));
+            mine[j] = lane == c ? eb : mine[j];
+            mx[c % NH] = max_raw(mx[c % NH], eb);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < GF_EW; ++j) {
+        if (j < n_mine && lane < H) {
+          const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
+          p.e[(long long)(beg + eidx) * H + lane] = (bf16_t)(__float_as_uint(mine[j]) >> 16);
+          sh_e[eidx][lane] = mine[j];
+        }
+      }
+      return;
+    }
+    float er[NG][W], at[NG][W];
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+      for (int jj = 0; jj < W; ++jj) { er[c][jj] = sh_er[c * 64 * W + lane * W + jj]; at[c][jj] = sh_at[c * 64 * W + lane * W + jj]; }
+#pragma unroll
+    for (int j = 0; j < GF_EW; ++j) {
+      if (j < n_mine) {                                 // (wave-uniform)
+        float x[NG][W];
+        unpack_row<VEC4, W, NG>(x, raw[j]);
+        const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
+        float part[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) part[h] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+          if (hd[c] >= 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < W; ++jj) v += rbf_hw(at[c][jj] * rbf_hw(lrelu_f(rbf_hw(x[c][jj] + er[c][jj]), p.slope)));
 #pragma unroll
             for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
           }
         }
-      }
-      wave_sum_heads<NH>(part, H);
+        wave_sum_heads<NH>(part, H);
+        float mine = 0.f;                                // lane h < H: head h's logit of this edge
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (h < H) {
-          const bf16_t eb = f2bf_hw(part[h]);
-          if (lane == h) { p.e[(long long)(beg + eidx) * H + h] = eb; sh_e[eidx][h] = bf2f(eb); }
-          mx[h] = fmaxf(mx[h], bf2f(eb));
+        for (int h = 0; h < NH; ++h) {
+          if (h < H) {
+            const float eb = rbf_hw(part[h]);
+            mine = lane == h ? eb : mine;
+            mx[h] = max_raw(mx[h], eb);
+          }
         }
+        if (lane < H) { p.e[(long long)(beg + eidx) * H + lane] = (bf16_t)(__float_as_uint(mine) >> 16); sh_e[eidx][lane] = mine; }
       }
     }
-  }
   };
   for (int k = 0; k + 1 < n_chunks; ++k) {            // (rows of more than 64 in-edges only: these chunks are gathered again in pass 3)
     RawGroup<VEC4> tmp[GF_EW][NG];
@@ -466,7 +553,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_fwd(GatFused p) {
           if (HG || hd[c] >= 0) {
             const float cf = sh_e[eidx][HG ? c : hd[c]];
 #pragma unroll
-            for (int jj = 0; jj < W; ++jj) acc[c][jj] += cf * x[c][jj];
+            for (int jj = 0; jj < W; ++jj) acc[c][jj] = __builtin_fmaf(cf, x[c][jj], acc[c][jj]);   // (bf16 x bf16 is exact in fp32: == mul, add)
           }
         }
       }
@@ -525,7 +612,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   constexpr int W = VEC4 ? 4 : 1;
   constexpr int NG = HG ? HG : GF_ITER, NH = HG ? HG : GF_MAXH;
   __shared__ float sh_acc[GF_WAVES][NG * 64 * W], sh_acc2[GF_WAVES][NG * 64 * W];   // the waves' shares of d er_i / of d attn
-  __shared__ float sh_c[GF_SEG][GF_MAXH];                  // d a, then d e, of this workgroup's edges
+  __shared__ float sh_c[GF_MAXH][GF_SEG];                  // d a, then d e, of this workgroup's edges, head-major (pass 3 goes head by head)
   __shared__ float sh_t[GF_WAVES][GF_MAXH];
   __shared__ float sh_er[NG * 64 * W];                     // er_i (pass 3 reads it group by group)
   __shared__ int sh_last;
@@ -558,41 +645,65 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   // ---- pass 1: d a_ij[h] = g_i[h,:] . el_j[h,:] (bf16, like k_gat_edge_dot<1>), through the dropout mask; t[h] = sum a d a
   float tp = 0.f;                                        // lane h: head h's share of t over this wave's edges
   auto dalpha_of_chunk = [&](RawGroup<VEC4> (&raw)[GF_EW][NG], int k) {
-  const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
-  ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
+    const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
+    ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
+    // lane h < H: a / a_drop of head h of the wave's edges (the forward's outputs), in flight with the rows
+    bf16_t a_e[GF_EW], ad_e[GF_EW];
 #pragma unroll
-  for (int j = 0; j < GF_EW; ++j) {
-    if (j < n_mine) {
-      const int eidx = k * GF_CHUNK + j * GF_WAVES + wave;
-      float part[NH];
+    for (int j = 0; j < GF_EW; ++j) {
+      const bool on = j < n_mine && lane < H;
+      const long long o = on ? (long long)(beg + k * GF_CHUNK + j * GF_WAVES + wave) * H + lane : 0;
+      a_e[j] = p.a[o];
+      ad_e[j] = p.drop_thresh ? p.ad[o] : (bf16_t)0x3f80;
+    }
+    float mine[GF_EW];                                 // lane h: g_i[h,:] . el_j[h,:] of the wave's j-th edge
 #pragma unroll
-      for (int h = 0; h < NH; ++h) part[h] = 0.f;
+    for (int j = 0; j < GF_EW; ++j) mine[j] = 0.f;
+    if (HG) {
 #pragma unroll
       for (int c = 0; c < NG; ++c) {
-        if (HG || hd[c] >= 0) {
-          // g . el on the packed pairs (v_dot2_f32_bf16: exact products, fp32 accumulation)
-          float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.x), __builtin_bit_cast(bf16x2_t, raw[j][c].u.x), 0.f, false);
-          if (VEC4) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.y), __builtin_bit_cast(bf16x2_t, raw[j][c].u.y), v, false);
-          if (HG) part[c % NH] += v;
-          else {
 #pragma unroll
-            for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+        for (int j = 0; j < GF_EW; ++j) {
+          if (j < n_mine) {                            // (wave-uniform)
+            // g . el on the packed pairs (v_dot2_f32_bf16: exact products, fp32 accumulation)
+            float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.x), __builtin_bit_cast(bf16x2_t, raw[j][c].u.x), 0.f, false);
+            if (VEC4) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.y), __builtin_bit_cast(bf16x2_t, raw[j][c].u.y), v, false);
+            const float sum = wave_butterfly_sum(v);
+            mine[j] = lane == c ? sum : mine[j];
           }
         }
       }
-      wave_sum_heads<NH>(part, H);
-      if (lane < H) {                                  // lane h finishes head h of this edge
-        const long long o = (long long)(beg + eidx) * H + lane;
-        float pv = 0.f;
+    } else {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) if (h == lane) pv = part[h];
-        float da = rbf_hw(pv);
-        if (p.drop_thresh) da = (p.ad[o] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
-        sh_c[eidx][lane] = da;
-        tp += bf2f(p.a[o]) * da;
+      for (int j = 0; j < GF_EW; ++j) {
+        if (j < n_mine) {
+          float part[NH];
+#pragma unroll
+          for (int h = 0; h < NH; ++h) part[h] = 0.f;
+#pragma unroll
+          for (int c = 0; c < NG; ++c) {
+            if (hd[c] >= 0) {
+              float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.x), __builtin_bit_cast(bf16x2_t, raw[j][c].u.x), 0.f, false);
+              if (VEC4) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.y), __builtin_bit_cast(bf16x2_t, raw[j][c].u.y), v, false);
+#pragma unroll
+              for (int h = 0; h < NH; ++h) if (h == hd[c]) part[h] += v;
+            }
+          }
+          wave_sum_heads<NH>(part, H);
+#pragma unroll
+          for (int h = 0; h < NH; ++h) if (h == lane) mine[j] = part[h];
+        }
       }
     }
-  }
+#pragma unroll
+    for (int j = 0; j < GF_EW; ++j) {
+      if (j < n_mine && lane < H) {                    // lane h finishes head h of this edge
+        float da = rbf_hw(mine[j]);
+        if (p.drop_thresh) da = (ad_e[j] != 0) ? rbf_hw(da * p.drop_scale) : 0.f;   // dropout backward (mask = what the forward kept)
+        sh_c[lane][k * GF_CHUNK + j * GF_WAVES + wave] = da;
+        tp += bf2f(a_e[j]) * da;
+      }
+    }
   };
   for (int k = 0; k + 1 < n_chunks; ++k) {
     RawGroup<VEC4> tmp[GF_EW][NG];
@@ -629,9 +740,9 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
 #pragma unroll
     for (int w2 = 1; w2 < GF_WAVES; ++w2) t += sh_t[w2][h];
     const long long o = (long long)beg * H + i;
-    const bf16_t de = f2bf(bf2f(p.a[o]) * (sh_c[eidx][h] - t));
+    const bf16_t de = f2bf(bf2f(p.a[o]) * (sh_c[h][eidx] - t));
     p.de[o] = de;
-    sh_c[eidx][h] = bf2f(de);
+    sh_c[h][eidx] = bf2f(de);
   }
   __syncthreads();
   // ---- pass 3: d er_i = sum_j d e attn lrelu'(el_j + er_i);  d attn += d e lrelu(el_j + er_i)   (k_gat_rows<true, false>)
@@ -657,12 +768,12 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
               x[0] = __uint_as_float(raw[j][c].u.x << 16); x[1 % W] = __uint_as_float(raw[j][c].u.x & 0xffff0000u);
               x[2 % W] = __uint_as_float(raw[j][c].u.y << 16); x[3 % W] = __uint_as_float(raw[j][c].u.y & 0xffff0000u);
             } else x[0] = __uint_as_float(raw[j][c].u.x << 16);
-            const float cf = sh_c[k * GF_CHUNK + j * GF_WAVES + wave][HG ? c : hd[c]];
+            const float cf = sh_c[HG ? c : hd[c]][k * GF_CHUNK + j * GF_WAVES + wave];
 #pragma unroll
             for (int jj = 0; jj < W; ++jj) {
               const float sx = x[jj] + erc[jj];
-              da[jj] += cf * (sx > 0.f ? 1.f : p.slope);
-              aa[jj] += cf * lrelu_f(sx, p.slope);
+              da[jj] = __builtin_fmaf(cf, sx > 0.f ? 1.f : p.slope, da[jj]);
+              aa[jj] = __builtin_fmaf(cf, lrelu_f(sx, p.slope), aa[jj]);
             }
           }
         }
