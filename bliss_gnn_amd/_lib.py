@@ -179,7 +179,7 @@ SIGNATURES = {
     "bliss_sage_wgrad": [C.POINTER(WGrad), _I32, _P, _I64, _P],
     "bliss_gat_fused_supported": [_I32, _I32],
     "bliss_gat_segment_edges": [],
-    "bliss_gat_fused_stamps": [_P],
+    "bliss_gat_fused_stamps": [_P, _P],
     "bliss_gat_segments": [_P, _I32, _I32, _P, _P, _P, _P],
     "bliss_gat_fused_fwd": [C.POINTER(GatFused), _P],
     "bliss_gat_fused_bwd_dst": [C.POINTER(GatFused), _P, _P, _P, _P],

@@ -40,6 +40,17 @@ __device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max
 
 struct g4f { float v[4]; };
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two bf16 values at a time: unpack (2 ops), v_pk_add_f32 / v_pk_mul_f32 on the pair, ONE v_cvt_pk_bf16_f32 for both roundings
+__device__ __forceinline__ f32x2_t unpack2(unsigned u) { return f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+__device__ __forceinline__ unsigned round2(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
+// rbf(attn * rbf(lrelu(rbf(el + er)))) of a packed pair of el: the operations of k_gat_edge_dot<0>, element for element
+__device__ __forceinline__ f32x2_t logit_terms2(unsigned el2, f32x2_t er, f32x2_t at, float slope) {
+  const f32x2_t r = unpack2(round2(unpack2(el2) + er));
+  const f32x2_t l = unpack2(round2(r * f32x2_t{slope, slope}));
+  const f32x2_t sel = f32x2_t{r.x > 0.f ? r.x : l.x, r.y > 0.f ? r.y : l.y};
+  return unpack2(round2(sel * at));
+}
 template <bool VEC4>
 __device__ __forceinline__ g4f ldrow(const bf16_t* p) {            // W consecutive elements of a row as floats
   g4f r;
@@ -61,6 +72,7 @@ __device__ __forceinline__ uint32_t gf_drop_hash(uint32_t seed, uint32_t ctr, ui
 
 // phase stamps for scratch/gatbench.py (bliss_gat_fused_stamps): 8 x s_memrealtime (100 MHz) per virtual workgroup of the forward
 __device__ long long* g_gf_stamps = nullptr;
+__device__ long long* g_gf_stamps_bwd = nullptr;
 #define GF_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(long long)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
 struct GatFused {
@@ -75,7 +87,7 @@ struct GatFused {
   bf16_t* d_er; long long der_stride;                  // [n_dst, H*D] out
   float* dattn_part;                                   // [n_wg, H*D] out: this workgroup's share of d attn
   // heavy rows: a destination with more than GF_SEG in-edges is shared by several workgroups (segments of GF_SEG edges)
-  const int* wg_row; const int* n_wg_dev;              // virtual workgroup -> row (k_gat_segments); how many there are
+  const int4* wg_row; const int* n_wg_dev;             // virtual workgroup -> (row, first edge, end, G << 16 | segment): k_gat_segments; how many
   unsigned* rowws;                                     // [n_dst, GF_ROWWS] zero-initialised, self-cleaning: arrive counters, max, sum
   float* seg_part;                                     // [n_wg, H*D] partial rows of the segments; [n_wg, GF_MAXH] behind it for t
   int* err;
@@ -223,7 +235,12 @@ __device__ __forceinline__ bool row_last(unsigned* ws, int G, int* sh_flag) {
 // rows 1024 at a time, twice.
 #define GF_SEG_R 16                     // rows per thread of the one-sweep path
 __device__ __forceinline__ int gf_row_wgs(int deg) { return deg > GF_SEG ? (deg + GF_SEG - 1) / GF_SEG : 1; }
-__global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ indptr, int n_dst, int cap_wg, int* __restrict__ wg_row,
+// what one virtual workgroup needs to know, in ONE 16-byte load: its row, its edge range, how many workgroups share the row
+__device__ __forceinline__ int4 gf_desc(int row, int rbeg, int rend, int G, int seg_i) {
+  const int beg = rbeg + seg_i * GF_SEG;
+  return make_int4(row, beg, G > 1 ? min(rend, beg + GF_SEG) : rend, (G << 16) | seg_i);
+}
+__global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ indptr, int n_dst, int cap_wg, int4* __restrict__ wg_row,
                                                         int* __restrict__ n_wg_dev, int* err) {
   __shared__ int sh[17];
   int run = 0;
@@ -247,8 +264,8 @@ __global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ i
     for (int i = 0; i < GF_SEG_R; ++i) {
       if (i < R && r0 + i < n_dst) {
         const int g = gf_row_wgs(ip[i + 1] - ip[i]);
-        if (g > 1) { for (int q = 0; q < g; ++q) if (at_sh + q < cap_wg) wg_row[at_sh + q] = r0 + i; at_sh += g; }
-        else { if (at_1 < cap_wg) wg_row[at_1] = r0 + i; ++at_1; }
+        if (g > 1) { for (int q = 0; q < g; ++q) if (at_sh + q < cap_wg) wg_row[at_sh + q] = gf_desc(r0 + i, ip[i], ip[i + 1], g, q); at_sh += g; }
+        else { if (at_1 < cap_wg) wg_row[at_1] = gf_desc(r0 + i, ip[i], ip[i + 1], 1, 0); ++at_1; }
       }
     }
     run = tot_sh + tot_1;
@@ -256,13 +273,14 @@ __global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ i
     for (int pass = 0; pass < 2; ++pass) {
       for (int base = 0; base < n_dst; base += 1024) {
         const int r = base + threadIdx.x;
-        int g = 0;
+        int g = 0, b0 = 0, b1 = 0;
         if (r < n_dst) {
-          g = gf_row_wgs(indptr[r + 1] - indptr[r]);
+          b0 = indptr[r]; b1 = indptr[r + 1];
+          g = gf_row_wgs(b1 - b0);
           if ((g > 1) != (pass == 0)) g = 0;
         }
         int tot, ex = block_excl_scan(g, sh, &tot);
-        for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = r;
+        for (int i = 0; i < g; ++i) if (run + ex + i < cap_wg) wg_row[run + ex + i] = gf_desc(r, b0, b1, g, i);
         run += tot;
         __syncthreads();
       }
@@ -299,18 +317,9 @@ __device__ __forceinline__ void wave_sum_heads(float (&part)[NH], int H) {
 // this workgroup's share of its destination row: all of it (G == 1: at most GF_SEG edges) or segment seg_i of G
 struct RowSeg { int row, beg, end, G, seg_i; };
 __device__ __forceinline__ RowSeg row_segment(const GatFused& p, int vwg) {
+  const int4 d = p.wg_row[vwg];
   RowSeg r;
-  r.row = p.wg_row[vwg];
-  const int rbeg = p.indptr[r.row], rend = p.indptr[r.row + 1];
-  r.G = rend - rbeg > GF_SEG ? (rend - rbeg + GF_SEG - 1) / GF_SEG : 1;
-  r.seg_i = 0;
-  if (r.G > 1) {                                       // segment index = distance to the row's first virtual workgroup
-    int first = vwg;
-    while (first > 0 && p.wg_row[first - 1] == r.row) --first;
-    r.seg_i = vwg - first;
-  }
-  r.beg = rbeg + r.seg_i * GF_SEG;
-  r.end = r.G > 1 ? min(rend, r.beg + GF_SEG) : rend;
+  r.row = d.x; r.beg = d.y; r.end = d.z; r.G = d.w >> 16; r.seg_i = d.w & 0xffff;
   return r;
 }
 
@@ -397,21 +406,26 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_fwd(GatFused p) {
         float erc[W], atc[W];
 #pragma unroll
         for (int jj = 0; jj < W; ++jj) { erc[jj] = sh_er[c * 64 * W + lane * W + jj]; atc[jj] = sh_at[c * 64 * W + lane * W + jj]; }
+        // (two edges per wave-uniform branch: their butterflies interleave and fill each other's DPP wait states; the odd slot
+        // beyond the wave's share works on the re-read last row, its result is dropped)
 #pragma unroll
-        for (int j = 0; j < GF_EW; ++j) {
-          if (j < n_mine) {                           // (wave-uniform)
-            float x[W];
-            if (VEC4) {
-              x[0] = __uint_as_float(raw[j][c].u.x << 16); x[1 % W] = __uint_as_float(raw[j][c].u.x & 0xffff0000u);
-              x[2 % W] = __uint_as_float(raw[j][c].u.y << 16); x[3 % W] = __uint_as_float(raw[j][c].u.y & 0xffff0000u);
-            } else x[0] = __uint_as_float(raw[j][c].u.x << 16);
-            float v = 0.f, part = 0.f;
+        for (int j2 = 0; j2 < GF_EW; j2 += 2) {
+          if (j2 < n_mine) {                          // (wave-uniform)
+            float eb[2];
 #pragma unroll
-            for (int jj = 0; jj < W; ++jj) v += rbf_hw(atc[jj] * rbf_hw(lrelu_f(rbf_hw(x[jj] + erc[jj]), p.slope)));
-            part += v;
-            const float eb = rbf_hw(wave_butterfly_sum(part));
-            mine[j] = lane == c ? eb : mine[j];
-            mx[c % NH] = max_raw(mx[c % NH], eb);
+            for (int q = 0; q < 2; ++q) {
+              const int j = j2 + q;
+              float v = 0.f, part = 0.f;
+              if (VEC4) {
+                const f32x2_t t0 = logit_terms2(raw[j][c].u.x, f32x2_t{erc[0], erc[1 % W]}, f32x2_t{atc[0], atc[1 % W]}, p.slope);
+                const f32x2_t t1 = logit_terms2(raw[j][c].u.y, f32x2_t{erc[2 % W], erc[3 % W]}, f32x2_t{atc[2 % W], atc[3 % W]}, p.slope);
+                v += t0.x; v += t0.y; v += t1.x; v += t1.y;
+              } else v += rbf_hw(atc[0] * rbf_hw(lrelu_f(rbf_hw(__uint_as_float(raw[j][c].u.x << 16) + erc[0]), p.slope)));
+              part += v;
+              eb[q] = rbf_hw(wave_butterfly_sum(part));
+              mine[j] = lane == c ? eb[q] : mine[j];
+            }
+            mx[c % NH] = max_raw(mx[c % NH], max_raw(eb[0], j2 + 1 < n_mine ? eb[1] : eb[0]));
           }
         }
       }
@@ -618,12 +632,15 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   __shared__ int sh_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int vwg = blockIdx.x;
+  long long* stamps = g_gf_stamps_bwd;
+  GF_STAMP(0);
   if (vwg >= *p.n_wg_dev) return;
   int S = p.n_dst;
   if (p.n_dst_dev) { const int t = *p.n_dst_dev; S = t < S ? t : S; }
   const int H = HG ? HG : p.H, D = p.D, HD = H * D;
   const RowSeg rs = row_segment(p, vwg);
   const int row = rs.row, beg = rs.beg, end = rs.end, G = rs.G, seg_i = rs.seg_i;
+  GF_STAMP(1);
   if (row >= S) {
     for (int c = tid; c < HD; c += GF_TPB) { p.d_er[(long long)row * p.der_stride + c] = 0; p.dattn_part[(long long)vwg * HD + c] = 0.f; }
     return;
@@ -647,15 +664,6 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   auto dalpha_of_chunk = [&](RawGroup<VEC4> (&raw)[GF_EW][NG], int k) {
     const int n_mine = wave_edges_in_chunk(n_edges, k, wave);
     ld_wave_rows<VEC4, NG>(raw, p.feat, p.feat_stride, my_s, k * GF_EW, n_mine, coff);
-    // lane h < H: a / a_drop of head h of the wave's edges (the forward's outputs), in flight with the rows
-    bf16_t a_e[GF_EW], ad_e[GF_EW];
-#pragma unroll
-    for (int j = 0; j < GF_EW; ++j) {
-      const bool on = j < n_mine && lane < H;
-      const long long o = on ? (long long)(beg + k * GF_CHUNK + j * GF_WAVES + wave) * H + lane : 0;
-      a_e[j] = p.a[o];
-      ad_e[j] = p.drop_thresh ? p.ad[o] : (bf16_t)0x3f80;
-    }
     float mine[GF_EW];                                 // lane h: g_i[h,:] . el_j[h,:] of the wave's j-th edge
 #pragma unroll
     for (int j = 0; j < GF_EW; ++j) mine[j] = 0.f;
@@ -663,13 +671,17 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
 #pragma unroll
       for (int c = 0; c < NG; ++c) {
 #pragma unroll
-        for (int j = 0; j < GF_EW; ++j) {
-          if (j < n_mine) {                            // (wave-uniform)
-            // g . el on the packed pairs (v_dot2_f32_bf16: exact products, fp32 accumulation)
-            float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.x), __builtin_bit_cast(bf16x2_t, raw[j][c].u.x), 0.f, false);
-            if (VEC4) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.y), __builtin_bit_cast(bf16x2_t, raw[j][c].u.y), v, false);
-            const float sum = wave_butterfly_sum(v);
-            mine[j] = lane == c ? sum : mine[j];
+        for (int j2 = 0; j2 < GF_EW; j2 += 2) {
+          if (j2 < n_mine) {                           // (wave-uniform; two edges per branch: see the forward)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int j = j2 + q;
+              // g . el on the packed pairs (v_dot2_f32_bf16: exact products, fp32 accumulation)
+              float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.x), __builtin_bit_cast(bf16x2_t, raw[j][c].u.x), 0.f, false);
+              if (VEC4) v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, graw[c].u.y), __builtin_bit_cast(bf16x2_t, raw[j][c].u.y), v, false);
+              const float sum = wave_butterfly_sum(v);
+              mine[j] = lane == c ? sum : mine[j];
+            }
           }
         }
       }
@@ -695,6 +707,15 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
         }
       }
     }
+    // lane h < H: a / a_drop of head h of the wave's edges (the forward's outputs)
+    bf16_t a_e[GF_EW], ad_e[GF_EW];
+#pragma unroll
+    for (int j = 0; j < GF_EW; ++j) {
+      const bool on = j < n_mine && lane < H;
+      const long long o = on ? (long long)(beg + k * GF_CHUNK + j * GF_WAVES + wave) * H + lane : 0;
+      a_e[j] = p.a[o];
+      ad_e[j] = p.drop_thresh ? p.ad[o] : (bf16_t)0x3f80;
+    }
 #pragma unroll
     for (int j = 0; j < GF_EW; ++j) {
       if (j < n_mine && lane < H) {                    // lane h finishes head h of this edge
@@ -712,7 +733,9 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
   RawGroup<VEC4> raw[GF_EW][NG];
   if (n_chunks > 0) dalpha_of_chunk(raw, n_chunks - 1);
   if (lane < NH) sh_t[wave][lane] = tp;
+  GF_STAMP(2);
   __syncthreads();
+  GF_STAMP(3);
   if (G > 1) {                                         // t over the whole row: the segments' totals added in segment order
     float* tseg = p.seg_part + (long long)(*p.n_wg_dev) * HD;         // [n_wg, GF_MAXH] behind the partial rows
     if (tid < H) {
@@ -732,6 +755,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     }
     __syncthreads();
   }
+  GF_STAMP(4);
   // ---- pass 2: d e = a (d a - t)   (k_gat_softmax<true>); the by-source kernel reads it from memory, pass 3 from LDS
   const int cnt = (end - beg) * H;
   for (int i = tid; i < cnt; i += GF_TPB) {
@@ -745,6 +769,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     sh_c[h][eidx] = bf2f(de);
   }
   __syncthreads();
+  GF_STAMP(5);
   // ---- pass 3: d er_i = sum_j d e attn lrelu'(el_j + er_i);  d attn += d e lrelu(el_j + er_i)   (k_gat_rows<true, false>)
   // Chunk by chunk (the last one first: its rows are still in registers), column group by column group: one group's accumulators and
   // er_i beside the packed rows keep the kernel under 128 registers; a wave adds each chunk's share to its own slice in LDS
@@ -768,12 +793,14 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
               x[0] = __uint_as_float(raw[j][c].u.x << 16); x[1 % W] = __uint_as_float(raw[j][c].u.x & 0xffff0000u);
               x[2 % W] = __uint_as_float(raw[j][c].u.y << 16); x[3 % W] = __uint_as_float(raw[j][c].u.y & 0xffff0000u);
             } else x[0] = __uint_as_float(raw[j][c].u.x << 16);
-            const float cf = sh_c[HG ? c : hd[c]][k * GF_CHUNK + j * GF_WAVES + wave];
+            // d e times lrelu'(sx) is one of two per-edge values; lrelu(sx) = sx lrelu'(sx): add, compare, select, add, fma
+            const float cf = sh_c[HG ? c : hd[c]][k * GF_CHUNK + j * GF_WAVES + wave], cfs = cf * p.slope;
 #pragma unroll
             for (int jj = 0; jj < W; ++jj) {
               const float sx = x[jj] + erc[jj];
-              da[jj] = __builtin_fmaf(cf, sx > 0.f ? 1.f : p.slope, da[jj]);
-              aa[jj] = __builtin_fmaf(cf, lrelu_f(sx, p.slope), aa[jj]);
+              const float t = sx > 0.f ? cf : cfs;
+              da[jj] += t;
+              aa[jj] = __builtin_fmaf(t, sx, aa[jj]);
             }
           }
         }
@@ -789,6 +816,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     rows_of_chunk(tmp, k);
   }
   __syncthreads();
+  GF_STAMP(6);
   for (int col = tid; col < HD; col += GF_TPB) {       // the waves' shares in wave order; d er carries attn as a common factor
     float s = sh_acc[0][col], s2 = sh_acc2[0][col];
 #pragma unroll
@@ -807,6 +835,7 @@ __global__ void __launch_bounds__(GF_TPB, 4) k_gat_bwd_dst(GatFused p) {
     }
     for (int i = tid; i < GF_ROWWS; i += GF_TPB) ws[i] = 0u;
   }
+  GF_STAMP(7);
 }
 
 // d attn[col] = sum over the destination rows of their shares, in a fixed order (deterministic, no float atomics): stage 1 sums
@@ -857,7 +886,7 @@ bool gf_fill(const bliss_gat_fused_t* a, GatFused* p, bool* vec4) {
   p->seed = a->drop_seed; p->ctr = (unsigned long long*)a->drop_ctr; p->ctr_used = (unsigned*)a->drop_ctr_used;
   p->g = (const bf16_t*)a->g; p->g_stride = a->g_stride; p->de = (bf16_t*)a->de;
   p->d_er = (bf16_t*)a->d_er; p->der_stride = a->d_er_stride; p->dattn_part = a->dattn_part;
-  p->wg_row = a->wg_row; p->n_wg_dev = a->n_wg_dev; p->rowws = (unsigned*)a->row_ws; p->seg_part = a->seg_part; p->err = a->err;
+  p->wg_row = reinterpret_cast<const int4*>(a->wg_row); p->n_wg_dev = a->n_wg_dev; p->rowws = (unsigned*)a->row_ws; p->seg_part = a->seg_part; p->err = a->err;
   if (!a->wg_row || !a->n_wg_dev || !a->row_ws || !a->seg_part || a->cap_wg < a->n_dst) return false;
   *vec4 = v4;
   return true;
@@ -874,13 +903,14 @@ int bliss_gat_fused_supported(int32_t heads, int32_t head_dim) {
 
 int bliss_gat_segment_edges(void) { return GF_SEG; }
 
-int bliss_gat_fused_stamps(long long* stamps) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gf_stamps), &stamps, sizeof(stamps));
+int bliss_gat_fused_stamps(long long* stamps, long long* stamps_bwd) {
+  const int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gf_stamps), &stamps, sizeof(stamps));
+  return rc ? rc : (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gf_stamps_bwd), &stamps_bwd, sizeof(stamps_bwd));
 }
 
 int bliss_gat_segments(const int32_t* indptr, int32_t n_dst, int32_t cap_wg, int32_t* wg_row, int32_t* n_wg_dev, int32_t* err, void* stream) {
   if (!indptr || !wg_row || !n_wg_dev || n_dst <= 0 || cap_wg < n_dst) return BLISS_EINVAL;
-  k_gat_segments<<<1, 1024, 0, (hipStream_t)stream>>>(indptr, n_dst, cap_wg, wg_row, n_wg_dev, err);
+  k_gat_segments<<<1, 1024, 0, (hipStream_t)stream>>>(indptr, n_dst, cap_wg, reinterpret_cast<int4*>(wg_row), n_wg_dev, err);
   return (int)hipGetLastError();
 }
 

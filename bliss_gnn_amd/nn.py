@@ -659,14 +659,14 @@ class _GatAggregate(torch.autograd.Function):
 
 
 def _gat_segments(block, S, B, state):
-    """wg_row int32 [cap_wg], n_wg int32 [1] for ``block`` (bliss_gat_segments) and the per-row words the sharing workgroups
+    """wg_row int32 [cap_wg, 4] (one descriptor per virtual workgroup), n_wg int32 [1] for ``block`` (bliss_gat_segments) and the per-row words the sharing workgroups
     meet on (zero-initialised once per layer and size; the kernels return them to zero)."""
     import ctypes as C
     dev = block.indptr.device
     cap_wg = S + B // int(_lib.lib.bliss_gat_segment_edges()) + 1
     if state["row_ws"] is None or state["row_ws"].numel() < S * 32:
         state["row_ws"] = torch.zeros(max(S, 1) * 32, dtype=torch.int32, device=dev)
-    wg_row = torch.empty(cap_wg, dtype=torch.int32, device=dev)
+    wg_row = torch.empty(cap_wg, 4, dtype=torch.int32, device=dev)
     n_wg = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib.bliss_gat_segments(block.indptr.data_ptr(), S, cap_wg, wg_row.data_ptr(), n_wg.data_ptr(), state["err"].data_ptr(),
                                            _stream()), "bliss_gat_segments")

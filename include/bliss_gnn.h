@@ -507,20 +507,21 @@ typedef struct {
   void* rst; int64_t rst_stride;
   float drop_p; uint32_t drop_seed; void* drop_ctr; void* drop_ctr_used;
   const void* g; int64_t g_stride; void* de; void* d_er; int64_t d_er_stride; float* dattn_part;
-  /* heavy rows (optional; all NULL / 0 = one workgroup per row): a destination with more than bliss_gat_segment_edges()
-   * in-edges is shared by several workgroups.  wg_row [cap_wg] + n_wg_dev from bliss_gat_segments; row_ws uint32 [n_dst * 32],
+  /* virtual workgroups (required): a destination with more than bliss_gat_segment_edges() in-edges is shared by several
+   * workgroups.  wg_row int32 [cap_wg, 4], 16-byte aligned (row, first edge, end, G << 16 | segment per virtual workgroup; the
+   * shared rows first) + n_wg_dev from bliss_gat_segments; row_ws uint32 [n_dst * 32],
    * zero-initialised once (the kernels return it to zero); seg_part float [cap_wg * (heads*head_dim + 8)] scratch; dattn_part
    * then holds cap_wg rows and block_sums ceil(cap_wg / 32) rows; err receives BLISS_ERR_FLAG_TIMEOUT if a row's workgroups
    * fail to meet. */
   const int32_t* wg_row; const int32_t* n_wg_dev; int32_t cap_wg; void* row_ws; float* seg_part; int32_t* err;
 } bliss_gat_fused_t;
 int bliss_gat_segment_edges(void);
-/* measurement hook (scratch/gatbench.py): while `stamps` is not NULL every virtual workgroup of bliss_gat_fused_fwd writes eight
- * 100 MHz device timestamps (start, row resolved, pass 1 done, after its barrier, after the max exchange, pass 2 done, pass 3
- * done, end) to stamps[8 * workgroup ..]; NULL switches it off again.  Not part of the data path. */
-int bliss_gat_fused_stamps(long long* stamps);
-/* virtual workgroup -> destination row for the two kernels below: row r gets max(1, ceil(deg_r / bliss_gat_segment_edges()))
- * consecutive ids; cap_wg >= n_dst + nnz_bound / bliss_gat_segment_edges() suffices. */
+/* measurement hook (scratch/gatbench.py): while `stamps` / `stamps_bwd` is not NULL every virtual workgroup of bliss_gat_fused_fwd /
+ * bliss_gat_fused_bwd_dst writes eight 100 MHz device timestamps (start, row resolved, pass 1 done, after its barrier, after the
+ * exchange, pass 2 done, pass 3 done, end) to stamps[8 * workgroup ..]; NULL switches it off again.  Not part of the data path. */
+int bliss_gat_fused_stamps(long long* stamps, long long* stamps_bwd);
+/* the virtual workgroups' descriptors for the two kernels below: row r gets max(1, ceil(deg_r / bliss_gat_segment_edges()))
+ * consecutive ids; cap_wg >= n_dst + nnz_bound / bliss_gat_segment_edges() suffices; wg_row holds 4 * cap_wg int32. */
 int bliss_gat_segments(const int32_t* indptr, int32_t n_dst, int32_t cap_wg, int32_t* wg_row, int32_t* n_wg_dev, int32_t* err, void* stream);
 int bliss_gat_fused_supported(int32_t heads, int32_t head_dim);
 /* d el[j, :] = sum over the out-edges e = (j -> i) of  de[e, h] attn lrelu'(feat[j] + feat[i])  +  a_drop[e, h] g[i, :]  -- the

@@ -49,29 +49,28 @@ for li, blk in enumerate(blocks[:2]):
             rst, e = _GatFusedMP.apply(feat, attn, blk, H, D, 0.2, p, st)
             rst.backward(gout)
         print(f"  fused fwd+bwd  p={p}: {timeit(fb):8.1f} us")
-    # where a workgroup's time goes: the forward's phase stamps (100 MHz), one launch
-    import ctypes as C
+    # where a workgroup's time goes: the kernels' phase stamps (100 MHz), one launch each
     from bliss_gnn_amd import _lib
     seg = _lib.lib.bliss_gat_segment_edges()
     cap = S + B // seg + 8
-    stamps = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
-    _lib.check(_lib.lib.bliss_gat_fused_stamps(stamps.data_ptr()), "stamps")
-    with torch.no_grad():
-        _GatFusedMP.apply(feat.detach(), attn.detach(), blk, H, D, 0.2, 0.0, st)
+    st_f = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
+    st_b = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib.bliss_gat_fused_stamps(st_f.data_ptr(), st_b.data_ptr()), "stamps")
+    feat.grad = attn.grad = None
+    rst, e = _GatFusedMP.apply(feat, attn, blk, H, D, 0.2, 0.0, st)
+    rst.backward(gout)
     torch.cuda.synchronize()
-    _lib.check(_lib.lib.bliss_gat_fused_stamps(None), "stamps")
-    t = stamps.view(cap, 8).cpu().double()
-    live = t[:, 7] > 0
-    t = t[live]
-    g_of_row = torch.clamp((deg.cpu() + seg - 1) // seg, min=1)
-    shared = torch.repeat_interleave(g_of_row > 1, g_of_row)[: t.shape[0]]
-    names = ["row resolved", "pass 1 (gathers + logits)", "barrier", "max exchange", "pass 2 (softmax)", "pass 3 (aggregate)", "reduce + store"]
-    print(f"  forward: {t.shape[0]} workgroups ({int(shared.sum())} on shared rows), launch span {(t[:, 7].max() - t[:, 0].min()) / 100:.1f} us, "
-          f"workgroup life mean {((t[:, 7] - t[:, 0]).mean()) / 100:.2f} us")
-    for nm, sel in (("own row", ~shared), ("shared row", shared)):
-        if sel.any():
-            d = (t[sel, 1:] - t[sel, :-1]) / 100
-            print(f"    {nm:10s} " + "; ".join(f"{n} {d[:, i].mean():.2f}" for i, n in enumerate(names)) + f"; total {d.sum(1).mean():.2f} us")
+    _lib.check(_lib.lib.bliss_gat_fused_stamps(None, None), "stamps")
+    for what, stamps, names in (("forward", st_f, ["row resolved", "pass 1 (gathers + logits)", "barrier", "max exchange", "pass 2 (softmax)",
+                                                     "pass 3 (aggregate)", "reduce + store"]),
+                                ("backward by destination", st_b, ["row resolved", "pass 1 (gathers + d a)", "barrier", "t exchange",
+                                                                     "pass 2 (d e)", "pass 3 (d er, d attn)", "reduce + store"])):
+        t = stamps.view(cap, 8).cpu().double()
+        t = t[t[:, 7] > 0]
+        d = (t[:, 1:] - t[:, :-1]) / 100
+        print(f"  {what}: {t.shape[0]} workgroups, launch span {(t[:, 7].max() - t[:, 0].min()) / 100:.1f} us, workgroup life mean "
+              f"{d.sum(1).mean():.2f} us, max {d.sum(1).max():.1f} us")
+        print("    " + "; ".join(f"{n} {d[:, i].mean():.2f}" for i, n in enumerate(names)))
     def ufwd():
         with torch.no_grad():
             e = _GatLogits.apply(feat.detach(), attn.detach(), blk, H, D, 0.2)
