@@ -251,24 +251,42 @@ __global__ void __launch_bounds__(1024) k_gat_segments(const int* __restrict__ i
     int ip[GF_SEG_R + 1];
 #pragma unroll
     for (int i = 0; i <= GF_SEG_R; ++i) ip[i] = (i <= R && r0 + i <= n_dst) ? indptr[r0 + i] : 0;
-    int n_sh = 0, n_1 = 0;
-#pragma unroll
-    for (int i = 0; i < GF_SEG_R; ++i) {
-      if (i < R && r0 + i < n_dst) { const int g = gf_row_wgs(ip[i + 1] - ip[i]); if (g > 1) n_sh += g; else ++n_1; }
-    }
-    int tot_sh, tot_1;
-    int at_sh = block_excl_scan(n_sh, sh, &tot_sh);
-    __syncthreads();
-    int at_1 = tot_sh + block_excl_scan(n_1, sh, &tot_1);
+    // longest first: the shared rows, then the rows of 4, 3, 2 chunks, then the single-chunk ones (a workgroup's life is
+    // ~10 us per chunk; the dispatcher hands ids out in order, so the long ones must not be the last to start)
+    int n_sh = 0, n_43 = 0, n_21 = 0;                  // (two 16-bit counts per word: at most 16384 rows)
 #pragma unroll
     for (int i = 0; i < GF_SEG_R; ++i) {
       if (i < R && r0 + i < n_dst) {
-        const int g = gf_row_wgs(ip[i + 1] - ip[i]);
-        if (g > 1) { for (int q = 0; q < g; ++q) if (at_sh + q < cap_wg) wg_row[at_sh + q] = gf_desc(r0 + i, ip[i], ip[i + 1], g, q); at_sh += g; }
-        else { if (at_1 < cap_wg) wg_row[at_1] = gf_desc(r0 + i, ip[i], ip[i + 1], 1, 0); ++at_1; }
+        const int deg = ip[i + 1] - ip[i], g = gf_row_wgs(deg), ch = (deg + GF_CHUNK - 1) / GF_CHUNK;
+        if (g > 1) n_sh += g;
+        else if (ch >= 4) n_43 += 1 << 16;
+        else if (ch == 3) n_43 += 1;
+        else if (ch == 2) n_21 += 1 << 16;
+        else n_21 += 1;
       }
     }
-    run = tot_sh + tot_1;
+    int tot_sh, tot_43, tot_21;
+    int at_sh = block_excl_scan(n_sh, sh, &tot_sh);
+    __syncthreads();
+    const int ex_43 = block_excl_scan(n_43, sh, &tot_43);
+    __syncthreads();
+    const int ex_21 = block_excl_scan(n_21, sh, &tot_21);
+    const int c4 = tot_43 >> 16, c3 = tot_43 & 0xffff, c2 = tot_21 >> 16, c1 = tot_21 & 0xffff;
+    int at_4 = tot_sh + (ex_43 >> 16), at_3 = tot_sh + c4 + (ex_43 & 0xffff);
+    int at_2 = tot_sh + c4 + c3 + (ex_21 >> 16), at_1 = tot_sh + c4 + c3 + c2 + (ex_21 & 0xffff);
+#pragma unroll
+    for (int i = 0; i < GF_SEG_R; ++i) {
+      if (i < R && r0 + i < n_dst) {
+        const int deg = ip[i + 1] - ip[i], g = gf_row_wgs(deg), ch = (deg + GF_CHUNK - 1) / GF_CHUNK;
+        if (g > 1) { for (int q = 0; q < g; ++q) if (at_sh + q < cap_wg) wg_row[at_sh + q] = gf_desc(r0 + i, ip[i], ip[i + 1], g, q); at_sh += g; }
+        else {
+          int& at = ch >= 4 ? at_4 : ch == 3 ? at_3 : ch == 2 ? at_2 : at_1;
+          if (at < cap_wg) wg_row[at] = gf_desc(r0 + i, ip[i], ip[i + 1], 1, 0);
+          ++at;
+        }
+      }
+    }
+    run = tot_sh + c4 + c3 + c2 + c1;
   } else {
     for (int pass = 0; pass < 2; ++pass) {
       for (int base = 0; base < n_dst; base += 1024) {
