@@ -1,0 +1,253 @@
+// The STATIC-SHAPE sharded sampler's own kernels (bliss_gnn_amd/shard_static.py).
+//
+// bliss_gnn_amd/shard.py routes (source, partial sum) pairs to the sources' owners, all-reduces a histogram and all-gathers the
+// kept lists: three exchanges per layer whose sizes are data-dependent, hence a host sync each.  Here every exchange is DENSE:
+// a rank scatters the exact Q.44 partial sums of compute_prob's by-source reduction (bandit_sampler.py:67-75) over its own
+// seeds' columns into an int64 [2, |V|] buffer (sum, touch / seed mark), ONE all-reduce gives every rank every source's sum
+// (integer addition: the bits do not depend on the reduction order or on the number of shards), and every rank then derives the
+// SAME candidate list (ascending node id: the sharded mode's order, shard.py), importances, histogram, Poisson scale, keyed draw
+// and kept list with no further collective.  Every size stays on the device; the whole layer records into a HIP graph.
+//
+//   bliss_shard_local_seeds       the global seed list -> the seeds this rank owns (order kept) and their positions
+//   bliss_shard_scatter_partials  (seed, partial) + (touched source, partial) of bliss_frontier_prob(BLISS_MODE_PARTIALS) -> dense
+//   bliss_shard_candidates        dense -> candidates in node order, p_j = sqrt(bf16(sum)) (:75), histogram of p's bit patterns
+//   bliss_shard_select_kept       P_j, the keyed Poisson draw (:403-406, :422-424), kept list = seeds ++ drawn non-seeds, dense map
+#include "common.cuh"
+#include "bliss_gnn.h"
+
+namespace {
+
+#define SD_TPB 1024
+#define SD_SEED_MARK (1ll << 32)
+
+// ---- seeds of this rank ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SD_TPB) k_sd_local_seeds(const int* __restrict__ seeds_g, int n_seeds, const int* __restrict__ n_seeds_dev,
+                                                           int lo, int hi, int cap_s, int* __restrict__ seeds_l, int* __restrict__ seeds_l2,
+                                                           int* __restrict__ seed_pos, int* __restrict__ n_local_dev, int* err) {
+  __shared__ int sh[17];
+  int S = n_seeds >= 0 ? n_seeds : *n_seeds_dev;
+  if (S > cap_s) { if (threadIdx.x == 0 && err) atomicOr(err, BLISS_ERR_CAP_SEEDS); S = cap_s; }
+  int run = 0;
+  for (int base = 0; base < S; base += SD_TPB) {
+    const int i = base + threadIdx.x;
+    const int v = i < S ? seeds_g[i] : -1;
+    const int mine = (v >= lo && v < hi) ? 1 : 0;
+    int tot, ex = block_excl_scan(mine, sh, &tot);
+    if (mine) { seeds_l[run + ex] = v; if (seeds_l2) seeds_l2[run + ex] = v; seed_pos[run + ex] = i; }
+    run += tot;
+    __syncthreads();
+  }
+  // (positions beyond the count stay valid indices: consumers gather through seed_pos at capacity)
+  for (int i = run + threadIdx.x; i < cap_s; i += SD_TPB) seed_pos[i] = 0;
+  if (threadIdx.x == 0) *n_local_dev = run;
+}
+
+// ---- partial sums -> dense ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sd_scatter(const int* __restrict__ seeds_l, const long long* __restrict__ seed_p2,
+                                                    const int* __restrict__ n_local_dev, const unsigned long long* __restrict__ tkey,
+                                                    const long long* __restrict__ tsum, const int* __restrict__ n_touched_dev,
+                                                    long long* __restrict__ dense, int V, int* err) {
+  const int n_local = *n_local_dev, n_t = *n_touched_dev;
+  const int stride = gridDim.x * 256;
+  int bad = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_local + n_t; i += stride) {
+    int v; long long s, mark;
+    if (i < n_local) { v = seeds_l[i]; s = seed_p2[i]; mark = SD_SEED_MARK + 1; }     // a seed is a candidate whatever its sum (shard.py)
+    else { v = (int)(tkey[i - n_local] & 0xffffffffull); s = tsum[i - n_local]; mark = 1; }
+    if (v < 0 || v >= V) { bad = BLISS_ERR_CAP_CAND; continue; }
+    dense[v] = s;                                       // (one writer per node on a rank: local seeds and touched sources are disjoint)
+    dense[(long long)V + v] = mark;
+  }
+  if (bad && err) atomicOr(err, bad);
+}
+
+// ---- ordered compaction, three launches: per-block counts, their scan, the writes ----------------------------------------------
+template <class Pred>
+__device__ __forceinline__ void sd_block_count(int n, int* __restrict__ block_cnt, Pred pred) {
+  const int i = blockIdx.x * SD_TPB + threadIdx.x;
+  const int c = __syncthreads_count(i < n && pred(i));
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = c;
+}
+
+// exclusive scan of the n_blocks counts in place; the total goes to *total
+__global__ void __launch_bounds__(SD_TPB) k_sd_scan(int* __restrict__ block_cnt, int n_blocks, int* __restrict__ total) {
+  __shared__ int sh[17];
+  int run = 0;
+  for (int base = 0; base < n_blocks; base += SD_TPB) {
+    const int i = base + threadIdx.x;
+    const int c = i < n_blocks ? block_cnt[i] : 0;
+    int tot, ex = block_excl_scan(c, sh, &tot);
+    if (i < n_blocks) block_cnt[i] = run + ex;
+    run += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = run;
+}
+
+__global__ void __launch_bounds__(SD_TPB) k_sd_cand_count(const long long* __restrict__ dense, int V, int* __restrict__ block_cnt) {
+  sd_block_count(V, block_cnt, [&](int v) { return dense[(long long)V + v] != 0; });
+}
+
+__global__ void __launch_bounds__(SD_TPB) k_sd_cand_write(const long long* __restrict__ dense, int V, int uniform_nodes,
+                                                          const int* __restrict__ block_off, const int* __restrict__ total,
+                                                          int* __restrict__ cand_nid, bf16_t* __restrict__ p, unsigned char* __restrict__ is_seed,
+                                                          int* __restrict__ hist, LayerCounts* cnt, int cap_c, int* err) {
+  __shared__ int sh[17];
+  const int v = blockIdx.x * SD_TPB + threadIdx.x;
+  const long long mark = v < V ? dense[(long long)V + v] : 0;
+  int tot, ex = block_excl_scan(mark != 0 ? 1 : 0, sh, &tot);
+  int bad = 0;
+  if (mark != 0) {
+    const int at = block_off[blockIdx.x] + ex;
+    if (at < cap_c) {
+      const long long raw = dense[v];
+      bf16_t pj;
+      if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;                       // bandit_sampler.py:79-81
+      else pj = f2bf(sqrtf(bf2f(fixed_to_bf(raw, FRAC_SRC, &bad))));                  // :75 torch.sqrt(prob)
+      cand_nid[at] = v; p[at] = pj; is_seed[at] = mark >= SD_SEED_MARK ? 1 : 0;
+      atomicAdd(&hist[pj & 0x7fff], 1);                 // the histogram bliss_poisson_scale reads (and zeroes)
+    } else bad |= BLISS_ERR_CAP_CAND;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int C = *total;
+    if (C > cap_c) C = cap_c;
+    cnt->C = C; cnt->err = 0; cnt->iters = 0; cnt->all_one = 0;
+  }
+  if (bad && err) atomicOr(err, bad);
+}
+
+// SplitMix64 finaliser of (seed, step, layer, node id); top 24 bits -> u = r * 2^-24   (= csrc/shard.hip, oracle keyed_uniform)
+__device__ __forceinline__ unsigned long long sd_key(unsigned long long seed, unsigned long long step, int layer) {
+  unsigned long long key = seed * 0x9E3779B97F4A7C15ull + step;
+  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+  key ^= key >> 31;
+  return key ^ ((unsigned long long)((unsigned)layer & 0xffu) << 56);
+}
+__device__ __forceinline__ float sd_u24(unsigned long long key, int nid) {
+  unsigned long long z = key ^ (unsigned long long)(unsigned)nid;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+}
+// P_j and the draw of candidate i (csrc/shard.hip:k_keyed_select, bandit_sampler.py:403-406, :422-424)
+__device__ __forceinline__ bool sd_draw(int nid, bf16_t pj, bool seed, const LayerCounts* cnt, unsigned long long key, bf16_t* P_out) {
+  bf16_t Pv = 0x3f80;
+  if (!cnt->all_one && !seed) {
+    const float v = rbf(bf2f(pj) * (float)cnt->c);
+    Pv = (v < 1.0f || v != v) ? f2bf(v) : (bf16_t)0x3f80;
+  }
+  *P_out = Pv;
+  return sd_u24(key, nid) < bf2f(Pv);
+}
+
+__global__ void __launch_bounds__(SD_TPB) k_sd_keep_count(const int* __restrict__ cand_nid, const bf16_t* __restrict__ p,
+                                                          const unsigned char* __restrict__ is_seed, const LayerCounts* __restrict__ cnt,
+                                                          unsigned long long seed, const long long* __restrict__ step_dev, int layer,
+                                                          int* __restrict__ block_cnt) {
+  const unsigned long long key = sd_key(seed, (unsigned long long)*step_dev, layer);
+  sd_block_count(cnt->C, block_cnt, [&](int i) {
+    bf16_t Pv;
+    const bool s = is_seed[i] != 0;
+    return sd_draw(cand_nid[i], p[i], s, cnt, key, &Pv) && !s;
+  });
+}
+
+__global__ void __launch_bounds__(SD_TPB) k_sd_keep_write(const int* __restrict__ cand_nid, const bf16_t* __restrict__ p,
+                                                          const unsigned char* __restrict__ is_seed, const LayerCounts* __restrict__ cnt,
+                                                          unsigned long long seed, const long long* __restrict__ step_dev, int layer,
+                                                          const int* __restrict__ block_off, const int* __restrict__ total,
+                                                          const int* __restrict__ seeds_g, int n_seeds, const int* __restrict__ n_seeds_dev,
+                                                          bf16_t* __restrict__ P_out, int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
+                                                          int* __restrict__ kept_map, int cap_k, LayerCounts* layer_cnt,
+                                                          const int* __restrict__ n_local_dev, int* err) {
+  __shared__ int sh[17];
+  const unsigned long long key = sd_key(seed, (unsigned long long)*step_dev, layer);
+  const int S = n_seeds >= 0 ? n_seeds : *n_seeds_dev;
+  const int C = cnt->C;
+  const int i = blockIdx.x * SD_TPB + threadIdx.x;
+  int keep_new = 0;
+  bf16_t Pv = 0;
+  if (i < C) {
+    const bool s = is_seed[i] != 0;
+    keep_new = (sd_draw(cand_nid[i], p[i], s, cnt, key, &Pv) && !s) ? 1 : 0;
+    P_out[i] = Pv;
+  }
+  int tot, ex = block_excl_scan(keep_new, sh, &tot);
+  int bad = 0;
+  if (keep_new) {
+    const int at = S + block_off[blockIdx.x] + ex;      // the seeds come first, in seed order (bandit_sampler.py:408-414 union)
+    if (at < cap_k) { kept_nid[at] = cand_nid[i]; node_prob[at] = Pv; kept_map[cand_nid[i]] = at; }
+    else bad |= BLISS_ERR_CAP_KEPT;
+  }
+  // the seeds themselves: P = 1 (:403-404)
+  for (int j = i; j < S; j += gridDim.x * SD_TPB) {
+    if (j < cap_k) { const int v = seeds_g[j]; kept_nid[j] = v; node_prob[j] = 0x3f80; kept_map[v] = j; }
+    else bad |= BLISS_ERR_CAP_KEPT;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int K = S + *total;
+    if (K > cap_k) K = cap_k;
+    layer_cnt->K = K;
+    layer_cnt->C = *n_local_dev;                        // what bliss_build_block's clean-up walks: cand_nid[0 .. C) = this rank's seeds
+  }
+  if (bad && err) atomicOr(err, bad);
+}
+
+inline int sd_blocks(int n) { return (n + SD_TPB - 1) / SD_TPB; }
+
+}  // namespace
+
+extern "C" {
+
+int bliss_shard_local_seeds(const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev, int32_t lo, int32_t hi, int32_t cap_s,
+                            int32_t* seeds_l, int32_t* seeds_l_copy, int32_t* seed_pos, int32_t* n_local_dev, int32_t* err, void* stream) {
+  if (!seeds_g || !seeds_l || !seed_pos || !n_local_dev || cap_s <= 0 || (n_seeds < 0 && !n_seeds_dev) || n_seeds > cap_s) return BLISS_EINVAL;
+  k_sd_local_seeds<<<1, SD_TPB, 0, (hipStream_t)stream>>>(seeds_g, n_seeds, n_seeds_dev, lo, hi, cap_s, seeds_l, seeds_l_copy, seed_pos, n_local_dev, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2, const int32_t* n_local_dev, const int64_t* touched_key,
+                                 const int64_t* touched_sum, const int32_t* n_touched_dev, int64_t* dense, int32_t num_nodes,
+                                 int32_t* err, void* stream) {
+  if (!seeds_l || !seed_p2 || !n_local_dev || !touched_key || !touched_sum || !n_touched_dev || !dense || num_nodes <= 0) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dense, 0, (size_t)num_nodes * 16, st) != hipSuccess) return (int)hipGetLastError();
+  int grid = (num_nodes + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  k_sd_scatter<<<grid, 256, 0, st>>>(seeds_l, (const long long*)seed_p2, n_local_dev, (const unsigned long long*)touched_key,
+                                     (const long long*)touched_sum, n_touched_dev, (long long*)dense, num_nodes, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
+                           int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream) {
+  if (!dense || num_nodes <= 0 || !cand_nid || !p_bf16 || !is_seed || !hist || !counts || cap_c <= 0 || !scratch) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = sd_blocks(num_nodes);                  // scratch: int32[nb + 1]
+  k_sd_cand_count<<<nb, SD_TPB, 0, st>>>((const long long*)dense, num_nodes, scratch);
+  k_sd_scan<<<1, SD_TPB, 0, st>>>(scratch, nb, scratch + nb);
+  k_sd_cand_write<<<nb, SD_TPB, 0, st>>>((const long long*)dense, num_nodes, uniform_nodes, scratch, scratch + nb, cand_nid, (bf16_t*)p_bf16,
+                                         is_seed, hist, (LayerCounts*)counts, cap_c, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
+                            const int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
+                            void* P_bf16, int32_t* kept_nid, void* node_prob_bf16, int32_t* kept_map, int32_t cap_k, int32_t cap_c,
+                            void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t* err, void* stream) {
+  if (!cand_nid || !p_bf16 || !is_seed || !counts || !step_dev || !seeds_g || (n_seeds < 0 && !n_seeds_dev) || !P_bf16 || !kept_nid ||
+      !node_prob_bf16 || !kept_map || cap_k <= 0 || cap_c <= 0 || !layer_counts || !n_local_dev || !scratch) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = sd_blocks(cap_c);                      // scratch: int32[nb + 1]; blocks beyond the true count find nothing
+  k_sd_keep_count<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (const long long*)step_dev,
+                                         layer, scratch);
+  k_sd_scan<<<1, SD_TPB, 0, st>>>(scratch, nb, scratch + nb);
+  k_sd_keep_write<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (const long long*)step_dev,
+                                         layer, scratch, scratch + nb, seeds_g, n_seeds, n_seeds_dev, (bf16_t*)P_bf16, kept_nid,
+                                         (bf16_t*)node_prob_bf16, kept_map, cap_k, (LayerCounts*)layer_counts, n_local_dev, err);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+"""Destination-range shards with STATIC SHAPES: the sampler and the train step of
+``bliss_gnn_amd.shard`` with every exchange made dense, so that no size reaches the host inside a step and the step records
+into a HIP graph, collectives included.
+
+``shard.py`` routes what it exchanges: (source, partial sum) pairs to the sources' owners, a histogram all-reduce, an
+all-gather of the kept lists -- three exchanges per sampling layer with data-dependent sizes, i.e. a host sync each.  Here:
+
+  * one sampling layer = ONE all-reduce of a fixed shape.  Every rank expands the columns of the seeds it owns and reduces
+    (q/sum q)^2 by source over its own edges (bandit_sampler.py:67-73: the same kernels, ``BLISS_MODE_PARTIALS``), then scatters
+    these exact Q.44 partial sums into an ``int64 [2, |V|]`` buffer (sum; touch mark, + 2^32 for a seed) which is all-reduced
+    (1.9 MB on the Reddit-like graph).  Integer sums: the result has the same bits for any number of shards and any reduction
+    order.  Every rank then holds every source's sum and derives THE SAME candidate list (ascending node id), importances,
+    histogram, Poisson scale (:391-401), keyed draw (:403-406, :422-424) and kept list -- replicated work instead of routed data;
+  * a rank builds the block of ITS seeds over the global kept list (:269-339), as in ``shard.py``;
+  * block inputs (halo): each rank writes the rows it owns at their positions of a zero ``[cap_K, F]`` buffer and the buffers
+    are all-reduced as int32 words (x + 0 + .. + 0: exact, and an integer type both RCCL and gloo reduce); the backward of that
+    gather is the all-reduce of the fp32 gradient buffer;
+  * EXP3: owner-local updates, the L1 norm from the all-reduced exact row sums (``bliss_exp3_normalize_global``).
+
+Parity: ``DenseShardedSampler`` produces the kept lists, probabilities, blocks and EXP3 rows of ``ShardedPoissonBanditSampler``
+bit for bit (tests/test_gpu_shard_static.py; the CPU twin tests/test_shard_static_gloo.py runs the dense exchange with the
+oracle's arithmetic under gloo on 2 and 3 ranks against the single-process keyed oracle).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .graph import NID
+from .shard import HIST_BINS, ShardBlock, _HipShardOps, _all_reduce
+
+SEED_MARK = 1 << 32
+
+
+# ------------------------------------------------------------------------------------------- the exchange, generic form
+class DenseShardedSampler:
+    """PoissonBanditLadiesSampler (bandit_sampler.py:369-425) over destination-range shards, dense exchange.
+
+    ``ops`` given (tests: the oracle's arithmetic on CPU tensors; or ``shard._HipShardOps``): the layer is a sequence of tensor
+    ops with true sizes (host syncs) -- the REFERENCE FORM of the exchange, used to test it.  ``ops=None``: the static-shape
+    HIP path (``enqueue`` / ``sample_blocks``): capacity-sized buffers, sizes on the device, graph-capturable."""
+
+    def __init__(self, shard, nodes_per_layer, eta=0.4, importance_sampling=True, seed=0, model="sage", group=None, ops=None):
+        self.g, self.nodes_per_layer, self.eta = shard, list(nodes_per_layer), eta
+        self.seed, self.group, self.step = int(seed), group, 0
+        self.world, self.rank = shard.world, shard.rank
+        self.delta = 0.01                                                   # bandit_sampler.py:233
+        self._delta_f = float(torch.tensor(self.delta, dtype=torch.float32))
+        self.static = ops is None
+        self.ops = ops if ops is not None else _HipShardOps(shard, len(self.nodes_per_layer), eta, importance_sampling, model)
+        self.trace = []
+        self._bufs = None
+        self.bytes_per_step = 0
+
+    # ---------------------------------------------------------------- reference form (true sizes, any device)
+    def sample_blocks_generic(self, seeds_g, step=None):
+        g, ops, grp = self.g, self.ops, self.group
+        dev, V = seeds_g.device, int(g.indptr.numel() - 1)
+        step = self.step if step is None else int(step)
+        self.step = step + 1
+        seeds_g = seeds_g.to(torch.int32).contiguous()
+        L = len(self.nodes_per_layer)
+        order = list(reversed(range(L)))
+        fan = [self.nodes_per_layer[b] for b in order]
+        if hasattr(ops, "set_caps"):
+            ops.set_caps(int(seeds_g.numel()), fan)
+        blocks, self.trace = [], []
+        for n, layer in enumerate(order):
+            S_g = int(seeds_g.numel())
+            mine = (seeds_g >= g.lo) & (seeds_g < g.hi)
+            seed_pos = torch.nonzero(mine).flatten()
+            seeds_l = seeds_g[seed_pos].contiguous()
+            ids, sums = ops.frontier_partials(n, layer, seeds_l)              # my seeds first, then the other touched sources
+            dense = torch.zeros(2, V, dtype=torch.int64, device=dev)
+            dense[0, ids.long()] = sums
+            dense[1, ids.long()] = 1
+            dense[1, seeds_l.long()] += SEED_MARK
+            _all_reduce(dense, grp)                                           # THE exchange of this layer
+            cand = torch.nonzero(dense[1]).flatten()
+            is_seed = dense[1, cand] >= SEED_MARK
+            p = ops.importance(dense[0, cand])
+            hist = torch.bincount(p.view(torch.int16).long() & 0xFFFF, minlength=HIST_BINS)[:HIST_BINS]
+            ops.scale(hist, int(cand.numel()), fan[n])
+            cand = cand.to(torch.int32)
+            P, keep = ops.keyed_select(cand, p, is_seed, self.seed, step, n)
+            new = keep & ~is_seed
+            kept_g = torch.cat([seeds_g, cand[new]]).contiguous()
+            prob_g = torch.cat([torch.ones(S_g, dtype=torch.bfloat16, device=dev), P[new]])
+            blk = ops.build_block(n, kept_g, prob_g, seed_pos)
+            blk.edata["edge_weights"] = blk._edge_weights
+            blk.edata["q_ij"] = blk._q
+            blk.srcdata["node_prob"] = blk._node_prob
+            self.trace.append(dict(cand=cand, p=p, P=P, C=int(cand.numel()), scale=ops.scale_result() if hasattr(ops, "scale_result") else None))
+            blocks.insert(0, blk)
+            seeds_g = kept_g
+        return blocks[0].srcdata[NID], blocks[-1].dstdata[NID], blocks
+
+    # ---------------------------------------------------------------- static form (HIP, no host sync)
+    def _ensure_static(self, S0, fan):
+        ops, eng, dev = self.ops, self.ops.eng, self.g.device
+        ops.set_caps(S0, fan)
+        L, V = len(fan), eng.V
+        key = (S0, tuple(fan), tuple((c["S"], c["K"], c["B"]) for c in eng.caps))
+        if self._bufs is not None and self._bufs["key"] == key:
+            return self._bufs
+        nb = V // 1024 + 4
+        b = dict(key=key, counts=torch.zeros(L * 10, dtype=torch.int32, device=dev), rec=torch.zeros(L, 10, dtype=torch.int32, device=dev),
+                 dense=torch.zeros(2 * V, dtype=torch.int64, device=dev),
+                 cand=torch.zeros(V, dtype=torch.int32, device=dev), p=torch.zeros(V, dtype=torch.bfloat16, device=dev),
+                 P=torch.zeros(V, dtype=torch.bfloat16, device=dev), is_seed=torch.zeros(V, dtype=torch.uint8, device=dev),
+                 scr_a=torch.zeros(nb, dtype=torch.int32, device=dev), scr_b=torch.zeros(nb, dtype=torch.int32, device=dev),
+                 sel=torch.zeros(nb, dtype=torch.int32, device=dev), err=torch.zeros(1, dtype=torch.int32, device=dev),
+                 step=torch.zeros(1, dtype=torch.int64, device=dev), seeds0=torch.zeros(S0, dtype=torch.int32, device=dev),
+                 seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
+                 seed_pos=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
+                 n_local=torch.zeros(L, dtype=torch.int32, device=dev),
+                 counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(), rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(),
+                 nloc_host=torch.empty(L, dtype=torch.int32).pin_memory(), err_host=torch.empty(1, dtype=torch.int32).pin_memory())
+        self._bufs = b
+        self.bytes_per_step = L * 2 * V * 8
+        return b
+
+    def enqueue(self, seeds_g):
+        """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
+        outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
+        advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors."""
+        if not self.static:
+            raise RuntimeError("enqueue() is the static HIP path; construct the sampler without ops")
+        g, ops = self.g, self.ops
+        eng = ops.eng
+        L = len(self.nodes_per_layer)
+        order = list(reversed(range(L)))
+        fan = [self.nodes_per_layer[b] for b in order]
+        S0 = int(seeds_g.numel())
+        b = self._ensure_static(S0, fan)
+        st = torch.cuda.current_stream().cuda_stream
+        lib, chk = _lib.lib, _lib.check
+        V = eng.V
+        b["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
+        eta_f, ome_f = float(np.float32(self.eta)), float(np.float32(1.0 - self.eta))
+        bins = eng._bin_buffers()
+        n_touched_ptr = bins["cursor"].data_ptr() + 4 * eng.n_bins
+        cur, n_seeds, n_seeds_dev = b["seeds0"], S0, 0
+        blocks = []
+        for n, layer in enumerate(order):
+            cap = eng.caps[n]
+            cs, ws = cap["S"], eng.ws[n]
+            c_ws, c_out, lay, cnt_ptr, kept_nid = eng._layer_buffers(n, b["counts"], slot="dense")
+            seeds_l, seed_pos = b["seeds_l"][n], b["seed_pos"][n]
+            nloc_ptr = b["n_local"].data_ptr() + 4 * n
+            rec_ptr = b["rec"].data_ptr() + 40 * n
+            w_pos = ops.w_pos[layer]
+            chk(lib.bliss_shard_local_seeds(cur.data_ptr(), n_seeds, n_seeds_dev, g.lo, g.hi, cs, seeds_l.data_ptr(), ws.cand_nid.data_ptr(),
+                                            seed_pos.data_ptr(), nloc_ptr, b["err"].data_ptr(), st), "bliss_shard_local_seeds")
+            chk(lib.bliss_frontier_prob(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), -1, nloc_ptr,
+                                        cs, ops.mode | _lib.MODE_PARTIALS, eta_f, ome_f, eng.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
+            seed_p2_ptr = ws.seed_acc.data_ptr() + 8 * 4 * cs
+            chk(lib.bliss_shard_scatter_partials(seeds_l.data_ptr(), seed_p2_ptr, nloc_ptr, bins["tkey"].data_ptr(), bins["tsum"].data_ptr(),
+                                                 n_touched_ptr, b["dense"].data_ptr(), V, b["err"].data_ptr(), st), "bliss_shard_scatter_partials")
+            _all_reduce(b["dense"], self.group)                               # THE exchange of this layer (static shape)
+            st = torch.cuda.current_stream().cuda_stream
+            chk(lib.bliss_shard_candidates(b["dense"].data_ptr(), V, ops.uniform_nodes, b["cand"].data_ptr(), b["p"].data_ptr(),
+                                           b["is_seed"].data_ptr(), eng.hist.data_ptr(), rec_ptr, V, b["scr_a"].data_ptr(), b["err"].data_ptr(), st),
+                "bliss_shard_candidates")
+            chk(lib.bliss_poisson_scale(eng.hist.data_ptr(), rec_ptr, int(fan[n]), 0.9999, b["sel"].data_ptr(), st), "bliss_poisson_scale")
+            chk(lib.bliss_shard_select_kept(b["cand"].data_ptr(), b["p"].data_ptr(), b["is_seed"].data_ptr(), rec_ptr, self.seed, b["step"].data_ptr(),
+                                            n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
+                                            c_ws.kept_map, cap["K"], V, cnt_ptr, nloc_ptr, b["scr_b"].data_ptr(), b["err"].data_ptr(), st),
+                "bliss_shard_select_kept")
+            chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
+                                      eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
+            b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept, node_prob, cdev, t_indptr, t_edge = lay
+            blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos)
+            blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
+            blk._counts, blk._counts_dev, blk._layer = None, cdev, layer
+            blk._nnz_ptr = b["counts"].data_ptr() + 40 * n + 16
+            blk._xcap = int(cap["B"])
+            if t_indptr is not None:
+                blk._transposed = (t_indptr, t_edge)
+            blk.edata["edge_weights"], blk.edata["q_ij"], blk.srcdata["node_prob"] = b_w, b_q, node_prob
+            blocks.insert(0, blk)
+            cur, n_seeds, n_seeds_dev = kept, -1, cnt_ptr + 12
+        b["step"].add_(1)
+        self._static_blocks = blocks
+        return blocks
+
+    def finish(self):
+        """After a synchronisation: true sizes per layer (sampling order) and the error check."""
+        b = self._bufs
+        b["counts_host"].copy_(b["counts"]); b["rec_host"].copy_(b["rec"]); b["nloc_host"].copy_(b["n_local"]); b["err_host"].copy_(b["err"])
+        torch.cuda.current_stream().synchronize()
+        raw = b["counts_host"].numpy().tobytes()
+        L = len(self.nodes_per_layer)
+        cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
+        bad = int(b["err_host"][0])
+        for c in cnts:
+            bad |= c.err
+        if bad:
+            raise RuntimeError(f"static sharded sampler kernel error 0x{bad:x}: {_lib.err_string(bad)}")
+        recs = [_lib.LayerCounts.from_buffer_copy(b["rec_host"][n].numpy().tobytes()) for n in range(L)]
+        self.trace = [dict(C=r.C, scale=(float(r.c), bool(r.all_one), int(r.iters))) for r in recs]
+        return [dict(S=int(b["nloc_host"][n]), K=c.K, B=c.B) for n, c in enumerate(cnts)]
+
+    def sample_blocks(self, seeds_g, step=None):
+        if not self.static:
+            return self.sample_blocks_generic(seeds_g, step)
+        if step is not None:
+            self._ensure_static(int(seeds_g.numel()), [self.nodes_per_layer[b] for b in reversed(range(len(self.nodes_per_layer)))])
+            self._bufs["step"].fill_(int(step))
+        blocks = self.enqueue(seeds_g)
+        self.sizes = self.finish()
+        return blocks[0].srcdata[NID], blocks[-1].dstdata[NID], blocks
+
+    # ---------------------------------------------------------------- EXP3 (owner-local update, global norm)
+    def exp3(self, mfgs, g=None):
+        """bandit_sampler.py:251-267 on the owned in-edges of every block, then the global L1 renormalisation."""
+        for idx, mfg in enumerate(mfgs):
+            self.ops.exp3_update(mfg, mfg.srcdata["embed_norm"], self._delta_f)
+            self.ops.normalize(idx, self.group)
+
+    def check_errors(self):
+        if hasattr(self.ops, "check_errors"):
+            self.ops.check_errors()
+        if self._bufs is not None:
+            bits = int(self._bufs["err"].item())
+            if bits:
+                raise RuntimeError(f"static sharded sampler kernel error 0x{bits:x}: {_lib.err_string(bits)}")

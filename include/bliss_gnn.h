@@ -234,6 +234,34 @@ int bliss_cand_importance(const int64_t* sums, int32_t n, int uniform_nodes, voi
 int bliss_poisson_scale(int32_t* hist, void* counts, int32_t fanout, double eps, int32_t* scratch, void* stream);
 int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is_seed, int32_t n, const void* counts,
                        uint64_t seed, uint64_t step, int32_t layer, void* P_bf16, uint8_t* keep, void* stream);
+/* The STATIC-SHAPE sharded sampler (csrc/shard_dense.hip, bliss_gnn_amd/shard_static.py): the same split as above with every
+ * exchange made dense, so that a layer has ONE collective of a fixed shape and no size ever reaches the host:
+ *   bliss_shard_local_seeds:      the seeds of the global list (n_seeds, or *n_seeds_dev when n_seeds < 0) that lie in [lo, hi),
+ *                                 order kept -> seeds_l (and a second copy: what bliss_build_block's clean-up walks),
+ *                                 seed_pos[i] = position in the global list (0 beyond the count), *n_local_dev;
+ *   bliss_shard_scatter_partials: zeroes dense (int64 [2 * num_nodes]) and scatters the per-source partial sums that
+ *                                 bliss_frontier_prob(BLISS_MODE_PARTIALS) left (seeds: seed_p2; others: touched_key / touched_sum,
+ *                                 their count in *n_touched_dev) into dense[v], with dense[num_nodes + v] = 1 (+ 2^32 for a seed).
+ *                                 The caller all-reduces dense (integer sums: exact for any shard count, any order);
+ *   bliss_shard_candidates:       candidates = nodes with a non-zero mark, ascending id: cand_nid, p_j = sqrt(bf16(sum)) (:75),
+ *                                 is_seed, the histogram of p's bit patterns, counts->C; scratch int32[num_nodes / 1024 + 3];
+ *   (bliss_poisson_scale on that histogram and counts)
+ *   bliss_shard_select_kept:      P_j and the keyed draw (as bliss_keyed_select, the step read from *step_dev), kept list =
+ *                                 the seeds in seed order, then the drawn non-seeds in node order: kept_nid, node_prob, kept_map
+ *                                 [kept_nid[i]] = i, layer_counts->K, layer_counts->C = *n_local_dev (bliss_build_block's clean-up
+ *                                 bound); scratch int32[cap_c / 1024 + 3].
+ * (source: bandit_sampler.py:47-82, 381-425; no reference counterpart for the split itself -- SURVEY.md section 8e) */
+int bliss_shard_local_seeds(const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev, int32_t lo, int32_t hi, int32_t cap_s,
+                            int32_t* seeds_l, int32_t* seeds_l_copy, int32_t* seed_pos, int32_t* n_local_dev, int32_t* err, void* stream);
+int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2, const int32_t* n_local_dev, const int64_t* touched_key,
+                                 const int64_t* touched_sum, const int32_t* n_touched_dev, int64_t* dense, int32_t num_nodes,
+                                 int32_t* err, void* stream);
+int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
+                           int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream);
+int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
+                            const int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
+                            void* P_bf16, int32_t* kept_nid, void* node_prob_bf16, int32_t* kept_map, int32_t cap_k, int32_t cap_c,
+                            void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t* err, void* stream);
 /* bliss_exp3_normalize with the norm taken from norm_limbs (int64[3 * BLISS_ROWSUM_SLOTS], e.g. the all-reduced row sums of
  * all shards) instead of row_sum; row_sum receives the exact sum of THIS row part after the division. */
 int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum, const int64_t* norm_limbs, int64_t* scratch,
