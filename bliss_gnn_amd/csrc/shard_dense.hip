@@ -43,6 +43,11 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_local_seeds(const int* __restrict
 }
 
 // ---- partial sums -> dense ------------------------------------------------------------------------------------------------
+// (hipMemsetAsync issued from library code into a stream that torch is capturing did not replay with the graph here -- the
+// buffer kept the marks of earlier steps from the second replay on -- so the zeroing is a kernel like everything else)
+__global__ void __launch_bounds__(256) k_sd_zero(long long* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0;
+}
 __global__ void __launch_bounds__(256) k_sd_scatter(const int* __restrict__ seeds_l, const long long* __restrict__ seed_p2,
                                                     const int* __restrict__ n_local_dev, const unsigned long long* __restrict__ tkey,
                                                     const long long* __restrict__ tsum, const int* __restrict__ n_touched_dev,
@@ -213,9 +218,9 @@ int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2,
                                  int32_t* err, void* stream) {
   if (!seeds_l || !seed_p2 || !n_local_dev || !touched_key || !touched_sum || !n_touched_dev || !dense || num_nodes <= 0) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dense, 0, (size_t)num_nodes * 16, st) != hipSuccess) return (int)hipGetLastError();
   int grid = (num_nodes + 255) / 256;
   if (grid > 1024) grid = 1024;
+  k_sd_zero<<<grid, 256, 0, st>>>((long long*)dense, 2ll * num_nodes);       // (a kernel, not hipMemsetAsync: see k_sd_zero)
   k_sd_scatter<<<grid, 256, 0, st>>>(seeds_l, (const long long*)seed_p2, n_local_dev, (const unsigned long long*)touched_key,
                                      (const long long*)touched_sum, n_touched_dev, (long long*)dense, num_nodes, err);
   return (int)hipGetLastError();

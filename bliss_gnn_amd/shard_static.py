@@ -227,3 +227,180 @@ class DenseShardedSampler:
             bits = int(self._bufs["err"].item())
             if bits:
                 raise RuntimeError(f"static sharded sampler kernel error 0x{bits:x}: {_lib.err_string(bits)}")
+
+
+# ------------------------------------------------------------------------------------------- the model step
+class _HaloAllReduce(torch.autograd.Function):
+    """Block inputs over all ranks: every rank wrote the rows it owns into a zero buffer of the block's capacity; the sum of
+    the buffers is the full input.  Sent as int32 words (two bf16 each: x + 0 + .. + 0 is exact and an integer is a type both
+    RCCL and gloo reduce).  Backward: the gradient of a row goes back to the rank that produced it, summed over all consumers
+    -- the all-reduce of the fp32 gradient buffer, of which autograd then takes this rank's rows."""
+
+    @staticmethod
+    def forward(ctx, buf, group):
+        ctx.group = group
+        out = buf.contiguous().clone()
+        if (out.shape[1] * out.element_size()) % 4 == 0:
+            _all_reduce(out.view(torch.int32), group)
+        else:                                                    # odd row length: fp32 carries bf16 exactly
+            f = out.float()
+            _all_reduce(f, group)
+            out = f.to(buf.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gf = g.float().contiguous()
+        _all_reduce(gf, ctx.group)
+        return gf.to(g.dtype), None
+
+
+def halo_all_reduce(buf, group=None):
+    return _HaloAllReduce.apply(buf, group)
+
+
+class StaticShardedTrainStep:
+    """One optimiser step of ModelLightning (train_lightning.py:100-168, 205-216, 463-471) over destination-range shards with
+    static shapes: every rank contributes ``batch`` seeds it owns (the global batch is their concatenation, rank by rank), the
+    sampler is ``DenseShardedSampler.enqueue``, block inputs travel as capacity-sized all-reduces, the loss is the mean over the
+    GLOBAL batch.  No size reaches the host inside ``_body``: with RCCL the whole step records into ONE HIP graph (``capture``).
+
+    Collectives per step: 1 all-gather (seeds) + L dense all-reduces (sampler) + L halo all-reduces (+ L - 1 backward) + 1
+    (gradients) + L (EXP3 row sums) + 1 (loss): all of fixed shape; ``bytes_per_step`` adds up what a rank contributes."""
+
+    def __init__(self, shard, sampler, model, batch, lr=0.002, multilabel=False, group=None):
+        import torch.nn as nn
+        from .train import make_adam
+        if not sampler.static:
+            raise ValueError("StaticShardedTrainStep needs a DenseShardedSampler on its static HIP path (ops=None)")
+        self.g, self.sampler, self.model, self.group, self.batch = shard, sampler, model, group, int(batch)
+        self.multilabel = bool(multilabel)
+        self.opt = make_adam(model, lr, capturable=True)
+        dev = shard.device
+        self.my_seeds = torch.zeros(self.batch, dtype=torch.int32, device=dev)
+        self.seeds_g = torch.zeros(self.batch * shard.world, dtype=torch.int32, device=dev)
+        self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.graph = None
+        self.last = {}
+        self.bytes_per_step = 0
+
+    def _gather_seeds(self):
+        if self.g.world == 1:
+            self.seeds_g.copy_(self.my_seeds)
+        elif dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.seeds_g, self.my_seeds, group=self.group)
+        else:
+            parts = [torch.empty(self.batch, dtype=torch.int32) for _ in range(self.g.world)]
+            dist.all_gather(parts, self.my_seeds.cpu(), group=self.group)
+            self.seeds_g.copy_(torch.cat(parts))
+
+    def _forward(self, blocks):
+        from .nn import embed_norm
+        g, model, grp = self.g, self.model, self.group
+        lo, hi = g.lo, g.hi
+        n_own = hi - lo
+        L = len(blocks)
+        n_local = self.sampler._bufs["n_local"]
+        h, halo_bytes = None, 0
+        for l, (layer, blk) in enumerate(zip(model.layers, blocks)):
+            cap_k = blk.num_src_nodes()
+            if l == 0:                                             # train_lightning.py:138, owner side: my feature rows, zeros elsewhere
+                nid = blk.srcdata[NID]
+                k_dev = blk._counts_dev[3]
+                valid = (torch.arange(cap_k, device=nid.device) < k_dev) & (nid >= lo) & (nid < hi)
+                rows = g.ndata_owned["features"][(nid.long() - lo).clamp(0, n_own - 1)]
+                buf = torch.where(valid[:, None], rows, torch.zeros((), dtype=rows.dtype, device=rows.device))   # (+0 bits: x * 0 can be -0)
+                h_src = halo_all_reduce(buf.detach(), grp)
+            else:                                                  # the rows I computed, at their positions of this block's source list
+                prev = blocks[l - 1]
+                cap_s = prev.num_dst_nodes()
+                n_prev = n_local[L - l]                            # block l-1 <-> sampling layer L-l
+                idx = torch.where(torch.arange(cap_s, device=h.device) < n_prev, prev.dst_pos.long(), torch.full((), cap_k, device=h.device))
+                buf = torch.zeros(cap_k + 1, h.shape[1], dtype=h.dtype, device=h.device).index_copy(0, idx, h)[:cap_k]
+                h_src = halo_all_reduce(buf, grp)
+            halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
+            blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
+            h = layer(blk, (h_src, h_src[blk.dst_pos.long()]), edge_weight=blk.edata["edge_weights"])
+            if l < L - 1:
+                h = model.dropout(model.activation(h))             # :330-332
+        self._halo_bytes = halo_bytes
+        return h
+
+    def _body(self):
+        from .shard import allreduce_gradients_sum
+        g, grp = self.g, self.group
+        self._gather_seeds()
+        blocks = self.sampler.enqueue(self.seeds_g)
+        pred = self._forward(blocks)                                                              # train_lightning.py:138-141
+        last = blocks[-1]
+        cap_s = last.num_dst_nodes()
+        n_mine = self.sampler._bufs["n_local"][0]                                                 # (sampling layer 0 = the output block)
+        mask = torch.arange(cap_s, device=pred.device) < n_mine
+        y = g.ndata_owned["labels"][(last.dstdata[NID].long() - g.lo).clamp(0, g.hi - g.lo - 1)]  # :139
+        n_global = self.batch * g.world
+        if self.multilabel:
+            per_row = torch.nn.functional.binary_cross_entropy_with_logits(pred.float(), y.float(), reduction="none").sum(1)
+            scale = 1.0 / (n_global * pred.shape[1])
+        else:
+            per_row = torch.nn.functional.cross_entropy(pred.float(), y, reduction="none")
+            scale = 1.0 / n_global
+        loss_sum = (per_row * mask).sum()                                                         # padding rows: no loss, no gradient
+        self.opt.zero_grad(set_to_none=True)
+        loss_sum.backward()
+        allreduce_gradients_sum(self.model, scale, grp)
+        self.opt.step()
+        self.sampler.exp3(blocks)                                                                 # :469-471
+        tot = loss_sum.detach().float().reshape(1).clone()
+        _all_reduce(tot, grp)
+        self.loss_dev.copy_(tot * scale)
+        self.last = dict(mfgs=blocks, pred=pred.detach())
+        n_par = sum(p.numel() for p in self.model.parameters())
+        self.bytes_per_step = self.sampler.bytes_per_step + self._halo_bytes + 4 * n_par + 4 * self.batch + 96 * 8 * len(blocks) + 4
+
+    def __call__(self, my_seeds):
+        """``my_seeds``: the ``batch`` seeds this rank contributes (ids it owns).  Returns the global mean loss (a device scalar
+        read after the step's one synchronisation)."""
+        self.my_seeds.copy_(my_seeds.to(torch.int32), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+        return self.loss_dev
+
+    def capture(self, loader, warmup=2):
+        """Warm-up steps on a side stream, then record the step -- sampler, collectives, model, Adam, EXP3 -- into one HIP graph
+        (RCCL only: gloo's collectives run on the host)."""
+        if self.g.world > 1 and dist.get_backend(self.group) != "nccl":
+            raise RuntimeError("graph capture needs the collectives on the device (backend nccl)")
+        import gc
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self(next(loader))
+            torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().wait_stream(side)
+        self.sampler.check_errors()
+        self.last = {}
+        gc.collect()
+        torch.cuda.synchronize()
+        self.my_seeds.copy_(next(loader).to(torch.int32))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._body()
+        self.graph = graph
+        self.graph.replay()                                        # the capture executed nothing: this batch is a real step
+        torch.cuda.synchronize()
+
+    def finish(self):
+        """The step's one synchronisation: true block sizes, error words, the loss."""
+        sizes = self.sampler.finish()
+        self.sampler.check_errors()
+        return float(self.loss_dev.item()), sizes
+
+    def close(self):
+        import gc
+        torch.cuda.synchronize()
+        self.graph, self.last = None, {}
+        gc.collect()
+        torch.cuda.synchronize()

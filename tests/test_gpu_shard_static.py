@@ -82,3 +82,118 @@ def test_static_sharded_sampler_equals_the_routed_one(cuda, world):
         res = _spawn(_sampler_worker, world, outdir)
     for r in res:
         assert r["problems"] == [], r["problems"][:6]
+
+
+def _train_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from bliss_gnn_amd import shard as sh
+    from bliss_gnn_amd import shard_static as ss
+    from bliss_gnn_amd.model import SAGE
+    ip, ix, ei, batches, _, feats, labels = _problem()
+    bounds = sh.partition_by_in_edges(ip, world)
+    g = sh.GraphShard.from_global(ip, ix, ei, bounds, rank, device=dev, ndata={"features": feats, "labels": labels})
+    per_rank = BATCH // world
+    out = {}
+    for kind in ("eager", "static"):
+        torch.manual_seed(0)
+        model = SAGE(F, 32, CLASSES, 3, torch.relu, 0.0).to(dev).bfloat16()
+        if kind == "eager":
+            sampler = sh.ShardedPoissonBanditSampler(g, FAN, eta=ETA, seed=SEED)
+            step = sh.ShardedTrainStep(g, sampler, model, lr=0.002)
+        else:
+            sampler = ss.DenseShardedSampler(g, FAN, eta=ETA, seed=SEED)
+            step = ss.StaticShardedTrainStep(g, sampler, model, per_rank, lr=0.002)
+        losses, preds, kept = [], [], []
+        for si in range(len(batches)):
+            # every rank contributes the same number of seeds it owns (static shapes)
+            gen = torch.Generator().manual_seed(100 + 7 * si + rank)
+            mine = (torch.randperm(g.hi - g.lo, generator=gen)[:per_rank] + g.lo).to(torch.int32).to(dev)
+            if kind == "eager":
+                losses.append(float(step(mine)))
+                b = step.last["mfgs"][-1]
+                preds.append((b.dstdata["_ID"].cpu(), step.last["pred"].detach().float().cpu()))
+                kept.append([m.srcdata["_ID"].cpu().tolist() for m in step.last["mfgs"]])
+            else:
+                step(mine)
+                loss, sizes = step.finish()
+                losses.append(loss)
+                blocks = step.last["mfgs"]
+                n0 = sizes[0]["S"]
+                preds.append((blocks[-1].dstdata["_ID"].cpu()[:n0], step.last["pred"].float().cpu()[:n0]))
+                kept.append([m.srcdata["_ID"].cpu()[:sizes[len(FAN) - 1 - l]["K"]].tolist() for l, m in enumerate(blocks)])
+            sampler.check_errors()
+        out[kind] = dict(losses=losses, preds=preds, kept=kept, params=[p.detach().float().cpu() for p in model.parameters()],
+                         w=sampler.ops.w_pos.cpu().view(torch.int16))
+    torch.save(dict(rank=rank, **out), os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_static_sharded_train_step_follows_the_eager_one(cuda, world):
+    """Step 0 starts from identical parameters and EXP3 rows: same kept lists, predictions and loss within bf16 tolerances (the
+    capacity-padded GEMMs may tile differently); the input-most EXP3 row (a function of the FEATURES' norms) identical.  Later
+    steps: both paths keep training (finite, close losses) -- their optimisers differ (one-launch bf16 Adam vs torch's)."""
+    with tempfile.TemporaryDirectory() as outdir:
+        res = _spawn(_train_worker, world, outdir)
+    for r in res:
+        e, s = r["eager"], r["static"]
+        assert e["kept"][0] == s["kept"][0]
+        ref = dict(zip(e["preds"][0][0].tolist(), e["preds"][0][1]))
+        got = dict(zip(s["preds"][0][0].tolist(), s["preds"][0][1]))
+        assert set(ref) == set(got)
+        for nid, row in got.items():
+            tol = 4 * 2.0 ** -8 * max(1.0, float(ref[nid].abs().max()))
+            assert torch.allclose(row, ref[nid], rtol=3e-2, atol=tol)
+        assert abs(e["losses"][0] - s["losses"][0]) <= 2e-2 * max(1.0, abs(e["losses"][0]))
+        for a, b in zip(e["losses"], s["losses"]):
+            assert a == a and b == b and abs(a - b) <= 0.15 * max(1.0, abs(a))
+        assert all(torch.isfinite(p).all() for p in s["params"])
+    if world == 2:
+        assert all(torch.equal(a, b) for a, b in zip(res[0]["static"]["params"], res[1]["static"]["params"]))   # replicas of the parameters stay in step
+        assert res[0]["static"]["losses"] == res[1]["static"]["losses"]
+
+
+def test_static_sharded_step_replays_from_one_graph(cuda):
+    """World of one rank over RCCL: the whole step (sampler with its dense all-reduces, halo all-reduces, model, Adam, EXP3) is
+    recorded into ONE HIP graph; replaying it trains exactly like launching it kernel by kernel."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29743"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        from bliss_gnn_amd import shard as sh
+        from bliss_gnn_amd import shard_static as ss
+        from bliss_gnn_amd.model import SAGE
+        ip, ix, ei, _, _, feats, labels = _problem()
+        bounds = sh.partition_by_in_edges(ip, 1)
+        gen = torch.Generator().manual_seed(11)
+        batches = [torch.randperm(V, generator=gen)[:BATCH].to(torch.int32).to(cuda) for _ in range(7)]
+        outs = []
+        for graphed in (False, True):
+            g = sh.GraphShard.from_global(ip, ix, ei, bounds, 0, device=cuda, ndata={"features": feats, "labels": labels})
+            sampler = ss.DenseShardedSampler(g, FAN, eta=ETA, seed=SEED)
+            torch.manual_seed(0)
+            model = SAGE(F, 32, CLASSES, 3, torch.relu, 0.0).to(cuda).bfloat16()
+            step = ss.StaticShardedTrainStep(g, sampler, model, BATCH, lr=0.002)
+            it = iter(batches)
+            losses = []
+            if graphed:
+                step.capture(it, warmup=2)                  # batches 0, 1 eagerly, batch 2 by the first replay
+                assert step.graph is not None
+            else:
+                for _ in range(3):
+                    step(next(it))
+            for b in it:
+                step(b)
+                losses.append(step.finish()[0])
+            sampler.check_errors()
+            outs.append((losses, [p.detach().float().cpu() for p in model.parameters()], sampler.ops.w_pos.cpu().view(torch.int16).clone()))
+            step.close()
+        assert outs[0][0] == outs[1][0]
+        assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+        assert torch.equal(outs[0][2], outs[1][2])
+    finally:
+        dist.destroy_process_group()
