@@ -391,52 +391,113 @@ def main():
 
 
 def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, rank, world, t_setup):
-    """The destination-range-sharded step (bliss_gnn_amd/shard.py): every rank owns a node range, draws its batch from the
-    train ids it owns (weak scaling: global batch = world x batch) and takes part in one global step at a time.  Eager
-    launches with a host sync per exchange -- this measures the path as built, not a graph-replayed loop."""
+    """The destination-range-sharded step: every rank owns a node range, draws its batch from the train ids it owns (weak
+    scaling: global batch = world x batch) and takes part in one global step at a time.  Default: the STATIC-SHAPE step of
+    bliss_gnn_amd/shard_static.py (dense exchanges, no host sync, one HIP graph per step over RCCL); ``--eager``: the routed
+    step of bliss_gnn_amd/shard.py with its host sync per exchange."""
+    from bliss_gnn_amd import roofline
     from bliss_gnn_amd import shard as sh
+    from bliss_gnn_amd import shard_static as ss
     from bliss_gnn_amd.model import SAGE
     from bliss_gnn_amd.train import BatchLoader
     bounds = sh.partition_by_in_edges(ip, world)
     g = sh.GraphShard.from_global(ip, ix, ei, bounds, rank, device=dev, ndata={"features": feats, "labels": labels})
-    sampler = sh.ShardedPoissonBanditSampler(g, cfg["fanouts"], eta=0.1, seed=7)
     torch.manual_seed(1234)
     model = SAGE(cfg["feat"], hidden, cfg["classes"], 3, torch.relu, 0.1).to(dev).bfloat16()
-    step = sh.ShardedTrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"])
     mine = train_nid[(train_nid >= g.lo) & (train_nid < g.hi)]
     loader = BatchLoader(mine, cfg["batch"], shuffle=True, drop_last=True, seed=2 + rank).forever()
+    static = not args.eager
+    edges_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    if static:
+        sampler = ss.DenseShardedSampler(g, cfg["fanouts"], eta=0.1, seed=7)
+        step = ss.StaticShardedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"])
+        launch = "static shapes, launched kernel by kernel (no host sync inside a step)"
+        if world == 1 or dist.get_backend() == "nccl":
+            try:
+                if world == 1 and not dist.is_initialized():
+                    pass                                           # (a world of one rank needs no process group: the collectives fall away)
+                step.capture(loader, warmup=2)
+                launch = "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
+            except Exception as e:                                 # noqa: BLE001 -- a runtime that cannot capture collectives
+                print("rank %d: graph capture of the sharded step failed (%r); static shapes, eager launches" % (rank, e), file=sys.stderr)
+                step.graph = None
+
+        def one():
+            step(next(loader))
+            cnt = sampler._bufs["counts"]
+            edges_dev.add_(cnt[4::10].sum())
+    else:
+        sampler = sh.ShardedPoissonBanditSampler(g, cfg["fanouts"], eta=0.1, seed=7)
+        step = sh.ShardedTrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"])
+        launch = "eager, routed exchanges (one host sync per exchange)"
+
+        def one():
+            step(next(loader))
+            edges_dev.add_(sum(b.num_edges() for b in step.last["mfgs"]))
     for _ in range(args.warmup):
-        step(next(loader))
+        one()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    edges_dev.zero_()
     t1 = time.perf_counter()
-    edges = 0
     for _ in range(args.steps):
-        step(next(loader))
-        edges += sum(b.num_edges() for b in step.last["mfgs"])
+        one()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
-    t = torch.tensor([dt, float(edges)], dtype=torch.float64, device=dev)
+    edges = float(edges_dev.item())
+    t = torch.tensor([dt, edges], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, edges = float(tmax[0]), float(tsum[1])
     sampler.check_errors()
+    roof = None
+    if static and rank == 0 and not args.no_roofline:
+        # the dominant library kernel of the sampler, timed with HIP events over a few steps launched kernel by kernel
+        # (every rank must take part in the steps: the others run them too, below)
+        timer = roofline.KernelTimer()
+        timer.enable("k_bin_scatter")
+    n_roof = 0 if (not static or args.no_roofline) else 6
+    if n_roof:
+        saved, step.graph = step.graph, None
+        alg = 0.0
+        for _ in range(n_roof):
+            step(next(loader))
+            loss, sizes = step.finish()
+            alg += sum(roofline.algorithmic_bytes("k_bin_scatter", dict(S=z["S"], E=z["E"], C=0, K=z["K"], B=z["B"])) for z in sizes)
+        step.graph = saved
+        if rank == 0:
+            tm = timer.read().get("k_bin_scatter")
+            timer.enable("off")
+            if tm:
+                ach = alg / tm["launches"] / (tm["avg_us"] * 1e-6) / 1e9
+                roof = {"bound": "hbm", "kernel": "k_bin_scatter", "achieved": ach, "peak": roofline.HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach / roofline.HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": tm["avg_us"], "launches": tm["launches"],
+                        "algorithmic_bytes_per_launch": alg / tm["launches"],
+                        "note": "this rank's shard of the frontier; the step's other cost is the exchanges (bytes_per_rank_per_step)"}
     if rank == 0:
-        print(json.dumps({
+        out = {
             "metric": "steps/sec (train step over destination-range shards, batch-%d equivalents), %s-like" % (cfg["batch"], args.config),
             "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "%s-like Chung-Lu graph |V|=%d, 3-layer SAGE hidden %d, sharded poisson-bandit (keyed draws) fanouts %s, "
                                    "batch %d per GPU" % (args.config, ip.numel() - 1, hidden, "/".join(map(str, cfg["fanouts"])), cfg["batch"]),
-                       "parallelism": "destination-range shards x%d (partials all-to-all, histogram all-reduce, kept-list all-gather, halo "
-                                      "gathers, gradient all-reduce)" % world,
-                       "launch": "eager (one host sync per exchange)", "global_batch": cfg["batch"] * world},
-            "sampled_edges_per_sec": edges / dt, "setup_s": t_setup}), flush=True)
+                       "parallelism": ("destination-range shards x%d (per layer ONE dense int64 [2,|V|] all-reduce; halo rows as capacity-sized "
+                                       "all-reduces; gradient, EXP3 row-sum and loss all-reduces)" % world) if static else
+                                      ("destination-range shards x%d (partials all-to-all, histogram all-reduce, kept-list all-gather, halo "
+                                       "gathers, gradient all-reduce)" % world),
+                       "launch": launch, "global_batch": cfg["batch"] * world},
+            "sampled_edges_per_sec": edges / dt, "setup_s": t_setup}
+        if static:
+            out["bytes_per_rank_per_step"] = int(step.bytes_per_step)
+            out["roofline"] = roof
+        print(json.dumps(out), flush=True)
+    if static:
+        step.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

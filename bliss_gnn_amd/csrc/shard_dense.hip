@@ -93,14 +93,20 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_cand_count(const long long* __res
   sd_block_count(V, block_cnt, [&](int v) { return dense[(long long)V + v] != 0; });
 }
 
+// (the histogram is privatised in LDS like k_cand_number's: importances live in a narrow band -- sqrt of a sum of squared
+// fractions -- so a 4096-bin window + one counter for p == 0 catches them; plain global atomics on the few hot bins cost 70 us)
+#define SD_HWIN_LO 0x3000
+#define SD_HWIN_N 4096
 __global__ void __launch_bounds__(SD_TPB) k_sd_cand_write(const long long* __restrict__ dense, int V, int uniform_nodes,
                                                           const int* __restrict__ block_off, const int* __restrict__ total,
                                                           int* __restrict__ cand_nid, bf16_t* __restrict__ p, unsigned char* __restrict__ is_seed,
                                                           int* __restrict__ hist, LayerCounts* cnt, int cap_c, int* err) {
   __shared__ int sh[17];
+  __shared__ int lh[SD_HWIN_N + 1];
+  for (int i = threadIdx.x; i <= SD_HWIN_N; i += SD_TPB) lh[i] = 0;
   const int v = blockIdx.x * SD_TPB + threadIdx.x;
   const long long mark = v < V ? dense[(long long)V + v] : 0;
-  int tot, ex = block_excl_scan(mark != 0 ? 1 : 0, sh, &tot);
+  int tot, ex = block_excl_scan(mark != 0 ? 1 : 0, sh, &tot);          // (its barriers also cover the zeroing of lh)
   int bad = 0;
   if (mark != 0) {
     const int at = block_off[blockIdx.x] + ex;
@@ -110,8 +116,16 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_cand_write(const long long* __res
       if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;                       // bandit_sampler.py:79-81
       else pj = f2bf(sqrtf(bf2f(fixed_to_bf(raw, FRAC_SRC, &bad))));                  // :75 torch.sqrt(prob)
       cand_nid[at] = v; p[at] = pj; is_seed[at] = mark >= SD_SEED_MARK ? 1 : 0;
-      atomicAdd(&hist[pj & 0x7fff], 1);                 // the histogram bliss_poisson_scale reads (and zeroes)
+      const int bin = pj & 0x7fff;                      // the histogram bliss_poisson_scale reads (and zeroes)
+      if (bin == 0) atomicAdd(&lh[SD_HWIN_N], 1);
+      else if (bin >= SD_HWIN_LO && bin < SD_HWIN_LO + SD_HWIN_N) atomicAdd(&lh[bin - SD_HWIN_LO], 1);
+      else atomicAdd(&hist[bin], 1);
     } else bad |= BLISS_ERR_CAP_CAND;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= SD_HWIN_N; i += SD_TPB) {
+    const int c = lh[i];
+    if (c) atomicAdd(&hist[i == SD_HWIN_N ? 0 : SD_HWIN_LO + i], c);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int C = *total;
