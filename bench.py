@@ -409,13 +409,14 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
     static = not args.eager
     edges_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     if static:
-        sampler = ss.DenseShardedSampler(g, cfg["fanouts"], eta=0.1, seed=7)
+        caps = None
+        if os.environ.get("BLISS_SHARD_CALIBRATE", "1") != "0":     # capacities from observed sizes (a throw-away model / EXP3 state)
+            caps = ss.measure_caps(g, cfg["fanouts"], model, cfg["batch"], loader, steps=4, eta=0.1, seed=7, multilabel=cfg["multilabel"])
+        sampler = ss.DenseShardedSampler(g, cfg["fanouts"], eta=0.1, seed=7, fixed_caps=caps)
         step = ss.StaticShardedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"])
         launch = "static shapes, launched kernel by kernel (no host sync inside a step)"
-        if world == 1 or dist.get_backend() == "nccl":
+        if (world == 1 or dist.get_backend() == "nccl") and os.environ.get("BLISS_SHARD_GRAPH", "1") != "0":
             try:
-                if world == 1 and not dist.is_initialized():
-                    pass                                           # (a world of one rank needs no process group: the collectives fall away)
                 step.capture(loader, warmup=2)
                 launch = "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
             except Exception as e:                                 # noqa: BLE001 -- a runtime that cannot capture collectives

@@ -209,10 +209,19 @@ class _HipShardOps:
         """Capacities per sampling layer from the GLOBAL sizes (the kept list of a layer is global; a rank's seeds are a
         subset of the global seed list)."""
         eng, caps, s = self.eng, [], int(s_global)
-        for f in fanouts:
+        fixed = getattr(self, "fixed_caps", None)          # (shard_static: capacities calibrated from observed sizes, agreed by all ranks)
+        for n, f in enumerate(fanouts):
             k = min(eng.V, 2 * (int(f) + s) + 64)
-            caps.append(dict(S=s, C=eng.V, K=k, B=int(min(max(eng.Eg, 1), max(1 << 16, 64 * k)))))
+            b = int(min(max(eng.Eg, 1), max(1 << 16, 64 * k)))
+            if fixed is not None and len(fixed) == len(fanouts):
+                k, b = min(k, int(fixed[n]["K"])), min(b, int(fixed[n]["B"]))
+            caps.append(dict(S=s, C=eng.V, K=k, B=b))
             s = k
+        if fixed is not None and len(fixed) == len(fanouts):
+            if eng.caps is None or len(eng.caps) != len(caps) or any(a[x] != b[x] for a, b in zip(eng.caps, caps) for x in ("S", "K", "B")):
+                eng.caps, eng.ws = caps, None
+            eng._ensure(int(s_global), fanouts)
+            return
         if eng.caps is None or any(a[x] < b[x] for a, b in zip(eng.caps, caps) for x in ("S", "K", "B")) or len(eng.caps) != len(caps):
             eng.caps, eng.ws = caps, None
         eng._ensure(int(s_global), fanouts)

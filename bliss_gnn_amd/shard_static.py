@@ -42,7 +42,8 @@ class DenseShardedSampler:
     ops with true sizes (host syncs) -- the REFERENCE FORM of the exchange, used to test it.  ``ops=None``: the static-shape
     HIP path (``enqueue`` / ``sample_blocks``): capacity-sized buffers, sizes on the device, graph-capturable."""
 
-    def __init__(self, shard, nodes_per_layer, eta=0.4, importance_sampling=True, seed=0, model="sage", group=None, ops=None):
+    def __init__(self, shard, nodes_per_layer, eta=0.4, importance_sampling=True, seed=0, model="sage", group=None, ops=None,
+                 fixed_caps=None):
         self.g, self.nodes_per_layer, self.eta = shard, list(nodes_per_layer), eta
         self.seed, self.group, self.step = int(seed), group, 0
         self.world, self.rank = shard.world, shard.rank
@@ -50,6 +51,8 @@ class DenseShardedSampler:
         self._delta_f = float(torch.tensor(self.delta, dtype=torch.float32))
         self.static = ops is None
         self.ops = ops if ops is not None else _HipShardOps(shard, len(self.nodes_per_layer), eta, importance_sampling, model)
+        if fixed_caps is not None:
+            self.ops.fixed_caps = [dict(c) for c in fixed_caps]
         self.trace = []
         self._bufs = None
         self.bytes_per_step = 0
@@ -203,6 +206,15 @@ class DenseShardedSampler:
         self.trace = [dict(C=r.C, scale=(float(r.c), bool(r.all_one), int(r.iters))) for r in recs]
         return [dict(S=int(b["nloc_host"][n]), E=c.E, K=c.K, B=c.B) for n, c in enumerate(cnts)]
 
+    def finish_nothrow(self):
+        """finish() for diagnostics: sizes and the per-layer error words, no exception."""
+        b = self._bufs
+        b["counts_host"].copy_(b["counts"]); b["nloc_host"].copy_(b["n_local"])
+        torch.cuda.current_stream().synchronize()
+        raw = b["counts_host"].numpy().tobytes()
+        cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(len(self.nodes_per_layer))]
+        return [dict(S=int(b["nloc_host"][n]), E=c.E, K=c.K, B=c.B, err=c.err) for n, c in enumerate(cnts)]
+
     def sample_blocks(self, seeds_g, step=None):
         if not self.static:
             return self.sample_blocks_generic(seeds_g, step)
@@ -255,8 +267,77 @@ class _HaloAllReduce(torch.autograd.Function):
         return gf.to(g.dtype), None
 
 
+# Zero-filled buffers inside the (captured) step come from a FILL KERNEL, never from torch.zeros / zero_(): those are
+# hipMemsetAsync, and memset nodes of a captured HIP graph were observed to leave their buffer stale on replay (ROCm 7.2; the
+# same finding as csrc/sampler.hip:k_seg_scan and csrc/shard_dense.hip:k_sd_zero).  That includes the zero buffers autograd
+# creates on its own -- the backward of x[idx] / index_select / gather / nll_loss is "zeros, then scatter-add": replayed with a
+# stale buffer the gradients of earlier steps pile up and the parameters overflow within a few steps (seen on the Reddit-like
+# step with calibrated capacities).  Hence the three small autograd Functions below and the one-hot cross-entropy in _body.
+def _zeros(shape, dtype, device):
+    return torch.empty(shape, dtype=dtype, device=device).fill_(0)
+
+
+class _TakeRows(torch.autograd.Function):
+    """x[idx] (idx may repeat); backward: fill-kernel zeros + index_add_."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return torch.index_select(x, 0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gx = _zeros((ctx.n,) + tuple(g.shape[1:]), g.dtype, g.device)
+        gx.index_add_(0, idx, g.contiguous())
+        return gx, None
+
+
+class _PlaceRows(torch.autograd.Function):
+    """out = zeros[n_rows]; out[idx[i]] = h[i], rows with idx == n_rows (the sink) dropped.  Backward: g[idx] (the sink: 0)."""
+
+    @staticmethod
+    def forward(ctx, h, idx, n_rows):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = int(n_rows)
+        out = _zeros((ctx.n_rows + 1, h.shape[1]), h.dtype, h.device)
+        out.index_copy_(0, idx, h)
+        return out[:ctx.n_rows]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gp = torch.empty((ctx.n_rows + 1,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        gp[:ctx.n_rows] = g
+        gp[ctx.n_rows:].fill_(0)
+        return torch.index_select(gp, 0, idx), None, None
+
+
+def _xdev_of(t, group=None):
+    return t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def halo_all_reduce(buf, group=None):
     return _HaloAllReduce.apply(buf, group)
+
+
+def measure_caps(shard, nodes_per_layer, model, batch, loader, steps=4, eta=0.4, seed=0, multilabel=False, group=None,
+                 k_margin=1.4, b_margin=2.0):
+    """Static capacities for ``DenseShardedSampler(fixed_caps=...)`` from ``steps`` steps of a THROW-AWAY copy of the model and
+    sampler state: the run that is measured (and possibly captured) afterwards starts from untouched parameters and EXP3 rows,
+    and its first launches happen inside ``capture``'s warm-up -- see StaticShardedTrainStep.calibrate for the in-place form."""
+    import copy
+    tmp_sampler = DenseShardedSampler(shard, nodes_per_layer, eta=eta, seed=seed, group=group)
+    tmp_step = StaticShardedTrainStep(shard, tmp_sampler, copy.deepcopy(model), batch, multilabel=multilabel, group=group)
+    tmp_step.calibrate(loader, steps=steps, k_margin=k_margin, b_margin=b_margin)
+    caps = tmp_sampler.ops.fixed_caps
+    tmp_step.close()
+    del tmp_step, tmp_sampler
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    return caps
 
 
 class StaticShardedTrainStep:
@@ -309,21 +390,19 @@ class StaticShardedTrainStep:
                 k_dev = blk._counts_dev[3]
                 valid = (torch.arange(cap_k, device=nid.device) < k_dev) & (nid >= lo) & (nid < hi)
                 rows = g.ndata_owned["features"][(nid.long() - lo).clamp(0, n_own - 1)]
-                buf = torch.where(valid[:, None], rows, torch.zeros((), dtype=rows.dtype, device=rows.device))   # (+0 bits: x * 0 can be -0)
+                buf = torch.where(valid[:, None], rows, 0.0)          # (+0 bits: x * 0 can be -0, and the words are summed as integers)
                 h_src = halo_all_reduce(buf.detach(), grp)
             else:                                                  # the rows I computed, at their positions of this block's source list
                 prev = blocks[l - 1]
                 cap_s = prev.num_dst_nodes()
                 n_prev = n_local[L - l]                            # block l-1 <-> sampling layer L-l
                 idx = torch.where(torch.arange(cap_s, device=h.device) < n_prev, prev.dst_pos.long(), torch.full((), cap_k, device=h.device))
-                buf = torch.zeros(cap_k + 1, h.shape[1], dtype=h.dtype, device=h.device).index_copy(0, idx, h)[:cap_k]
-                h_src = halo_all_reduce(buf, grp)
+                h_src = halo_all_reduce(_PlaceRows.apply(h, idx, cap_k), grp)
             halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
             blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
-            # (index_select, not h_src[idx]: the padding entries all point at row 0, and advanced indexing's backward sorts and
-            # serialises duplicate indices -- 0.94 ms per layer on the Reddit-like step; index_select's is an atomic index_add,
-            # and the duplicates carry zero gradients, so the sum stays exact)
-            h = layer(blk, (h_src, torch.index_select(h_src, 0, blk.dst_pos.long())), edge_weight=blk.edata["edge_weights"])
+            # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
+            # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
+            h = layer(blk, (h_src, _TakeRows.apply(h_src, blk.dst_pos.long())), edge_weight=blk.edata["edge_weights"])
             if l < L - 1:
                 h = model.dropout(model.activation(h))             # :330-332
         self._halo_bytes = halo_bytes
@@ -344,8 +423,10 @@ class StaticShardedTrainStep:
         if self.multilabel:
             per_row = torch.nn.functional.binary_cross_entropy_with_logits(pred.float(), y.float(), reduction="none").sum(1)
             scale = 1.0 / (n_global * pred.shape[1])
-        else:
-            per_row = torch.nn.functional.cross_entropy(pred.float(), y, reduction="none")
+        else:                                                  # cross-entropy through a one-hot product (nll_loss's backward is zeros + scatter)
+            logp = torch.log_softmax(pred.float(), 1)
+            onehot = torch.arange(pred.shape[1], device=pred.device)[None, :] == y[:, None]
+            per_row = -(logp * onehot).sum(1)
             scale = 1.0 / n_global
         loss_sum = (per_row * mask).sum()                                                         # padding rows: no loss, no gradient
         self.opt.zero_grad(set_to_none=True)
@@ -369,6 +450,25 @@ class StaticShardedTrainStep:
         else:
             self._body()
         return self.loss_dev
+
+    def calibrate(self, loader, steps=4, k_margin=1.4, b_margin=2.0):
+        """Static capacities from observed sizes instead of the worst-case formula of shard._HipShardOps.set_caps (2 (fanout + S)
+        kept nodes per layer): ``steps`` eager static steps, the largest K and B per layer over all ranks (all-reduce MAX), times
+        a margin.  Halo buffers, padded GEMM rows and the bytes that cross xGMI shrink with them; a later step that exceeds a
+        capacity raises the kernels' capacity error bits (``finish`` / ``check_errors``)."""
+        L = len(self.sampler.nodes_per_layer)
+        mx = torch.zeros(L, 2, dtype=torch.int64, device=self.g.device)
+        for _ in range(steps):
+            self(next(loader))
+            _, sizes = self.finish()
+            mx = torch.maximum(mx, torch.tensor([[z["K"], z["B"]] for z in sizes], dtype=torch.int64, device=mx.device))
+        if self.g.world > 1:
+            x = mx.to(_xdev_of(mx, self.group))
+            dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.group)
+            mx = x.to(mx.device)
+        up = lambda x, m: (int(x) + m - 1) // m * m
+        self.sampler.ops.fixed_caps = [dict(K=up(k_margin * int(k) + 256, 64), B=up(b_margin * int(b) + 4096, 1024)) for k, b in mx.tolist()]
+        self.sampler._bufs = None                                  # re-sized on the next enqueue
 
     def capture(self, loader, warmup=2):
         """Warm-up steps on a side stream, then record the step -- sampler, collectives, model, Adam, EXP3 -- into one HIP graph

@@ -170,7 +170,7 @@ def test_static_sharded_step_replays_from_one_graph(cuda):
         ip, ix, ei, _, _, feats, labels = _problem()
         bounds = sh.partition_by_in_edges(ip, 1)
         gen = torch.Generator().manual_seed(11)
-        batches = [torch.randperm(V, generator=gen)[:BATCH].to(torch.int32).to(cuda) for _ in range(7)]
+        batches = [torch.randperm(V, generator=gen)[:BATCH].to(torch.int32).to(cuda) for _ in range(9)]
         outs = []
         for graphed in (False, True):
             g = sh.GraphShard.from_global(ip, ix, ei, bounds, 0, device=cuda, ndata={"features": feats, "labels": labels})
@@ -180,6 +180,8 @@ def test_static_sharded_step_replays_from_one_graph(cuda):
             step = ss.StaticShardedTrainStep(g, sampler, model, BATCH, lr=0.002)
             it = iter(batches)
             losses = []
+            step.calibrate(it, steps=2)                     # capacities from observed sizes (both runs: the same two batches)
+            assert sampler.ops.fixed_caps is not None and sampler.ops.eng.caps[0]["K"] <= 2 * (FAN[-1] + BATCH) + 64
             if graphed:
                 step.capture(it, warmup=2)                  # batches 0, 1 eagerly, batch 2 by the first replay
                 assert step.graph is not None
