@@ -44,7 +44,7 @@ def block_records(src_nid, dst_nid, src, dst, eid, w, q):
     return {(a, b): (int(e), x, y) for a, b, e, x, y in zip(s, d, eid.tolist(), bits(w), bits(q))}
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, exchange="routed"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bliss_gnn_amd import shard as sh
@@ -53,7 +53,11 @@ def _worker(rank, world, port, outdir):
     bounds = sh.partition_by_in_edges(ip, world)
     g = sh.GraphShard.from_global(ip, ix, ei, bounds, rank)
     ops = OracleShardOps(g, len(FAN), ETA)
-    sampler = sh.ShardedPoissonBanditSampler(g, FAN, eta=ETA, seed=SEED, ops=ops)
+    if exchange == "dense":         # shard_static.py: ONE dense int64 [2, |V|] all-reduce per layer instead of the three routed exchanges
+        from bliss_gnn_amd import shard_static as ss
+        sampler = ss.DenseShardedSampler(g, FAN, eta=ETA, seed=SEED, ops=ops)
+    else:
+        sampler = sh.ShardedPoissonBanditSampler(g, FAN, eta=ETA, seed=SEED, ops=ops)
     out = []
     for step, seeds in enumerate(batches):
         inp, outp, blocks = sampler.sample_blocks(seeds, step=step)
@@ -89,12 +93,12 @@ def _oracle_run():
     return og, steps
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_sampler_matches_keyed_oracle(world):
+@pytest.mark.parametrize("world,exchange", [(2, "routed"), (3, "routed"), (2, "dense"), (3, "dense")])
+def test_sharded_sampler_matches_keyed_oracle(world, exchange):
     port = _free_port()
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_worker, args=(r, world, port, outdir)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, outdir, exchange)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -168,3 +172,42 @@ def test_gather_rows_forward_and_reduce_scatter_backward():
     assert torch.equal(a["full"][b["pos"]], torch.arange(8, dtype=torch.float32).reshape(-1, 2) + 10)
     wsum = torch.arange(14, dtype=torch.float32).reshape(7, 2) * 3                        # (1 + 2) x the base weights
     assert torch.equal(a["grad"], wsum[a["pos"]]) and torch.equal(b["grad"], wsum[b["pos"]])
+
+
+def _halo_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bliss_gnn_amd import shard_static as ss
+    n_total, F_ = 7, 4
+    pos = torch.tensor([0, 3, 4] if rank == 0 else [1, 2, 5, 6])
+    gen = torch.Generator().manual_seed(5 + rank)
+    rows = (torch.randn(pos.numel(), F_, generator=gen) * 3).bfloat16().requires_grad_()      # (negative values too: -x, and the zeros stay +0)
+    buf = ss._PlaceRows.apply(rows, pos, n_total)                                             # my rows at their positions, zeros elsewhere
+    full = ss.halo_all_reduce(buf)
+    wgt = (torch.arange(n_total * F_, dtype=torch.float32).reshape(n_total, F_) * (rank + 1)).bfloat16()
+    (full.float() * wgt.float()).sum().backward()
+    taken = ss._TakeRows.apply(full.detach().requires_grad_(), torch.tensor([2, 2, 0]))
+    torch.save(dict(full=full.detach(), rows=rows.detach(), grad=rows.grad, pos=pos, taken=taken.detach()), os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_all_reduce_is_exact_forward_and_sums_gradients_backward():
+    """shard_static's halo exchange: the sum of the ranks' zero-padded buffers, sent as int32 words, is the full input bit for bit;
+    the gradient of a row is the sum over the ranks that consumed it."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_halo_worker, args=(r, world, port, outdir)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        a, b = (torch.load(os.path.join(outdir, f"r{r}.pt"), weights_only=False) for r in range(world))
+    bits = lambda t: t.view(torch.int16)
+    assert torch.equal(bits(a["full"]), bits(b["full"]))
+    assert torch.equal(bits(a["full"][a["pos"]]), bits(a["rows"])) and torch.equal(bits(a["full"][b["pos"]]), bits(b["rows"]))
+    wsum = (torch.arange(28, dtype=torch.float32).reshape(7, 4).bfloat16().float() + torch.arange(28, dtype=torch.float32).reshape(7, 4).mul(2).bfloat16().float())
+    assert torch.allclose(a["grad"].float(), wsum[a["pos"]], rtol=2 ** -7) and torch.allclose(b["grad"].float(), wsum[b["pos"]], rtol=2 ** -7)
+    assert torch.equal(bits(a["taken"]), bits(a["full"][torch.tensor([2, 2, 0])]))
