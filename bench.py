@@ -46,9 +46,11 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: run the replica exchange path (gradient all-reduce, EXP3 all-gather + apply) on a world of "
                          "one rank -- what the multi-GPU step costs per GPU before any communication time")
-    ap.add_argument("--dist", default="replicas", choices=["replicas", "shards"],
-                    help="multi-GPU layout: replicas (whole graph per rank, graph-captured step; the default) or destination-range "
-                         "shards (bliss_gnn_amd/shard.py: the north star's split; eager launches); with one GPU, shards = a world of one rank")
+    ap.add_argument("--dist", default="auto", choices=["auto", "replicas", "shards"],
+                    help="multi-GPU layout.  shards: destination-range shards, the north star's split (bliss_gnn_amd/shard_static.py: "
+                         "static shapes, dense exchanges, one HIP graph per step; --eager: the routed step of shard.py); replicas: whole "
+                         "graph per rank, graph-captured pipelined step.  auto (default): shards for --gpus > 1 (SAGE, poisson-bandit), "
+                         "the single-GPU step for --gpus 1.  With one GPU, shards = a world of one rank")
     ap.add_argument("--mode", default="train", choices=["train", "inference"],
                     help="inference: time SAGE.inference -- layer-wise full-neighbour evaluation of ALL nodes (model.py:335-383), the one "
                          "whole-graph SpMM of the reference -- with its own roofline")
@@ -123,6 +125,8 @@ def main():
                          "launcher)" % (args.gpus, world))
     if args.dry_run:
         return dry_run(args, rank, world)
+    if args.dist == "auto":
+        args.dist = "shards" if (world > 1 and args.model == "sage" and args.sampler == "poisson-bandit" and args.mode == "train") else "replicas"
     force_dist = (args.force_dist or args.dist == "shards") and world == 1
     if world > 1 or force_dist:
         from bliss_gnn_amd.dist import want_hw_queues
