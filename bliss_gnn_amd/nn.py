@@ -540,8 +540,15 @@ class GraphConv(nn.Module):
 
     def forward(self, graph, feat, weight=None, edge_weight=None):
         n_dst = graph.num_dst_nodes()
-        out_deg = torch.zeros(graph.num_src_nodes(), dtype=torch.int32, device=feat.device)
-        out_deg.index_add_(0, graph.src, torch.ones_like(graph.src))
+        src, ones = graph.src, None
+        if getattr(graph, "_nnz_ptr", 0) and getattr(graph, "_counts_dev", None) is not None:
+            # capacity-padded (static-shape) block, round 3: only the first B edges exist (B on the device: LayerCounts::B); the
+            # entries behind them are stale and must neither count nor index.  Padding rows have no edges: degree 0 -> clamp 1.
+            valid = torch.arange(src.numel(), device=feat.device) < graph._counts_dev[4]
+            src, ones = torch.where(valid, src, 0), valid.to(torch.int32)
+        # (a fill kernel, not torch.zeros: memset nodes of a captured HIP graph were seen stale on replay)
+        out_deg = torch.empty(graph.num_src_nodes(), dtype=torch.int32, device=feat.device).fill_(0)
+        out_deg.index_add_(0, src, torch.ones_like(src) if ones is None else ones)
         norm_src = out_deg.clamp(min=1).to(feat.dtype).pow(-0.5)
         feat_src = feat * norm_src[:, None]
         w = self.weight
