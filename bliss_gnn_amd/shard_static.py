@@ -228,9 +228,21 @@ class DenseShardedSampler:
     # ---------------------------------------------------------------- EXP3 (owner-local update, global norm)
     def exp3(self, mfgs, g=None):
         """bandit_sampler.py:251-267 on the owned in-edges of every block, then the global L1 renormalisation."""
-        for idx, mfg in enumerate(mfgs):
-            self.ops.exp3_update(mfg, mfg.srcdata["embed_norm"], self._delta_f)
-            self.ops.normalize(idx, self.group)
+        ops = self.ops
+        for mfg in mfgs:
+            ops.exp3_update(mfg, mfg.srcdata["embed_norm"], self._delta_f)
+        if not hasattr(ops, "row_sum"):                          # (test doubles: one normalisation per layer)
+            for idx in range(len(mfgs)):
+                ops.normalize(idx, self.group)
+            return
+        # the layers' rows are disjoint: ONE all-reduce of all exact row sums, then the normalisations
+        L = len(mfgs)
+        limbs = _all_reduce(ops.row_sum[:L].clone(), self.group)
+        st = torch.cuda.current_stream().cuda_stream
+        for idx in range(L):
+            _lib.check(_lib.lib.bliss_exp3_normalize_global(ops.w_pos[idx].data_ptr(), self.g.num_edges(), ops.row_sum[idx].data_ptr(),
+                                                            limbs[idx].data_ptr(), ops.scratch[idx].data_ptr(), ops.norms[idx:].data_ptr(), st),
+                       "bliss_exp3_normalize_global")
 
     def check_errors(self):
         if hasattr(self.ops, "check_errors"):
@@ -242,6 +254,37 @@ class DenseShardedSampler:
 
 
 # ------------------------------------------------------------------------------------------- the model step
+def _reduce_rows_(out, group):
+    """In-place sum over the ranks of a zero-padded bf16 row buffer, as int32 words (exact: one non-zero contributor per word)."""
+    if (out.shape[1] * out.element_size()) % 4 == 0 and out.is_contiguous():
+        _all_reduce(out.view(torch.int32), group)
+        return out
+    f = out.float()                                              # odd row length: fp32 carries bf16 exactly
+    _all_reduce(f, group)
+    return f.to(out.dtype)
+
+
+class _PlaceAndReduce(torch.autograd.Function):
+    """_PlaceRows + the halo all-reduce in one node (no copy in between): out = sum over ranks of (zeros; out[idx[i]] = h[i])."""
+
+    @staticmethod
+    def forward(ctx, h, idx, n_rows, group):
+        ctx.save_for_backward(idx)
+        ctx.n_rows, ctx.group = int(n_rows), group
+        out = _zeros((ctx.n_rows + 1, h.shape[1]), h.dtype, h.device)
+        out.index_copy_(0, idx, h)
+        return _reduce_rows_(out, group)[:ctx.n_rows]
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gp = torch.empty((ctx.n_rows + 1,) + tuple(g.shape[1:]), dtype=torch.float32, device=g.device)
+        gp[:ctx.n_rows] = g
+        gp[ctx.n_rows:].fill_(0)
+        _all_reduce(gp, ctx.group)                               # a row's gradient: the sum over the ranks that consumed it
+        return torch.index_select(gp, 0, idx).to(g.dtype), None, None, None
+
+
 class _HaloAllReduce(torch.autograd.Function):
     """Block inputs over all ranks: every rank wrote the rows it owns into a zero buffer of the block's capacity; the sum of
     the buffers is the full input.  Sent as int32 words (two bf16 each: x + 0 + .. + 0 is exact and an integer is a type both
@@ -364,6 +407,16 @@ class StaticShardedTrainStep:
         self.graph = None
         self.last = {}
         self.bytes_per_step = 0
+        self._aranges = {}
+
+    def _arange(self, n):
+        """0 .. n-1 (int64) on the device, created once per length: five launches less inside the step."""
+        t = self._aranges.get(int(n))
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                return torch.arange(int(n), device=self.g.device)
+            t = self._aranges[int(n)] = torch.arange(int(n), device=self.g.device)
+        return t
 
     def _gather_seeds(self):
         if self.g.world == 1:
@@ -388,16 +441,16 @@ class StaticShardedTrainStep:
             if l == 0:                                             # train_lightning.py:138, owner side: my feature rows, zeros elsewhere
                 nid = blk.srcdata[NID]
                 k_dev = blk._counts_dev[3]
-                valid = (torch.arange(cap_k, device=nid.device) < k_dev) & (nid >= lo) & (nid < hi)
+                valid = (self._arange(cap_k) < k_dev) & (nid >= lo) & (nid < hi)
                 rows = g.ndata_owned["features"][(nid.long() - lo).clamp(0, n_own - 1)]
                 buf = torch.where(valid[:, None], rows, 0.0)          # (+0 bits: x * 0 can be -0, and the words are summed as integers)
-                h_src = halo_all_reduce(buf.detach(), grp)
+                h_src = _reduce_rows_(buf, grp)                    # (fresh, no gradient: reduced in place)
             else:                                                  # the rows I computed, at their positions of this block's source list
                 prev = blocks[l - 1]
                 cap_s = prev.num_dst_nodes()
                 n_prev = n_local[L - l]                            # block l-1 <-> sampling layer L-l
-                idx = torch.where(torch.arange(cap_s, device=h.device) < n_prev, prev.dst_pos.long(), torch.full((), cap_k, device=h.device))
-                h_src = halo_all_reduce(_PlaceRows.apply(h, idx, cap_k), grp)
+                idx = torch.where(self._arange(cap_s) < n_prev, prev.dst_pos.long(), cap_k)
+                h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp)
             halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
             blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
             # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
@@ -409,7 +462,6 @@ class StaticShardedTrainStep:
         return h
 
     def _body(self):
-        from .shard import allreduce_gradients_sum
         g, grp = self.g, self.group
         self._gather_seeds()
         blocks = self.sampler.enqueue(self.seeds_g)
@@ -417,7 +469,7 @@ class StaticShardedTrainStep:
         last = blocks[-1]
         cap_s = last.num_dst_nodes()
         n_mine = self.sampler._bufs["n_local"][0]                                                 # (sampling layer 0 = the output block)
-        mask = torch.arange(cap_s, device=pred.device) < n_mine
+        mask = self._arange(cap_s) < n_mine
         y = g.ndata_owned["labels"][(last.dstdata[NID].long() - g.lo).clamp(0, g.hi - g.lo - 1)]  # :139
         n_global = self.batch * g.world
         if self.multilabel:
@@ -425,13 +477,13 @@ class StaticShardedTrainStep:
             scale = 1.0 / (n_global * pred.shape[1])
         else:                                                  # cross-entropy through a one-hot product (nll_loss's backward is zeros + scatter)
             logp = torch.log_softmax(pred.float(), 1)
-            onehot = torch.arange(pred.shape[1], device=pred.device)[None, :] == y[:, None]
+            onehot = self._arange(pred.shape[1])[None, :] == y[:, None]
             per_row = -(logp * onehot).sum(1)
             scale = 1.0 / n_global
         loss_sum = (per_row * mask).sum()                                                         # padding rows: no loss, no gradient
         self.opt.zero_grad(set_to_none=True)
         loss_sum.backward()
-        allreduce_gradients_sum(self.model, scale, grp)
+        self._allreduce_gradients(scale)
         self.opt.step()
         self.sampler.exp3(blocks)                                                                 # :469-471
         tot = loss_sum.detach().float().reshape(1).clone()
@@ -440,6 +492,22 @@ class StaticShardedTrainStep:
         self.last = dict(mfgs=blocks, pred=pred.detach())
         n_par = sum(p.numel() for p in self.model.parameters())
         self.bytes_per_step = self.sampler.bytes_per_step + self._halo_bytes + 4 * n_par + 4 * self.batch + 96 * 8 * len(blocks) + 4
+
+    def _allreduce_gradients(self, scale):
+        """Sum the gradients over the ranks and scale by 1 / global batch: ONE flat fp32 bucket (cat, cast, all-reduce, scale,
+        cast, one multi-tensor copy back) instead of a cast and a copy per parameter."""
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g_.reshape(-1) for g_ in grads]).float()
+        _all_reduce(flat, self.group)
+        flat = flat.mul_(scale).to(grads[0].dtype)
+        views, off = [], 0
+        for g_ in grads:
+            n = g_.numel()
+            views.append(flat[off:off + n].view_as(g_))
+            off += n
+        torch._foreach_copy_(grads, views)
 
     def __call__(self, my_seeds):
         """``my_seeds``: the ``batch`` seeds this rank contributes (ids it owns).  Returns the global mean loss (a device scalar
