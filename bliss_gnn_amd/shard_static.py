@@ -172,6 +172,8 @@ class DenseShardedSampler:
                                             n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
                                             c_ws.kept_map, cap["K"], V, cnt_ptr, nloc_ptr, b["scr_b"].data_ptr(), b["err"].data_ptr(), st),
                 "bliss_shard_select_kept")
+            # (measured and not kept: the block on a side stream beside the next layer's candidate work, own scratch set per layer --
+            # correct, but the forked graph replayed at 4.4 ms instead of 1.4: this runtime serialises branches of one graph badly)
             chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
                                       eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
             b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept, node_prob, cdev, t_indptr, t_edge = lay
