@@ -297,6 +297,8 @@ class GATv2(nn.Module):
             self.gatv2_layers.append(mk(num_hidden * heads[-2], num_classes, heads[-1], residual, None))       # :175-189
         else:
             self.gatv2_layers.append(mk(in_dim, num_classes, heads[-1], residual, None))
+        for l, layer in enumerate(self.gatv2_layers):              # the attention-dropout stream of layer l (nn.GATv2Conv._fused_state)
+            layer._drop_salt = l + 1
 
     def forward(self, blocks, inputs):
         h = inputs.bfloat16()

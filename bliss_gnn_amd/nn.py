@@ -828,11 +828,13 @@ class GATv2Conv(nn.Module):
 
     def _fused_state(self, device):
         """Device state of the fused kernels: the attention-dropout launch counter (uint64[2]: counter, ticket), its seed, and
-        the ticket of the d attn reduction."""
+        the ticket of the d attn reduction.  The seed is a function of torch's CUDA seed and of the layer's ordinal in its model
+        (``_drop_salt``, set by model.GATv2): the same seeds give the same masks run after run (round 3: it used to mix in
+        ``id(self)``, so two runs of one script trained differently)."""
         st = getattr(self, "_fstate", None)
         if st is None or st["ctr"].device != device:
             st = self._fstate = dict(ctr=torch.zeros(2, dtype=torch.int64, device=device), ticket=torch.zeros(1, dtype=torch.int32, device=device),
-                                     seed=(torch.cuda.initial_seed() ^ (0x9E3779B1 * (id(self) & 0xFFFF))) & 0xFFFFFFFF,
+                                     seed=(torch.cuda.initial_seed() ^ (0x9E3779B1 * (int(getattr(self, "_drop_salt", 0)) + 1))) & 0xFFFFFFFF,
                                      err=torch.zeros(1, dtype=torch.int32, device=device), row_ws=None)
         return st
 
