@@ -485,7 +485,8 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
                         "note": "this rank's shard of the frontier; the step's other cost is the exchanges (bytes_per_rank_per_step)"}
     if rank == 0:
         out = {
-            "metric": "steps/sec (train step over destination-range shards, batch-%d equivalents), %s-like" % (cfg["batch"], args.config),
+            "metric": "steps/sec (train step: sample_blocks + gather + SAGE fwd/bwd + Adam + exp3; destination-range shards, one step = "
+                      "%d seeds per GPU), %s-like" % (cfg["batch"], args.config),
             "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
