@@ -1,20 +1,23 @@
-// GATv2 message passing, one workgroup per DESTINATION row (round 3) -- custom_GATv2Conv.forward, model.py:82-99, and its
+// GATv2 message passing, one (virtual) workgroup per DESTINATION row (round 3) -- custom_GATv2Conv.forward, model.py:82-99, and its
 // backward by destination.  csrc/gat.hip runs the same arithmetic as five launches per direction that each re-gather the
 // 2 KB feature rows of every edge (logits: source + destination row; aggregation: source row again; backward: seven row
 // gathers per edge) and pass [B, H] tensors through memory in between: 760 us forward and 1.2 ms backward per step on the
-// Reddit-like config (profiles/r03_d_gat_step_timeline.txt).  Here a workgroup of 8 waves owns one destination i:
-//   forward   er_i stays in registers; pass 1 gathers el_j per in-edge -> logits e_ij[h] (stored: the reference returns them
-//             as "attention", model.py:108-110) and the per-head maximum; pass 2 is the edge softmax over the stored logits
-//             (exact per-destination sum like every copy_e_sum), with attention dropout (model.py:88) folded in; pass 3
-//             gathers el_j again (L2-warm) and accumulates  sum_j a_ij el_j.  Two row gathers per edge instead of three, one
-//             launch instead of five, no partial/fix-up pass (a row never leaves its workgroup).
-//   backward  (by destination) g_i = d rst_i and er_i in registers; pass 1: d a_ij = g_i . el_j and t = sum a d a; pass 2:
-//             d e_ij = a (d a - t) (softmax backward); pass 3: d er_i = sum_j d e_ij attn lrelu'(el_j + er_i) and this row's
-//             share of d attn.  The by-SOURCE half (d el_j: out-degrees are far more skewed) stays on the merge-style
-//             kernel of gat.hip, now with the aggregation's backward folded in.
+// Reddit-like config (profiles/r03_d_gat_step_timeline.txt).  Here a workgroup of 8 waves owns up to 256 in-edges of one
+// destination i (k_gat_segments: one 16-byte descriptor per virtual workgroup, longest first; a longer row is shared, see below):
+//   forward   edges in chunks of 64 (8 per wave): all row gathers of a chunk in flight at once, the rows kept PACKED IN REGISTERS
+//             (64 VGPRs); pass 1: logits e_ij[h] (stored: the reference returns them as "attention", model.py:108-110; kept in
+//             LDS for the next passes) and the per-head maximum; pass 2: the edge softmax over the logits in LDS (exact
+//             per-destination sum like every copy_e_sum), attention dropout (model.py:88) folded in; pass 3: sum_j a_ij el_j
+//             from the rows still in registers -- a row of <= 64 in-edges (most) is gathered ONCE; earlier chunks of a longer
+//             row are gathered a second time.  One launch instead of five, no partial / fix-up pass.
+//   backward  (by destination, same shape) g_i = d rst_i packed in registers, er_i in LDS; pass 1: d a_ij = g_i . el_j on
+//             v_dot2_f32_bf16 and t = sum a d a; pass 2: d e_ij = a (d a - t) (softmax backward); pass 3: d er_i = attn * sum_j
+//             d e_ij lrelu'(el_j + er_i) and the workgroup's share of d attn.  The by-SOURCE half (d el_j: out-degrees are far
+//             more skewed) stays on the merge-style kernel of gat.hip, with the aggregation's backward folded in.
 // The forward rounds exactly where gat.hip's kernels round (= where the reference's bf16 tensor ops round): the golden
 // fixtures of tests/golden/gat*_model_exp3.npz hold for both paths.  bf16 conversions use the hardware's
 // v_cvt_pk_bf16_f32 (round to nearest even, like common.cuh:f2bf on every finite input).
+// Where a workgroup's time goes is measured by the kernels themselves (bliss_gat_fused_stamps, scratch/gatbench.py).
 #include "common.cuh"
 #include "bliss_gnn.h"
 
@@ -93,11 +96,7 @@ struct GatFused {
   int* err;
 };
 
-// A wave's share of a row's edges, SWEEP = 64 * GF_WAVES edges at a time: lane l of wave w holds the source id of edge
-// base + l * GF_WAVES + w, fetched with ONE coalesced load per sweep; the loop over the wave's edges then reads the id with
-// v_readlane (wave-uniform, no dependent global load per edge) and keeps the rows of TWO edges in flight.
-// a row of one edge as the lane's NG column groups, still packed (two registers per group of four bf16): FOUR edges' rows are
-// kept in flight per wave -- the loop is bound by the latency of these gathers, not by their bytes
+// A row of one edge as the lane's NG column groups, still packed (two registers per group of four bf16).
 template <bool VEC4> struct RawGroup { uint2 u; };
 template <bool VEC4, int NG>
 __device__ __forceinline__ void ld_edge_raw(RawGroup<VEC4> (&r)[NG], const bf16_t* el, const int (&coff)[NG]) {
@@ -141,45 +140,6 @@ __device__ __forceinline__ void ld_wave_rows(RawGroup<VEC4> (&raw)[GF_EW][NG], c
     for (int j = GF_EW / 2; j < GF_EW; ++j)
       ld_edge_raw<VEC4, NG>(raw[j], feat + (long long)__builtin_amdgcn_readlane(my_s, lane0 + (j < last ? j : last)) * stride, coff);
   }
-}
-
-// per-edge, per-head coefficients ([nnz, H] bf16 arrays) of a sweep: lane l fetches those of ITS edge once (agent-scope loads:
-// another wave of the workgroup may have written them), the edge loop broadcasts them with v_readlane
-template <int NH>
-__device__ __forceinline__ void ld_edge_coefs(float (&cv)[NH], const bf16_t* arr, long long e, int H, bool valid) {
-  // one agent-scope load per edge where the H values form an aligned 2 / 4 / 8 / 16-byte unit (each atomic load is waited for)
-#pragma unroll
-  for (int h = 0; h < NH; ++h) cv[h] = 0.f;
-  if (!valid) return;
-  const bf16_t* q = arr + e * H;
-  if (NH >= 4 && H == 4) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cv[0] = bf2f((bf16_t)(v & 0xffffu)); cv[1 % NH] = bf2f((bf16_t)((v >> 16) & 0xffffu));
-    cv[2 % NH] = bf2f((bf16_t)((v >> 32) & 0xffffu)); cv[3 % NH] = bf2f((bf16_t)(v >> 48));
-  } else if (NH >= 8 && H == 8) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cv[0] = bf2f((bf16_t)(v & 0xffffu)); cv[1 % NH] = bf2f((bf16_t)((v >> 16) & 0xffffu));
-    cv[2 % NH] = bf2f((bf16_t)((v >> 32) & 0xffffu)); cv[3 % NH] = bf2f((bf16_t)(v >> 48));
-    cv[4 % NH] = bf2f((bf16_t)(w & 0xffffu)); cv[5 % NH] = bf2f((bf16_t)((w >> 16) & 0xffffu));
-    cv[6 % NH] = bf2f((bf16_t)((w >> 32) & 0xffffu)); cv[7 % NH] = bf2f((bf16_t)(w >> 48));
-  } else if (NH >= 2 && H == 2) {
-    const unsigned v = __hip_atomic_load(reinterpret_cast<const unsigned*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cv[0] = bf2f((bf16_t)(v & 0xffffu)); cv[1 % NH] = bf2f((bf16_t)(v >> 16));
-  } else {
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-      if (h < H) cv[h] = bf2f(__hip_atomic_load(q + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  }
-}
-__device__ __forceinline__ float bcast_f32(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
-// the coefficient of this lane's column group (head hd) out of the edge's H broadcast values
-template <int NH>
-__device__ __forceinline__ float pick_head(const float (&sv)[NH], int hd) {
-  float r = 0.f;
-#pragma unroll
-  for (int h = 0; h < NH; ++h) r = (h == hd) ? sv[h] : r;
-  return r;
 }
 
 
