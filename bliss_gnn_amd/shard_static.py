@@ -430,6 +430,19 @@ class StaticShardedTrainStep:
             dist.all_gather(parts, self.my_seeds.cpu(), group=self.group)
             self.seeds_g.copy_(torch.cat(parts))
 
+    def _fused_layer_ok(self, layer, h):
+        """The MFMA tail applies to an aggregate-first SAGEConv (in <= out) of the reference's kind: bf16 on the GPU, ReLU between
+        the layers, plain dropout, bias on fc_self, within the tile kernel's limits.  BLISS_SHARD_MFMA=0: library GEMMs."""
+        import os
+        from .nn import tile_gemm_ok
+        m = self.model
+        act = getattr(m, "activation", None)
+        relu = act in (torch.relu, torch.nn.functional.relu) or isinstance(act, torch.nn.ReLU)
+        return (os.environ.get("BLISS_SHARD_MFMA", "1") != "0" and relu and hasattr(m, "_dropout_state") and isinstance(m.dropout, torch.nn.Dropout)
+                and h.is_cuda and h.dtype == torch.bfloat16 and layer._in_src_feats <= layer._out_feats
+                and tile_gemm_ok(layer._in_src_feats, layer._out_feats) and layer.fc_self.bias is not None and layer.norm is None
+                and layer.activation is None and layer.feat_drop.p == 0)
+
     def _forward(self, blocks):
         from .nn import embed_norm
         g, model, grp = self.g, self.model, self.group
@@ -457,9 +470,22 @@ class StaticShardedTrainStep:
             blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
             # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
             # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
-            h = layer(blk, (h_src, _TakeRows.apply(h_src, blk.dst_pos.long())), edge_weight=blk.edata["edge_weights"])
-            if l < L - 1:
-                h = model.dropout(model.activation(h))             # :330-332
+            h_dst = _TakeRows.apply(h_src, blk.dst_pos.long())
+            if self._fused_layer_ok(layer, h_src):
+                # an aggregate-first layer's tail on the in-tree MFMA tiles (nn._SageDualLinear: fc_neigh(h_neigh) + fc_self(h_dst) +
+                # bias, ReLU and dropout in ONE launch, its backward on csrc/sage_bwd.hip) -- the true row count from the device
+                from .nn import _SageDualLinear, weighted_aggregate
+                last = l == L - 1
+                p = model.dropout.p if (model.training and not last) else 0.0
+                ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
+                agg = weighted_aggregate(blk, h_src, blk.edata["edge_weights"], mean=True)
+                rows_dev = n_local.data_ptr() + 4 * (L - 1 - l)
+                h, _ = _SageDualLinear.apply(agg, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias, not last, p, ctr, seed,
+                                             blk.num_dst_nodes(), rows_dev)
+            else:
+                h = layer(blk, (h_src, h_dst), edge_weight=blk.edata["edge_weights"])
+                if l < L - 1:
+                    h = model.dropout(model.activation(h))         # :330-332
         self._halo_bytes = halo_bytes
         return h
 
@@ -472,6 +498,7 @@ class StaticShardedTrainStep:
         cap_s = last.num_dst_nodes()
         n_mine = self.sampler._bufs["n_local"][0]                                                 # (sampling layer 0 = the output block)
         mask = self._arange(cap_s) < n_mine
+        pred = torch.where(mask[:, None], pred, 0.0)                                              # (rows beyond the count: whatever the layer left)
         y = g.ndata_owned["labels"][(last.dstdata[NID].long() - g.lo).clamp(0, g.hi - g.lo - 1)]  # :139
         n_global = self.batch * g.world
         if self.multilabel:
