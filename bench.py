@@ -417,19 +417,26 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
         if os.environ.get("BLISS_SHARD_CALIBRATE", "1") != "0":     # capacities from observed sizes (a throw-away model / EXP3 state)
             caps = ss.measure_caps(g, cfg["fanouts"], model, cfg["batch"], loader, steps=4, eta=0.1, seed=7, multilabel=cfg["multilabel"])
         sampler = ss.DenseShardedSampler(g, cfg["fanouts"], eta=0.1, seed=7, fixed_caps=caps)
-        step = ss.StaticShardedTrainStep(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"])
+        pipelined = os.environ.get("BLISS_SHARD_PIPELINE", "1") != "0"
+        cls = ss.PipelinedShardedTrainStep if pipelined else ss.StaticShardedTrainStep
+        step = cls(g, sampler, model, cfg["batch"], lr=0.002, multilabel=cfg["multilabel"])
         launch = "static shapes, launched kernel by kernel (no host sync inside a step)"
         if (world == 1 or dist.get_backend() == "nccl") and os.environ.get("BLISS_SHARD_GRAPH", "1") != "0":
             try:
                 step.capture(loader, warmup=2)
-                launch = "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
+                launch = ("three HIP graphs per step on two streams (static shapes): forward + EXP3 and the next batch's sampling with its "
+                          "dense all-reduces on the critical stream; loss, backward, gradient all-reduce and Adam beside them, on a "
+                          "communicator of their own") if pipelined else \
+                         "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
             except Exception as e:                                 # noqa: BLE001 -- a runtime that cannot capture collectives
                 print("rank %d: graph capture of the sharded step failed (%r); static shapes, eager launches" % (rank, e), file=sys.stderr)
                 step.graph = None
+        if pipelined and not step.primed:
+            step.prime(next(loader))
 
         def one():
             step(next(loader))
-            cnt = sampler._bufs["counts"]
+            cnt = sampler._slot_bufs(step.slot if pipelined else 0)["counts"]
             edges_dev.add_(cnt[4::10].sum())
     else:
         sampler = sh.ShardedPoissonBanditSampler(g, cfg["fanouts"], eta=0.1, seed=7)

@@ -121,11 +121,27 @@ class DenseShardedSampler:
                  n_local=torch.zeros(L, dtype=torch.int32, device=dev),
                  counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(), rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(),
                  nloc_host=torch.empty(L, dtype=torch.int32).pin_memory(), err_host=torch.empty(1, dtype=torch.int32).pin_memory())
+        b["slots"] = {0: b}                                       # slot 0 = the entries above; further slots: _slot_bufs
         self._bufs = b
         self.bytes_per_step = L * 2 * V * 8
         return b
 
-    def enqueue(self, seeds_g):
+    def _slot_bufs(self, slot=0):
+        """The per-batch outputs of ``enqueue`` exist once per slot (a pipelined loop holds two batches at a time: the one being
+        trained and the one being sampled); the candidate-side scratch is shared."""
+        b = self._bufs
+        if slot not in b["slots"]:
+            dev, L = self.g.device, len(self.nodes_per_layer)
+            caps = self.ops.eng.caps
+            b["slots"][slot] = dict(counts=torch.zeros(L * 10, dtype=torch.int32, device=dev), rec=torch.zeros(L, 10, dtype=torch.int32, device=dev),
+                                    seeds0=torch.zeros_like(b["seeds0"]), n_local=torch.zeros(L, dtype=torch.int32, device=dev),
+                                    seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
+                                    seed_pos=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
+                                    counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(),
+                                    rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
+        return b["slots"][slot]
+
+    def enqueue(self, seeds_g, slot=0):
         """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
         outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
         advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors."""
@@ -138,22 +154,23 @@ class DenseShardedSampler:
         fan = [self.nodes_per_layer[b] for b in order]
         S0 = int(seeds_g.numel())
         b = self._ensure_static(S0, fan)
+        sb = self._slot_bufs(slot)
         st = torch.cuda.current_stream().cuda_stream
         lib, chk = _lib.lib, _lib.check
         V = eng.V
-        b["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
+        sb["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
         eta_f, ome_f = float(np.float32(self.eta)), float(np.float32(1.0 - self.eta))
         bins = eng._bin_buffers()
         n_touched_ptr = bins["cursor"].data_ptr() + 4 * eng.n_bins
-        cur, n_seeds, n_seeds_dev = b["seeds0"], S0, 0
+        cur, n_seeds, n_seeds_dev = sb["seeds0"], S0, 0
         blocks = []
         for n, layer in enumerate(order):
             cap = eng.caps[n]
             cs, ws = cap["S"], eng.ws[n]
-            c_ws, c_out, lay, cnt_ptr, kept_nid = eng._layer_buffers(n, b["counts"], slot="dense")
-            seeds_l, seed_pos = b["seeds_l"][n], b["seed_pos"][n]
-            nloc_ptr = b["n_local"].data_ptr() + 4 * n
-            rec_ptr = b["rec"].data_ptr() + 40 * n
+            c_ws, c_out, lay, cnt_ptr, kept_nid = eng._layer_buffers(n, sb["counts"], slot=("dense", slot))
+            seeds_l, seed_pos = sb["seeds_l"][n], sb["seed_pos"][n]
+            nloc_ptr = sb["n_local"].data_ptr() + 4 * n
+            rec_ptr = sb["rec"].data_ptr() + 40 * n
             w_pos = ops.w_pos[layer]
             chk(lib.bliss_shard_local_seeds(cur.data_ptr(), n_seeds, n_seeds_dev, g.lo, g.hi, cs, seeds_l.data_ptr(), ws.cand_nid.data_ptr(),
                                             seed_pos.data_ptr(), nloc_ptr, b["err"].data_ptr(), st), "bliss_shard_local_seeds")
@@ -180,7 +197,7 @@ class DenseShardedSampler:
             blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos)
             blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
             blk._counts, blk._counts_dev, blk._layer = None, cdev, layer
-            blk._nnz_ptr = b["counts"].data_ptr() + 40 * n + 16
+            blk._nnz_ptr = sb["counts"].data_ptr() + 40 * n + 16
             blk._xcap = int(cap["B"])
             if t_indptr is not None:
                 blk._transposed = (t_indptr, t_edge)
@@ -191,15 +208,15 @@ class DenseShardedSampler:
         self._static_blocks = blocks
         return blocks
 
-    def finish(self):
+    def finish(self, slot=0):
         """After a synchronisation: true sizes per layer (sampling order) and the error check."""
-        b = self._bufs
-        b["counts_host"].copy_(b["counts"]); b["rec_host"].copy_(b["rec"]); b["nloc_host"].copy_(b["n_local"]); b["err_host"].copy_(b["err"])
+        b, eb = self._slot_bufs(slot), self._bufs
+        b["counts_host"].copy_(b["counts"]); b["rec_host"].copy_(b["rec"]); b["nloc_host"].copy_(b["n_local"]); eb["err_host"].copy_(eb["err"])
         torch.cuda.current_stream().synchronize()
         raw = b["counts_host"].numpy().tobytes()
         L = len(self.nodes_per_layer)
         cnts = [_lib.LayerCounts.from_buffer_copy(raw[40 * n: 40 * n + 40]) for n in range(L)]
-        bad = int(b["err_host"][0])
+        bad = int(eb["err_host"][0])
         for c in cnts:
             bad |= c.err
         if bad:
@@ -208,9 +225,9 @@ class DenseShardedSampler:
         self.trace = [dict(C=r.C, scale=(float(r.c), bool(r.all_one), int(r.iters))) for r in recs]
         return [dict(S=int(b["nloc_host"][n]), E=c.E, K=c.K, B=c.B) for n, c in enumerate(cnts)]
 
-    def finish_nothrow(self):
+    def finish_nothrow(self, slot=0):
         """finish() for diagnostics: sizes and the per-layer error words, no exception."""
-        b = self._bufs
+        b = self._slot_bufs(slot)
         b["counts_host"].copy_(b["counts"]); b["nloc_host"].copy_(b["n_local"])
         torch.cuda.current_stream().synchronize()
         raw = b["counts_host"].numpy().tobytes()
@@ -270,9 +287,9 @@ class _PlaceAndReduce(torch.autograd.Function):
     """_PlaceRows + the halo all-reduce in one node (no copy in between): out = sum over ranks of (zeros; out[idx[i]] = h[i])."""
 
     @staticmethod
-    def forward(ctx, h, idx, n_rows, group):
+    def forward(ctx, h, idx, n_rows, group, group_bwd=None):
         ctx.save_for_backward(idx)
-        ctx.n_rows, ctx.group = int(n_rows), group
+        ctx.n_rows, ctx.group = int(n_rows), (group if group_bwd is None else group_bwd)
         out = _zeros((ctx.n_rows + 1, h.shape[1]), h.dtype, h.device)
         out.index_copy_(0, idx, h)
         return _reduce_rows_(out, group)[:ctx.n_rows]
@@ -284,7 +301,7 @@ class _PlaceAndReduce(torch.autograd.Function):
         gp[:ctx.n_rows] = g
         gp[ctx.n_rows:].fill_(0)
         _all_reduce(gp, ctx.group)                               # a row's gradient: the sum over the ranks that consumed it
-        return torch.index_select(gp, 0, idx).to(g.dtype), None, None, None
+        return torch.index_select(gp, 0, idx).to(g.dtype), None, None, None, None
 
 
 class _HaloAllReduce(torch.autograd.Function):
@@ -411,6 +428,12 @@ class StaticShardedTrainStep:
         self.bytes_per_step = 0
         self._aranges = {}
 
+    def _group_bwd(self):
+        """The communicator of the collectives the BACKWARD pass issues (None: the forward's).  A loop that runs the backward
+        pass on a second stream beside the sampler gives it a communicator of its own: one RCCL communicator must see its
+        collectives in one order on every rank, which two streams do not guarantee."""
+        return getattr(self, "group_b", None)
+
     def _arange(self, n):
         """0 .. n-1 (int64) on the device, created once per length: five launches less inside the step."""
         t = self._aranges.get(int(n))
@@ -443,13 +466,13 @@ class StaticShardedTrainStep:
                 and tile_gemm_ok(layer._in_src_feats, layer._out_feats) and layer.fc_self.bias is not None and layer.norm is None
                 and layer.activation is None and layer.feat_drop.p == 0)
 
-    def _forward(self, blocks):
+    def _forward(self, blocks, slot=0):
         from .nn import embed_norm
         g, model, grp = self.g, self.model, self.group
         lo, hi = g.lo, g.hi
         n_own = hi - lo
         L = len(blocks)
-        n_local = self.sampler._bufs["n_local"]
+        n_local = self.sampler._slot_bufs(slot)["n_local"]
         h, halo_bytes = None, 0
         for l, (layer, blk) in enumerate(zip(model.layers, blocks)):
             cap_k = blk.num_src_nodes()
@@ -465,7 +488,7 @@ class StaticShardedTrainStep:
                 cap_s = prev.num_dst_nodes()
                 n_prev = n_local[L - l]                            # block l-1 <-> sampling layer L-l
                 idx = torch.where(self._arange(cap_s) < n_prev, prev.dst_pos.long(), cap_k)
-                h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp)
+                h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp, self._group_bwd())
             halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
             blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
             # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
@@ -489,14 +512,14 @@ class StaticShardedTrainStep:
         self._halo_bytes = halo_bytes
         return h
 
-    def _body(self):
-        g, grp = self.g, self.group
-        self._gather_seeds()
-        blocks = self.sampler.enqueue(self.seeds_g)
-        pred = self._forward(blocks)                                                              # train_lightning.py:138-141
+    def _loss_backward_step(self, blocks, pred, slot=0):
+        """Masked loss over this rank's output seeds, backward, gradient all-reduce, Adam, the global mean loss (the collectives of
+        this part go through ``_group_bwd()`` when the loop runs it beside the sampler)."""
+        g = self.g
+        grp = self._group_bwd() if self._group_bwd() is not None else self.group
         last = blocks[-1]
         cap_s = last.num_dst_nodes()
-        n_mine = self.sampler._bufs["n_local"][0]                                                 # (sampling layer 0 = the output block)
+        n_mine = self.sampler._slot_bufs(slot)["n_local"][0]                                      # (sampling layer 0 = the output block)
         mask = self._arange(cap_s) < n_mine
         pred = torch.where(mask[:, None], pred, 0.0)                                              # (rows beyond the count: whatever the layer left)
         y = g.ndata_owned["labels"][(last.dstdata[NID].long() - g.lo).clamp(0, g.hi - g.lo - 1)]  # :139
@@ -512,24 +535,31 @@ class StaticShardedTrainStep:
         loss_sum = (per_row * mask).sum()                                                         # padding rows: no loss, no gradient
         self.opt.zero_grad(set_to_none=True)
         loss_sum.backward()
-        self._allreduce_gradients(scale)
+        self._allreduce_gradients(scale, grp)
         self.opt.step()
-        self.sampler.exp3(blocks)                                                                 # :469-471
         tot = loss_sum.detach().float().reshape(1).clone()
         _all_reduce(tot, grp)
         self.loss_dev.copy_(tot * scale)
-        self.last = dict(mfgs=blocks, pred=pred.detach())
         n_par = sum(p.numel() for p in self.model.parameters())
         self.bytes_per_step = self.sampler.bytes_per_step + self._halo_bytes + 4 * n_par + 4 * self.batch + 96 * 8 * len(blocks) + 4
+        return pred.detach()
 
-    def _allreduce_gradients(self, scale):
+    def _body(self):
+        self._gather_seeds()
+        blocks = self.sampler.enqueue(self.seeds_g)
+        pred = self._forward(blocks)                                                              # train_lightning.py:138-141
+        pred = self._loss_backward_step(blocks, pred)
+        self.sampler.exp3(blocks)                                                                 # :469-471
+        self.last = dict(mfgs=blocks, pred=pred)
+
+    def _allreduce_gradients(self, scale, group=None):
         """Sum the gradients over the ranks and scale by 1 / global batch: ONE flat fp32 bucket (cat, cast, all-reduce, scale,
         cast, one multi-tensor copy back) instead of a cast and a copy per parameter."""
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
         if not grads:
             return
         flat = torch.cat([g_.reshape(-1) for g_ in grads]).float()
-        _all_reduce(flat, self.group)
+        _all_reduce(flat, self.group if group is None else group)
         flat = flat.mul_(scale).to(grads[0].dtype)
         views, off = [], 0
         for g_ in grads:
@@ -602,5 +632,143 @@ class StaticShardedTrainStep:
         import gc
         torch.cuda.synchronize()
         self.graph, self.last = None, {}
+        gc.collect()
+        torch.cuda.synchronize()
+
+
+
+class PipelinedShardedTrainStep(StaticShardedTrainStep):
+    """The static sharded step as a two-stream loop (the single-GPU loop's shape, train.PipelinedTrainStep): on the critical stream
+    F(t) -> X(t) -> S(t+1) -- the forward pass of the batch sampled one call earlier, its EXP3 update, the next batch's sampling --
+    and beside it, on a second stream, loss / backward / gradient all-reduce / Adam of batch t, which F(t+1) waits for.  Same
+    arithmetic, same order of the data flow as ``StaticShardedTrainStep`` (X(t) reads the norms F(t) stored; it no longer waits for
+    Adam): the two train identically.
+
+    Two block slots (the batch being trained, the batch being sampled).  The backward stream's collectives -- halo gradients,
+    parameter gradients, the loss -- go through ``group_b``, a communicator of their own: one RCCL communicator must see its
+    collectives in one order on every rank, and two streams do not guarantee one.  Graph mode (``capture``): per slot three graphs
+    -- F + X, S, B -- replayed from the two streams and ordered by two events; forks INSIDE one graph serialise on this runtime."""
+
+    def __init__(self, shard, sampler, model, batch, lr=0.002, multilabel=False, group=None, group_b=None):
+        super().__init__(shard, sampler, model, batch, lr=lr, multilabel=multilabel, group=group)
+        if shard.world > 1 and group_b is None:
+            group_b = dist.new_group(backend=dist.get_backend(group))
+        self.group_b = group_b
+        self.side = torch.cuda.Stream()
+        self.slot, self.primed = 0, False
+        self.blocks2 = [None, None]
+        self.ev_f, self.ev_b = torch.cuda.Event(), torch.cuda.Event()
+        self.g_fx, self.g_s, self.g_b = [None, None], [None, None], [None, None]
+        self._held = [None, None]
+
+    # ---- the three parts ---------------------------------------------------------------------------------------------------
+    def _sample(self, slot):
+        self._gather_seeds()
+        self.blocks2[slot] = self.sampler.enqueue(self.seeds_g, slot=slot)
+
+    def _fwd_x(self, slot):
+        blocks = self.blocks2[slot]
+        pred = self._forward(blocks, slot)
+        self.sampler.exp3(blocks)
+        return pred
+
+    def _bwd(self, pred, slot):
+        out = self._loss_backward_step(self.blocks2[slot], pred, slot)
+        self.last = dict(mfgs=self.blocks2[slot], pred=out, slot=slot)
+
+    def prime(self, my_seeds):
+        """Sample the first batch (slot 0): the loop trains a batch one call after it was sampled."""
+        self.my_seeds.copy_(my_seeds.to(torch.int32), non_blocking=True)
+        if self.graph is not None:
+            self.g_s[0].replay()
+        else:
+            self._sample(0)
+        self.slot, self.primed = 0, True
+
+    def __call__(self, next_seeds):
+        """Train the batch sampled by the previous call (or ``prime``) and sample ``next_seeds`` for the next one.  Returns the
+        device scalar that holds the trained batch's global mean loss once the backward stream has finished it (``finish``)."""
+        if not self.primed:
+            raise RuntimeError("prime(seeds) first: the loop trains a batch one call after sampling it")
+        s = self.slot
+        main = torch.cuda.current_stream()
+        self.my_seeds.copy_(next_seeds.to(torch.int32), non_blocking=True)
+        main.wait_event(self.ev_b)                               # batch t-1: parameters updated, its block slot free again
+        if self.graph is not None:
+            self.g_fx[s].replay()
+            self.ev_f.record(main)
+            self.g_s[1 - s].replay()
+            self.side.wait_event(self.ev_f)
+            with torch.cuda.stream(self.side):
+                self.g_b[s].replay()
+                self.ev_b.record(self.side)
+        else:
+            pred = self._fwd_x(s)
+            self.ev_f.record(main)
+            self._sample(1 - s)
+            self.side.wait_event(self.ev_f)
+            with torch.cuda.stream(self.side):
+                self._bwd(pred, s)
+                self.ev_b.record(self.side)
+        self.trained_slot, self.slot = s, 1 - s
+        return self.loss_dev
+
+    def finish(self):
+        """Wait for both streams; the trained batch's loss, the sizes of the batch just sampled, the error check."""
+        self.side.synchronize()
+        torch.cuda.current_stream().synchronize()
+        sizes = self.sampler.finish(self.slot)
+        self.sampler.check_errors()
+        return float(self.loss_dev.item()), sizes
+
+    def calibrate(self, loader, steps=4, k_margin=1.4, b_margin=2.0):
+        raise NotImplementedError("capacities for the pipelined loop: shard_static.measure_caps + DenseShardedSampler(fixed_caps=...)")
+
+    def capture(self, loader, warmup=2):
+        """Eager pipelined warm-up, then the six graphs (per slot: F + X, S, B; F + X and B share a memory pool: the backward pass
+        is recorded against the forward's autograd graph)."""
+        if self.g.world > 1 and dist.get_backend(self.group) != "nccl":
+            raise RuntimeError("graph capture needs the collectives on the device (backend nccl)")
+        import gc
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            if not self.primed:
+                self.prime(next(loader))
+            for _ in range(warmup):
+                self(next(loader))
+            self.side.synchronize()
+            torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().wait_stream(warm)
+        self.sampler.check_errors()
+        self.last = {}
+        gc.collect()
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()                                # (one capture stream for F and B: autograd replays a node on its forward's stream)
+        g_fx, g_s, g_b = [None, None], [None, None], [None, None]
+        for s in (0, 1):                                         # S first: the slot's block objects must come from a recorded enqueue
+            g_s[s] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_s[s], stream=cap):
+                self._sample(s)
+        for s in (0, 1):
+            g_fx[s], g_b[s] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fx[s], pool=pool, stream=cap):
+                self._held[s] = self._fwd_x(s)
+            with torch.cuda.graph(g_b[s], pool=pool, stream=cap):
+                self._bwd(self._held[s], s)
+        self.g_fx, self.g_s, self.g_b = g_fx, g_s, g_b
+        self.graph = True
+        # the captures executed nothing, and the slot the loop trains next now consists of recorded tensors: sample its batch again
+        # (my_seeds still holds it) under the SAME step number of the keyed draw -- the loop continues as if nothing had happened
+        self.sampler._bufs["step"].sub_(1)
+        self.g_s[self.slot].replay()
+        torch.cuda.synchronize()
+
+    def close(self):
+        import gc
+        torch.cuda.synchronize()
+        self.g_fx, self.g_s, self.g_b, self._held = [None, None], [None, None], [None, None], [None, None]
+        self.graph, self.last, self.blocks2 = None, {}, [None, None]
         gc.collect()
         torch.cuda.synchronize()

@@ -199,3 +199,53 @@ def test_static_sharded_step_replays_from_one_graph(cuda):
         assert torch.equal(outs[0][2], outs[1][2])
     finally:
         dist.destroy_process_group()
+
+
+def test_pipelined_sharded_loop_trains_like_the_one_stream_step(cuda):
+    """World of one rank over RCCL.  PipelinedShardedTrainStep (F(t) -> X(t) -> S(t+1) on one stream, loss / backward / Adam of batch t
+    on a second) leaves the losses, parameters and EXP3 rows of StaticShardedTrainStep bit for bit -- launched kernel by kernel, and
+    replayed from its six graphs."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29751"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        from bliss_gnn_amd import shard as sh
+        from bliss_gnn_amd import shard_static as ss
+        from bliss_gnn_amd.model import SAGE
+        ip, ix, ei, _, _, feats, labels = _problem()
+        bounds = sh.partition_by_in_edges(ip, 1)
+        gen = torch.Generator().manual_seed(13)
+        batches = [torch.randperm(V, generator=gen)[:BATCH].to(torch.int32).to(cuda) for _ in range(8)]
+        outs = {}
+        for kind in ("one-stream", "pipelined", "pipelined-graphs"):
+            g = sh.GraphShard.from_global(ip, ix, ei, bounds, 0, device=cuda, ndata={"features": feats, "labels": labels})
+            sampler = ss.DenseShardedSampler(g, FAN, eta=ETA, seed=SEED)
+            torch.manual_seed(0)
+            model = SAGE(F, 32, CLASSES, 3, torch.relu, 0.0).to(cuda).bfloat16()
+            losses = []
+            if kind == "one-stream":
+                step = ss.StaticShardedTrainStep(g, sampler, model, BATCH, lr=0.002)
+                for b in batches[:7]:                       # trains batches 0 .. 6
+                    step(b)
+                    losses.append(step.finish()[0])
+            else:
+                step = ss.PipelinedShardedTrainStep(g, sampler, model, BATCH, lr=0.002)
+                it = iter(batches)
+                if kind == "pipelined-graphs":
+                    step.capture(it, warmup=2)              # prime(0), call(1), call(2): batches 0, 1 trained kernel by kernel
+                    assert step.graph
+                else:
+                    step.prime(next(it))
+                for b in it:                                # every call trains the batch sampled one call earlier: 0 .. 6 in the end
+                    step(b)
+                    losses.append(step.finish()[0])
+            sampler.check_errors()
+            outs[kind] = (losses, [p.detach().float().cpu() for p in model.parameters()], sampler.ops.w_pos.cpu().view(torch.int16).clone())
+            step.close()
+        assert outs["pipelined"][0] == outs["one-stream"][0]
+        assert outs["pipelined-graphs"][0] == outs["one-stream"][0][2:]
+        for kind in ("pipelined", "pipelined-graphs"):
+            assert all(torch.equal(a, b) for a, b in zip(outs[kind][1], outs["one-stream"][1])), kind
+            assert torch.equal(outs[kind][2], outs["one-stream"][2]), kind
+    finally:
+        dist.destroy_process_group()
