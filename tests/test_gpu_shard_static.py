@@ -97,20 +97,35 @@ def _train_worker(rank, world, port, outdir):
     g = sh.GraphShard.from_global(ip, ix, ei, bounds, rank, device=dev, ndata={"features": feats, "labels": labels})
     per_rank = BATCH // world
     out = {}
-    for kind in ("eager", "static"):
+    def my_batch(si):
+        # every rank contributes the same number of seeds it owns (static shapes)
+        gen = torch.Generator().manual_seed(100 + 7 * si + rank)
+        return (torch.randperm(g.hi - g.lo, generator=gen)[:per_rank] + g.lo).to(torch.int32).to(dev)
+
+    for kind in ("eager", "static", "pipelined"):
         torch.manual_seed(0)
         model = SAGE(F, 32, CLASSES, 3, torch.relu, 0.0).to(dev).bfloat16()
         if kind == "eager":
             sampler = sh.ShardedPoissonBanditSampler(g, FAN, eta=ETA, seed=SEED)
             step = sh.ShardedTrainStep(g, sampler, model, lr=0.002)
-        else:
+        elif kind == "static":
             sampler = ss.DenseShardedSampler(g, FAN, eta=ETA, seed=SEED)
             step = ss.StaticShardedTrainStep(g, sampler, model, per_rank, lr=0.002)
+        else:                       # the two-stream loop, launched kernel by kernel (gloo): its backward stream has its own group
+            sampler = ss.DenseShardedSampler(g, FAN, eta=ETA, seed=SEED)
+            step = ss.PipelinedShardedTrainStep(g, sampler, model, per_rank, lr=0.002)
+            step.prime(my_batch(0))
+            losses = []
+            for si in range(len(batches)):
+                step(my_batch(si + 1))
+                losses.append(step.finish()[0])
+            sampler.check_errors()
+            out[kind] = dict(losses=losses, params=[p.detach().float().cpu() for p in model.parameters()],
+                             w=sampler.ops.w_pos.cpu().view(torch.int16))
+            continue
         losses, preds, kept = [], [], []
         for si in range(len(batches)):
-            # every rank contributes the same number of seeds it owns (static shapes)
-            gen = torch.Generator().manual_seed(100 + 7 * si + rank)
-            mine = (torch.randperm(g.hi - g.lo, generator=gen)[:per_rank] + g.lo).to(torch.int32).to(dev)
+            mine = my_batch(si)
             if kind == "eager":
                 losses.append(float(step(mine)))
                 b = step.last["mfgs"][-1]
@@ -152,6 +167,9 @@ def test_static_sharded_train_step_follows_the_eager_one(cuda, world):
         for a, b in zip(e["losses"], s["losses"]):
             assert a == a and b == b and abs(a - b) <= 0.15 * max(1.0, abs(a))
         assert all(torch.isfinite(p).all() for p in s["params"])
+        pl = r["pipelined"]                                     # the two-stream loop == the one-stream static step, bit for bit
+        assert pl["losses"] == s["losses"] and torch.equal(pl["w"], s["w"])
+        assert all(torch.equal(a, b) for a, b in zip(pl["params"], s["params"]))
     if world == 2:
         assert all(torch.equal(a, b) for a, b in zip(res[0]["static"]["params"], res[1]["static"]["params"]))   # replicas of the parameters stay in step
         assert res[0]["static"]["losses"] == res[1]["static"]["losses"]
