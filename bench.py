@@ -424,9 +424,10 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
         if (world == 1 or dist.get_backend() == "nccl") and os.environ.get("BLISS_SHARD_GRAPH", "1") != "0":
             try:
                 step.capture(loader, warmup=2)
-                launch = ("three HIP graphs per step on two streams (static shapes): forward + EXP3 and the next batch's sampling with its "
+                launch = ("%s per step on two streams (static shapes): forward + EXP3 and the next batch's sampling with its "
                           "dense all-reduces on the critical stream; loss, backward, gradient all-reduce and Adam beside them, on a "
-                          "communicator of their own") if pipelined else \
+                          "communicator of their own" % ("two HIP graphs ordered by device flags" if step.use_flags else
+                                                         "three HIP graphs ordered by stream events")) if pipelined else \
                          "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
             except Exception as e:                                 # noqa: BLE001 -- a runtime that cannot capture collectives
                 print("rank %d: graph capture of the sharded step failed (%r); static shapes, eager launches" % (rank, e), file=sys.stderr)

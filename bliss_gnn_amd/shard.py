@@ -95,10 +95,10 @@ class ShardBlock(Block):
     """The block of one rank: destinations = the seeds this rank owns (``dst_pos`` = their positions in the global source
     list, whose first entries are ALL seeds in seed order); sources index the global kept list."""
 
-    def __init__(self, g, n_src, n_dst, indptr, src, dst, pos, eid, src_nid, dst_pos):
+    def __init__(self, g, n_src, n_dst, indptr, src, dst, pos, eid, src_nid, dst_pos, dst_nid=None):
         super().__init__(g, n_src, n_dst, indptr, src, dst, pos, eid, src_nid)
         self.dst_pos = dst_pos
-        self.dstdata[NID] = src_nid[dst_pos]
+        self.dstdata[NID] = src_nid[dst_pos] if dst_nid is None else dst_nid      # (dst_nid: the caller's persistent buffer)
 
 
 # ----------------------------------------------------------------------------------------------- collectives

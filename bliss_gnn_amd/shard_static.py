@@ -118,6 +118,7 @@ class DenseShardedSampler:
                  step=torch.zeros(1, dtype=torch.int64, device=dev), seeds0=torch.zeros(S0, dtype=torch.int32, device=dev),
                  seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
                  seed_pos=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
+                 dst_nid=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
                  n_local=torch.zeros(L, dtype=torch.int32, device=dev),
                  counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(), rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(),
                  nloc_host=torch.empty(L, dtype=torch.int32).pin_memory(), err_host=torch.empty(1, dtype=torch.int32).pin_memory())
@@ -137,6 +138,7 @@ class DenseShardedSampler:
                                     seeds0=torch.zeros_like(b["seeds0"]), n_local=torch.zeros(L, dtype=torch.int32, device=dev),
                                     seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
                                     seed_pos=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
+                                    dst_nid=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
                                     counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(),
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
@@ -194,7 +196,9 @@ class DenseShardedSampler:
             chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
                                       eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
             b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept, node_prob, cdev, t_indptr, t_edge = lay
-            blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos)
+            # (the destinations' ids into a persistent per-slot buffer: block objects of one slot are interchangeable between graphs)
+            torch.index_select(kept, 0, seed_pos.long(), out=sb["dst_nid"][n])
+            blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos, dst_nid=sb["dst_nid"][n])
             blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
             blk._counts, blk._counts_dev, blk._layer = None, cdev, layer
             blk._nnz_ptr = sb["counts"].data_ptr() + 40 * n + 16
@@ -661,8 +665,9 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.slot, self.primed = 0, False
         self.blocks2 = [None, None]
         self.ev_f, self.ev_b = torch.cuda.Event(), torch.cuda.Event()
-        self.g_fx, self.g_s, self.g_b = [None, None], [None, None], [None, None]
+        self.g_main, self.g_fx, self.g_s, self.g_b = [None, None], [None, None], [None, None], [None, None]
         self._held = [None, None]
+        self._flags_primed, self.use_flags = False, False
 
     # ---- the three parts ---------------------------------------------------------------------------------------------------
     def _sample(self, slot):
@@ -674,6 +679,42 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         pred = self._forward(blocks, slot)
         self.sampler.exp3(blocks)
         return pred
+
+    FLAG_F_DONE, FLAG_B_DONE = 12, 13                           # slots of the engine's device flags (0 .. L: the single-GPU sampler's)
+
+    def _flags_usable(self, tries=4):
+        """Device flags order two streams only if the streams really run side by side (HIP multiplexes streams onto a few
+        hardware queues; a wait that shares its producer's queue would spin until its time-out): probe with harmless kernels, in
+        both directions, and take another stream of PyTorch's pool if the probe fails (as train.PipelinedTrainStep does)."""
+        eng = self.sampler.ops.eng
+        main = torch.cuda.current_stream()
+
+        def probe(waiter, raiser):
+            torch.cuda.synchronize()
+            eng.flag_err.zero_(); eng.flags.zero_()
+            torch.cuda.synchronize()
+            f = eng.flags.data_ptr() + 4 * 14
+            _lib.check(_lib.lib.bliss_flag_wait(f, eng.flag_err.data_ptr(), waiter.cuda_stream), "bliss_flag_wait")
+            _lib.check(_lib.lib.bliss_flag_raise(f, raiser.cuda_stream), "bliss_flag_raise")
+            torch.cuda.synchronize()
+            ok = int(eng.flag_err.item()) == 0
+            eng.flag_err.zero_(); eng.flags.zero_()
+            torch.cuda.synchronize()
+            return ok
+
+        for _ in range(tries):
+            if probe(self.side, main) and probe(main, self.side):
+                return True
+            self.side = torch.cuda.Stream()
+        return False
+
+    def _flag(self, which, raise_):
+        eng = self.sampler.ops.eng
+        st = torch.cuda.current_stream().cuda_stream
+        if raise_:
+            _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * which, st), "bliss_flag_raise")
+        else:
+            _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * which, eng.flag_err.data_ptr(), st), "bliss_flag_wait")
 
     def _bwd(self, pred, slot):
         out = self._loss_backward_step(self.blocks2[slot], pred, slot)
@@ -687,6 +728,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         else:
             self._sample(0)
         self.slot, self.primed = 0, True
+        self._flags_primed = False
 
     def __call__(self, next_seeds):
         """Train the batch sampled by the previous call (or ``prime``) and sample ``next_seeds`` for the next one.  Returns the
@@ -696,8 +738,19 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         s = self.slot
         main = torch.cuda.current_stream()
         self.my_seeds.copy_(next_seeds.to(torch.int32), non_blocking=True)
-        main.wait_event(self.ev_b)                               # batch t-1: parameters updated, its block slot free again
-        if self.graph is not None:
+        if self.graph is not None and self.use_flags:
+            # two graphs per step, ordered by DEVICE FLAGS (bliss_flag_wait / raise, bounded spins): the main graph waits for
+            # "batch t-1's backward pass and Adam are done" with its first kernel and raises "forward done" behind F; the backward
+            # graph waits for that one and raises the other.  Both are launched ahead by the host; a stream-event wait in front of
+            # each graph cost 40-90 us per boundary (profiles/r03_u: 1.10 ms/step with three event-ordered graphs)
+            if not self._flags_primed:                           # nothing precedes the first step
+                self._flag(self.FLAG_B_DONE, True)
+                self._flags_primed = True
+            self.g_main[s].replay()
+            with torch.cuda.stream(self.side):
+                self.g_b[s].replay()
+        elif self.graph is not None:                             # three graphs per step, ordered by stream events
+            main.wait_event(self.ev_b)
             self.g_fx[s].replay()
             self.ev_f.record(main)
             self.g_s[1 - s].replay()
@@ -706,6 +759,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                 self.g_b[s].replay()
                 self.ev_b.record(self.side)
         else:
+            main.wait_event(self.ev_b)                           # batch t-1: parameters updated, its block slot free again
             pred = self._fwd_x(s)
             self.ev_f.record(main)
             self._sample(1 - s)
@@ -722,6 +776,8 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         torch.cuda.current_stream().synchronize()
         sizes = self.sampler.finish(self.slot)
         self.sampler.check_errors()
+        if self.graph is not None and self.use_flags and int(self.sampler.ops.eng.flag_err.item()):
+            raise RuntimeError("a cross-stream flag never arrived (bliss_flag_wait timed out): the pipelined results are invalid")
         return float(self.loss_dev.item()), sizes
 
     def calibrate(self, loader, steps=4, k_margin=1.4, b_margin=2.0):
@@ -747,20 +803,41 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.last = {}
         gc.collect()
         torch.cuda.synchronize()
-        pool = torch.cuda.graph_pool_handle()
+        pool, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         cap = torch.cuda.Stream()                                # (one capture stream for F and B: autograd replays a node on its forward's stream)
-        g_fx, g_s, g_b = [None, None], [None, None], [None, None]
-        for s in (0, 1):                                         # S first: the slot's block objects must come from a recorded enqueue
+        g_main, g_s, g_b = [None, None], [None, None], [None, None]
+        for s in (0, 1):                                         # (S alone: what prime() replays)
             g_s[s] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_s[s], stream=cap):
                 self._sample(s)
+        import os
+        self.use_flags = os.environ.get("BLISS_SHARD_FLAGS", "1") != "0" and self._flags_usable()
+        g_fx = [None, None]
         for s in (0, 1):
-            g_fx[s], g_b[s] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fx[s], pool=pool, stream=cap):
-                self._held[s] = self._fwd_x(s)
-            with torch.cuda.graph(g_b[s], pool=pool, stream=cap):
-                self._bwd(self._held[s], s)
-        self.g_fx, self.g_s, self.g_b = g_fx, g_s, g_b
+            g_b[s] = torch.cuda.CUDAGraph()
+            if self.use_flags:
+                g_main[s] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_main[s], pool=pool, stream=cap):
+                    self._flag(self.FLAG_B_DONE, False)          # batch t-1: parameters updated, its block slot free again
+                    blocks = self.blocks2[s]
+                    self._held[s] = self._forward(blocks, s)     # F(t)
+                    self._flag(self.FLAG_F_DONE, True)
+                    self.sampler.exp3(blocks)                    # X(t)
+                    self._sample(1 - s)                          # S(t+1)
+                # (a pool of its own: B(t) runs BESIDE the S(t+1) part of the main graph, and two graphs that share a pool share the
+                # memory of their temporaries -- the sampler's were overwritten by the backward pass's until the pools were split.
+                # The forward's saved tensors live in the main graph's pool and stay alive through _held.)
+                with torch.cuda.graph(g_b[s], pool=pool_b, stream=cap):
+                    self._flag(self.FLAG_F_DONE, False)
+                    self._bwd(self._held[s], s)                  # B(t)
+                    self._flag(self.FLAG_B_DONE, True)
+            else:
+                g_fx[s] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fx[s], pool=pool, stream=cap):
+                    self._held[s] = self._fwd_x(s)
+                with torch.cuda.graph(g_b[s], pool=pool, stream=cap):
+                    self._bwd(self._held[s], s)
+        self.g_main, self.g_fx, self.g_s, self.g_b = g_main, g_fx, g_s, g_b
         self.graph = True
         # the captures executed nothing, and the slot the loop trains next now consists of recorded tensors: sample its batch again
         # (my_seeds still holds it) under the SAME step number of the keyed draw -- the loop continues as if nothing had happened
@@ -771,7 +848,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
     def close(self):
         import gc
         torch.cuda.synchronize()
-        self.g_fx, self.g_s, self.g_b, self._held = [None, None], [None, None], [None, None], [None, None]
+        self.g_main, self.g_fx, self.g_s, self.g_b, self._held = [None, None], [None, None], [None, None], [None, None], [None, None]
         self.graph, self.last, self.blocks2 = None, {}, [None, None]
         gc.collect()
         torch.cuda.synchronize()
