@@ -426,7 +426,8 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
                 step.capture(loader, warmup=2)
                 launch = ("%s per step on two streams (static shapes): forward + EXP3 and the next batch's sampling with its "
                           "dense all-reduces on the critical stream; loss, backward, gradient all-reduce and Adam beside them, on a "
-                          "communicator of their own" % ("two HIP graphs ordered by device flags" if step.use_flags else
+                          "communicator of their own" % (("three HIP graphs on three streams (the third builds the next batch's blocks) ordered by device flags" if step.use_third else
+                                                          "two HIP graphs ordered by device flags") if step.use_flags else
                                                          "three HIP graphs ordered by stream events")) if pipelined else \
                          "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
             except Exception as e:                                 # noqa: BLE001 -- a runtime that cannot capture collectives
@@ -438,7 +439,11 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
         def one():
             step(next(loader))
             cnt = sampler._slot_bufs(step.slot if pipelined else 0)["counts"]
-            edges_dev.add_(cnt[4::10].sum())
+            if pipelined and step.graph is not None and step.use_third:        # (the blocks just sampled are built on the third stream)
+                with torch.cuda.stream(step.third):
+                    edges_dev.add_(cnt[4::10].sum())
+            else:
+                edges_dev.add_(cnt[4::10].sum())
     else:
         sampler = sh.ShardedPoissonBanditSampler(g, cfg["fanouts"], eta=0.1, seed=7)
         step = sh.ShardedTrainStep(g, sampler, model, lr=0.002, multilabel=cfg["multilabel"])

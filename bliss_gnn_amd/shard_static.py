@@ -34,6 +34,17 @@ from .shard import HIST_BINS, ShardBlock, _HipShardOps, _all_reduce
 SEED_MARK = 1 << 32
 
 
+def _cap_kw():
+    """Keyword arguments of every ``torch.cuda.graph`` capture here: with a process group alive, ProcessGroupNCCL's watchdog thread
+    queries its events at any time, and a capture in the default "global" error mode turns such a query from ANOTHER thread into
+    "operation not permitted when stream is capturing" (seen once captures became frequent: bench.py --dist shards aborted)."""
+    try:
+        import torch.distributed as _d
+        return {"capture_error_mode": "thread_local"} if _d.is_available() and _d.is_initialized() else {}
+    except Exception:                                            # noqa: BLE001
+        return {}
+
+
 # ------------------------------------------------------------------------------------------- the exchange, generic form
 class DenseShardedSampler:
     """PoissonBanditLadiesSampler (bandit_sampler.py:369-425) over destination-range shards, dense exchange.
@@ -143,10 +154,15 @@ class DenseShardedSampler:
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
 
-    def enqueue(self, seeds_g, slot=0):
+    def enqueue(self, seeds_g, slot=0, part=None, hook=None):
         """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
         outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
-        advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors."""
+        advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors.
+
+        ``part``: None = everything.  "select" = candidates, draw and kept lists of all layers without the blocks themselves
+        (``hook(n)`` is called behind layer n's kept list); "build" = only the blocks (generate_block, :269-339) of a preceding
+        "select" with the same slot (``hook(n)`` in front of layer n's block) -- for a loop that builds them on another stream.
+        Needs one scratch set per layer: a layer's dense maps live until its block is built."""
         if not self.static:
             raise RuntimeError("enqueue() is the static HIP path; construct the sampler without ops")
         g, ops = self.g, self.ops
@@ -160,7 +176,11 @@ class DenseShardedSampler:
         st = torch.cuda.current_stream().cuda_stream
         lib, chk = _lib.lib, _lib.check
         V = eng.V
-        sb["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
+        select, build = part in (None, "select"), part in (None, "build")
+        if part is not None and eng.scratch_sets < L:
+            raise RuntimeError("split enqueue needs one scratch set per layer (set ops.eng.scratch_sets before the first call)")
+        if select:
+            sb["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
         eta_f, ome_f = float(np.float32(self.eta)), float(np.float32(1.0 - self.eta))
         bins = eng._bin_buffers()
         n_touched_ptr = bins["cursor"].data_ptr() + 4 * eng.n_bins
@@ -174,28 +194,38 @@ class DenseShardedSampler:
             nloc_ptr = sb["n_local"].data_ptr() + 4 * n
             rec_ptr = sb["rec"].data_ptr() + 40 * n
             w_pos = ops.w_pos[layer]
-            chk(lib.bliss_shard_local_seeds(cur.data_ptr(), n_seeds, n_seeds_dev, g.lo, g.hi, cs, seeds_l.data_ptr(), ws.cand_nid.data_ptr(),
-                                            seed_pos.data_ptr(), nloc_ptr, b["err"].data_ptr(), st), "bliss_shard_local_seeds")
-            chk(lib.bliss_frontier_prob(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), -1, nloc_ptr,
-                                        cs, ops.mode | _lib.MODE_PARTIALS, eta_f, ome_f, eng.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
-            seed_p2_ptr = ws.seed_acc.data_ptr() + 8 * 4 * cs
-            chk(lib.bliss_shard_scatter_partials(seeds_l.data_ptr(), seed_p2_ptr, nloc_ptr, bins["tkey"].data_ptr(), bins["tsum"].data_ptr(),
-                                                 n_touched_ptr, b["dense"].data_ptr(), V, b["err"].data_ptr(), st), "bliss_shard_scatter_partials")
-            _all_reduce(b["dense"], self.group)                               # THE exchange of this layer (static shape)
-            st = torch.cuda.current_stream().cuda_stream
-            chk(lib.bliss_shard_candidates(b["dense"].data_ptr(), V, ops.uniform_nodes, b["cand"].data_ptr(), b["p"].data_ptr(),
-                                           b["is_seed"].data_ptr(), eng.hist.data_ptr(), rec_ptr, V, b["scr_a"].data_ptr(), b["err"].data_ptr(), st),
-                "bliss_shard_candidates")
-            chk(lib.bliss_poisson_scale(eng.hist.data_ptr(), rec_ptr, int(fan[n]), 0.9999, b["sel"].data_ptr(), st), "bliss_poisson_scale")
-            chk(lib.bliss_shard_select_kept(b["cand"].data_ptr(), b["p"].data_ptr(), b["is_seed"].data_ptr(), rec_ptr, self.seed, b["step"].data_ptr(),
-                                            n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
-                                            c_ws.kept_map, cap["K"], V, cnt_ptr, nloc_ptr, b["scr_b"].data_ptr(), b["err"].data_ptr(), st),
-                "bliss_shard_select_kept")
-            # (measured and not kept: the block on a side stream beside the next layer's candidate work, own scratch set per layer --
-            # correct, but the forked graph replayed at 4.4 ms instead of 1.4: this runtime serialises branches of one graph badly)
-            chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
-                                      eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
+            if select:
+                chk(lib.bliss_shard_local_seeds(cur.data_ptr(), n_seeds, n_seeds_dev, g.lo, g.hi, cs, seeds_l.data_ptr(), ws.cand_nid.data_ptr(),
+                                                seed_pos.data_ptr(), nloc_ptr, b["err"].data_ptr(), st), "bliss_shard_local_seeds")
+                chk(lib.bliss_frontier_prob(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), -1, nloc_ptr,
+                                            cs, ops.mode | _lib.MODE_PARTIALS, eta_f, ome_f, eng.Eg, C.byref(c_ws), st), "bliss_frontier_prob")
+                seed_p2_ptr = ws.seed_acc.data_ptr() + 8 * 4 * cs
+                chk(lib.bliss_shard_scatter_partials(seeds_l.data_ptr(), seed_p2_ptr, nloc_ptr, bins["tkey"].data_ptr(), bins["tsum"].data_ptr(),
+                                                     n_touched_ptr, b["dense"].data_ptr(), V, b["err"].data_ptr(), st), "bliss_shard_scatter_partials")
+                _all_reduce(b["dense"], self.group)                               # THE exchange of this layer (static shape)
+                st = torch.cuda.current_stream().cuda_stream
+                chk(lib.bliss_shard_candidates(b["dense"].data_ptr(), V, ops.uniform_nodes, b["cand"].data_ptr(), b["p"].data_ptr(),
+                                               b["is_seed"].data_ptr(), eng.hist.data_ptr(), rec_ptr, V, b["scr_a"].data_ptr(), b["err"].data_ptr(), st),
+                    "bliss_shard_candidates")
+                chk(lib.bliss_poisson_scale(eng.hist.data_ptr(), rec_ptr, int(fan[n]), 0.9999, b["sel"].data_ptr(), st), "bliss_poisson_scale")
+                chk(lib.bliss_shard_select_kept(b["cand"].data_ptr(), b["p"].data_ptr(), b["is_seed"].data_ptr(), rec_ptr, self.seed, b["step"].data_ptr(),
+                                                n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
+                                                c_ws.kept_map, cap["K"], V, cnt_ptr, nloc_ptr, b["scr_b"].data_ptr(), b["err"].data_ptr(), st),
+                    "bliss_shard_select_kept")
+                if hook is not None and part == "select":
+                    hook(n)
+            # (measured and not kept: the block forked to a side stream INSIDE one graph -- correct, but the forked graph replayed at
+            # 4.4 ms instead of 1.4: this runtime serialises branches of one graph badly; see PipelinedShardedTrainStep for the form
+            # that works: a graph of its own on a third stream, ordered by device flags)
+            if build:
+                if hook is not None and part == "build":
+                    hook(n)
+                chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
+                                          eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
             b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept, node_prob, cdev, t_indptr, t_edge = lay
+            if not select:                                         # (the block objects exist: made by the "select" part)
+                cur, n_seeds, n_seeds_dev = kept, -1, cnt_ptr + 12
+                continue
             # (the destinations' ids into a persistent per-slot buffer: block objects of one slot are interchangeable between graphs)
             torch.index_select(kept, 0, seed_pos.long(), out=sb["dst_nid"][n])
             blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos, dst_nid=sb["dst_nid"][n])
@@ -208,6 +238,8 @@ class DenseShardedSampler:
             blk.edata["edge_weights"], blk.edata["q_ij"], blk.srcdata["node_prob"] = b_w, b_q, node_prob
             blocks.insert(0, blk)
             cur, n_seeds, n_seeds_dev = kept, -1, cnt_ptr + 12
+        if not select:
+            return None
         b["step"].add_(1)
         self._static_blocks = blocks
         return blocks
@@ -620,7 +652,7 @@ class StaticShardedTrainStep:
         torch.cuda.synchronize()
         self.my_seeds.copy_(next(loader).to(torch.int32))
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, **_cap_kw()):
             self._body()
         self.graph = graph
         self.graph.replay()                                        # the capture executed nothing: this batch is a real step
@@ -661,13 +693,16 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         if shard.world > 1 and group_b is None:
             group_b = dist.new_group(backend=dist.get_backend(group))
         self.group_b = group_b
-        self.side = torch.cuda.Stream()
+        self.side, self.third = torch.cuda.Stream(), torch.cuda.Stream()
+        # (flag mode builds the next batch's blocks on the third stream, beside the later layers' candidate work: one scratch set
+        # per layer -- a layer's dense maps live until its block is built)
+        sampler.ops.eng.scratch_sets = max(sampler.ops.eng.scratch_sets, len(sampler.nodes_per_layer))
         self.slot, self.primed = 0, False
         self.blocks2 = [None, None]
         self.ev_f, self.ev_b = torch.cuda.Event(), torch.cuda.Event()
-        self.g_main, self.g_fx, self.g_s, self.g_b = [None, None], [None, None], [None, None], [None, None]
+        self.g_main, self.g_fx, self.g_s, self.g_b, self.g_blk = [None, None], [None, None], [None, None], [None, None], [None, None]
         self._held = [None, None]
-        self._flags_primed, self.use_flags = False, False
+        self._flags_primed, self.use_flags, self.use_third = False, False, False
 
     # ---- the three parts ---------------------------------------------------------------------------------------------------
     def _sample(self, slot):
@@ -680,7 +715,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.sampler.exp3(blocks)
         return pred
 
-    FLAG_F_DONE, FLAG_B_DONE = 12, 13                           # slots of the engine's device flags (0 .. L: the single-GPU sampler's)
+    FLAG_BLK_DONE, FLAG_F_DONE, FLAG_B_DONE = 11, 12, 13        # slots of the engine's device flags; 0 .. L-1: "layer n's kept list is final"
 
     def _flags_usable(self, tries=4):
         """Device flags order two streams only if the streams really run side by side (HIP multiplexes streams onto a few
@@ -702,11 +737,15 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
             torch.cuda.synchronize()
             return ok
 
-        for _ in range(tries):
-            if probe(self.side, main) and probe(main, self.side):
-                return True
-            self.side = torch.cuda.Stream()
-        return False
+        for name in ("side", "third"):
+            for _ in range(tries):
+                st = getattr(self, name)
+                if probe(st, main) and probe(main, st):
+                    break
+                setattr(self, name, torch.cuda.Stream())
+            else:
+                return False
+        return True
 
     def _flag(self, which, raise_):
         eng = self.sampler.ops.eng
@@ -743,12 +782,17 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
             # "batch t-1's backward pass and Adam are done" with its first kernel and raises "forward done" behind F; the backward
             # graph waits for that one and raises the other.  Both are launched ahead by the host; a stream-event wait in front of
             # each graph cost 40-90 us per boundary (profiles/r03_u: 1.10 ms/step with three event-ordered graphs)
-            if not self._flags_primed:                           # nothing precedes the first step
+            if not self._flags_primed:                           # nothing precedes the first step; its blocks were built by prime()
                 self._flag(self.FLAG_B_DONE, True)
+                if self.use_third:
+                    self._flag(self.FLAG_BLK_DONE, True)
                 self._flags_primed = True
             self.g_main[s].replay()
             with torch.cuda.stream(self.side):
                 self.g_b[s].replay()
+            if self.use_third:
+                with torch.cuda.stream(self.third):
+                    self.g_blk[1 - s].replay()
         elif self.graph is not None:                             # three graphs per step, ordered by stream events
             main.wait_event(self.ev_b)
             self.g_fx[s].replay()
@@ -773,6 +817,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
     def finish(self):
         """Wait for both streams; the trained batch's loss, the sizes of the batch just sampled, the error check."""
         self.side.synchronize()
+        self.third.synchronize()
         torch.cuda.current_stream().synchronize()
         sizes = self.sampler.finish(self.slot)
         self.sampler.check_errors()
@@ -803,41 +848,56 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.last = {}
         gc.collect()
         torch.cuda.synchronize()
-        pool, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        pool, pool_b, pool_k = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         cap = torch.cuda.Stream()                                # (one capture stream for F and B: autograd replays a node on its forward's stream)
-        g_main, g_s, g_b = [None, None], [None, None], [None, None]
+        g_main, g_s, g_b, g_blk = [None, None], [None, None], [None, None], [None, None]
         for s in (0, 1):                                         # (S alone: what prime() replays)
             g_s[s] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_s[s], stream=cap):
+            with torch.cuda.graph(g_s[s], stream=cap, **_cap_kw()):
                 self._sample(s)
         import os
         self.use_flags = os.environ.get("BLISS_SHARD_FLAGS", "1") != "0" and self._flags_usable()
+        # BLISS_SHARD_THIRD=1: the next batch's blocks as a graph of their own on a third stream, layer by layer behind "layer n's kept
+        # list is final" flags (the single-GPU loop's arrangement).  Correct (same bits) but 2.6 ms/step instead of 1.02 here: the
+        # spinning waits of that graph sit on a hardware queue the backward pass needs -- measured, off by default
+        self.use_third = self.use_flags and os.environ.get("BLISS_SHARD_THIRD", "0") == "1"
         g_fx = [None, None]
         for s in (0, 1):
             g_b[s] = torch.cuda.CUDAGraph()
             if self.use_flags:
                 g_main[s] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_main[s], pool=pool, stream=cap):
+                with torch.cuda.graph(g_main[s], pool=pool, stream=cap, **_cap_kw()):
                     self._flag(self.FLAG_B_DONE, False)          # batch t-1: parameters updated, its block slot free again
+                    if self.use_third:
+                        self._flag(self.FLAG_BLK_DONE, False)    # batch t's blocks are built (third stream, during step t-1)
                     blocks = self.blocks2[s]
                     self._held[s] = self._forward(blocks, s)     # F(t)
                     self._flag(self.FLAG_F_DONE, True)
                     self.sampler.exp3(blocks)                    # X(t)
-                    self._sample(1 - s)                          # S(t+1)
+                    if self.use_third:                           # S(t+1) without its blocks; "layer n's kept list is final": flag n
+                        self._gather_seeds()
+                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, part="select", hook=lambda n: self._flag(n, True))
+                    else:
+                        self._sample(1 - s)                      # S(t+1)
+                if self.use_third:
+                    g_blk[1 - s] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_blk[1 - s], pool=pool_k, stream=cap, **_cap_kw()):     # the blocks of batch t+1, third stream
+                        self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", hook=lambda n: self._flag(n, False))
+                        self._flag(self.FLAG_BLK_DONE, True)
                 # (a pool of its own: B(t) runs BESIDE the S(t+1) part of the main graph, and two graphs that share a pool share the
                 # memory of their temporaries -- the sampler's were overwritten by the backward pass's until the pools were split.
                 # The forward's saved tensors live in the main graph's pool and stay alive through _held.)
-                with torch.cuda.graph(g_b[s], pool=pool_b, stream=cap):
+                with torch.cuda.graph(g_b[s], pool=pool_b, stream=cap, **_cap_kw()):
                     self._flag(self.FLAG_F_DONE, False)
                     self._bwd(self._held[s], s)                  # B(t)
                     self._flag(self.FLAG_B_DONE, True)
             else:
                 g_fx[s] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fx[s], pool=pool, stream=cap):
+                with torch.cuda.graph(g_fx[s], pool=pool, stream=cap, **_cap_kw()):
                     self._held[s] = self._fwd_x(s)
-                with torch.cuda.graph(g_b[s], pool=pool, stream=cap):
+                with torch.cuda.graph(g_b[s], pool=pool, stream=cap, **_cap_kw()):
                     self._bwd(self._held[s], s)
-        self.g_main, self.g_fx, self.g_s, self.g_b = g_main, g_fx, g_s, g_b
+        self.g_main, self.g_fx, self.g_s, self.g_b, self.g_blk = g_main, g_fx, g_s, g_b, g_blk
         self.graph = True
         # the captures executed nothing, and the slot the loop trains next now consists of recorded tensors: sample its batch again
         # (my_seeds still holds it) under the SAME step number of the keyed draw -- the loop continues as if nothing had happened
@@ -848,7 +908,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
     def close(self):
         import gc
         torch.cuda.synchronize()
-        self.g_main, self.g_fx, self.g_s, self.g_b, self._held = [None, None], [None, None], [None, None], [None, None], [None, None]
+        self.g_main, self.g_fx, self.g_s, self.g_b, self.g_blk, self._held = ([None, None] for _ in range(6))
         self.graph, self.last, self.blocks2 = None, {}, [None, None]
         gc.collect()
         torch.cuda.synchronize()

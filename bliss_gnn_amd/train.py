@@ -46,6 +46,17 @@ class BatchLoader:
             yield from iter(self)
 
 
+def _cap_kw():
+    """Keyword arguments of every ``torch.cuda.graph`` capture here: with a process group alive, ProcessGroupNCCL's watchdog thread
+    queries its events at any time, and a capture in the default "global" error mode turns such a query from ANOTHER thread into
+    "operation not permitted when stream is capturing" (seen once captures became frequent: bench.py --dist shards aborted)."""
+    try:
+        import torch.distributed as _d
+        return {"capture_error_mode": "thread_local"} if _d.is_available() and _d.is_initialized() else {}
+    except Exception:                                            # noqa: BLE001
+        return {}
+
+
 def _inputs(model, mfgs):
     """``mfgs[0].srcdata['features']`` (train_lightning.py:138); for a model whose first layer gathers the rows as its operand
     load (model.SAGE on the MFMA path) the not-yet-gathered (table, ids) pair instead."""
@@ -242,7 +253,7 @@ class GraphedTrainStep:
         self.seeds.copy_(next(loader))
         eng.stage_rng_from_torch()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **_cap_kw()):
             self.loss = self._body()
         # the capture itself executed nothing: replay once so that this batch is a real step
         self.graph.replay()
@@ -553,7 +564,7 @@ class PipelinedTrainStep(GraphedTrainStep):
             # renormalised into their other buffers -- beside the sampler, which keeps reading the old ones (dividing on the fly)
             # until the pass has switched a row over
             self.g_norm = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_norm, pool=pool):
+            with torch.cuda.graph(self.g_norm, pool=pool, **_cap_kw()):
                 _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * self.FLAG_X_DONE, eng.flag_err.data_ptr(), st_()), "bliss_flag_wait")
                 self.sampler.normalize_pending()
         for cur, nxt, chain in ((0, 1, False), (1, 0, True)):
@@ -561,7 +572,7 @@ class PipelinedTrainStep(GraphedTrainStep):
             self.g_bwd[cur] = torch.cuda.CUDAGraph()
             if self.use_flags:
                 self.g_main[cur] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_main[cur], pool=pool, stream=side):
+                with torch.cuda.graph(self.g_main[cur], pool=pool, stream=side, **_cap_kw()):
                     if self._flag_boundary:
                         # "the previous step's backward pass, Adam and early blocks are done", as a device flag: the graph is
                         # launched ahead and its first kernel waits ~3 us past the raise; a stream-event wait in front of the
@@ -576,29 +587,29 @@ class PipelinedTrainStep(GraphedTrainStep):
                                                   last_block=not self._defer_block0)
                 if L > 1:
                     self.g_blk[nxt] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_blk[nxt]):
+                    with torch.cuda.graph(self.g_blk[nxt], **_cap_kw()):
                         self._sample(nxt, chain, external_rng=True, part="early_blocks")
                 if self._defer_block0:
                     self.g_blk0[nxt] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_blk0[nxt]):
+                    with torch.cuda.graph(self.g_blk0[nxt], **_cap_kw()):
                         # (raises FLAG_BLOCK0 itself, before it sorts the by-source index the backward pass will read)
                         early = os.environ.get("BLISS_BLOCK0_EARLY_FLAG", "1") != "0"
                         self._sample(nxt, chain, external_rng=True, part="last_block",
                                      ready_flag=eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0 if early else 0)
                         if not early:
                             _lib.check(_lib.lib.bliss_flag_raise(eng.flags.data_ptr() + 4 * self.FLAG_BLOCK0, st_()), "bliss_flag_raise")
-                with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
+                with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side, **_cap_kw()):
                     # B may start once S has (flag 0 is raised by the sampler's first kernel: F and X have completed)
                     _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr(), eng.flag_err.data_ptr(),
                                                         torch.cuda.current_stream().cuda_stream), "bliss_flag_wait")
                     out[cur] = self._backward(held[cur])
             else:
                 self.g_fwd[cur], self.g_smp[nxt] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side):
+                with torch.cuda.graph(self.g_fwd[cur], pool=pool, stream=side, **_cap_kw()):
                     held[cur] = self._forward(self.mfgs[cur])
-                with torch.cuda.graph(self.g_smp[nxt]):
+                with torch.cuda.graph(self.g_smp[nxt], **_cap_kw()):
                     self.mfgs[nxt] = self._sample(nxt, chain, external_rng=True)
-                with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side):
+                with torch.cuda.graph(self.g_bwd[cur], pool=pool, stream=side, **_cap_kw()):
                     out[cur] = self._backward(held[cur])
         self.losses = tuple(out)
         self.graph = True
