@@ -214,6 +214,19 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_keep_write(const int* __restrict_
   if (bad && err) atomicOr(err, bad);
 }
 
+// ---- block inputs, owner side: out[i] = table[nid[i] - lo] for the rows i < K this rank owns, +0 elsewhere (the halo buffer that
+// is then summed over the ranks as integer words: the zeros must be +0 bits).  One workgroup per row, 32-bit words.
+__global__ void __launch_bounds__(128) k_sd_pack_rows(const int* __restrict__ nid, const int* __restrict__ n_rows_dev, int lo, int hi,
+                                                      const unsigned* __restrict__ table, long long table_words, int row_words,
+                                                      unsigned* __restrict__ out, long long out_words) {
+  const int i = blockIdx.x;
+  const int v = nid[i];
+  const bool mine = i < *n_rows_dev && v >= lo && v < hi;
+  const unsigned* src = table + (long long)(mine ? v - lo : 0) * table_words;
+  unsigned* dst = out + (long long)i * out_words;
+  for (int w = threadIdx.x; w < row_words; w += 128) dst[w] = mine ? src[w] : 0u;
+}
+
 inline int sd_blocks(int n) { return (n + SD_TPB - 1) / SD_TPB; }
 
 }  // namespace
@@ -237,6 +250,15 @@ int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2,
   k_sd_zero<<<grid, 256, 0, st>>>((long long*)dense, 2ll * num_nodes);       // (a kernel, not hipMemsetAsync: see k_sd_zero)
   k_sd_scatter<<<grid, 256, 0, st>>>(seeds_l, (const long long*)seed_p2, n_local_dev, (const unsigned long long*)touched_key,
                                      (const long long*)touched_sum, n_touched_dev, (long long*)dense, num_nodes, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_pack_rows(const int32_t* nid, const int32_t* n_rows_dev, int32_t cap_rows, int32_t lo, int32_t hi, const void* table_bf16,
+                          int64_t table_stride, int32_t row_len, void* out_bf16, int64_t out_stride, void* stream) {
+  if (!nid || !n_rows_dev || cap_rows <= 0 || hi <= lo || !table_bf16 || !out_bf16 || row_len <= 0 || (row_len & 1) || (table_stride & 1) ||
+      (out_stride & 1) || ((uintptr_t)table_bf16 & 3) || ((uintptr_t)out_bf16 & 3)) return BLISS_EINVAL;
+  k_sd_pack_rows<<<cap_rows, 128, 0, (hipStream_t)stream>>>(nid, n_rows_dev, lo, hi, (const unsigned*)table_bf16, table_stride / 2, row_len / 2,
+                                                            (unsigned*)out_bf16, out_stride / 2);
   return (int)hipGetLastError();
 }
 

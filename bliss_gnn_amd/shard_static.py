@@ -514,10 +514,17 @@ class StaticShardedTrainStep:
             cap_k = blk.num_src_nodes()
             if l == 0:                                             # train_lightning.py:138, owner side: my feature rows, zeros elsewhere
                 nid = blk.srcdata[NID]
-                k_dev = blk._counts_dev[3]
-                valid = (self._arange(cap_k) < k_dev) & (nid >= lo) & (nid < hi)
-                rows = g.ndata_owned["features"][(nid.long() - lo).clamp(0, n_own - 1)]
-                buf = torch.where(valid[:, None], rows, 0.0)          # (+0 bits: x * 0 can be -0, and the words are summed as integers)
+                feats = g.ndata_owned["features"]
+                if (feats.dtype == torch.bfloat16 and feats.is_cuda and feats.stride(1) == 1 and feats.shape[1] % 2 == 0 and feats.stride(0) % 2 == 0
+                        and nid.dtype == torch.int32 and nid.is_contiguous()):
+                    buf = torch.empty(cap_k, feats.shape[1], dtype=feats.dtype, device=feats.device)          # one launch: csrc/shard_dense.hip
+                    _lib.check(_lib.lib.bliss_shard_pack_rows(nid.data_ptr(), blk._counts_dev.data_ptr() + 12, cap_k, lo, hi, feats.data_ptr(),
+                                                              feats.stride(0), feats.shape[1], buf.data_ptr(), buf.stride(0),
+                                                              torch.cuda.current_stream().cuda_stream), "bliss_shard_pack_rows")
+                else:
+                    valid = (self._arange(cap_k) < blk._counts_dev[3]) & (nid >= lo) & (nid < hi)
+                    rows = feats[(nid.long() - lo).clamp(0, n_own - 1)]
+                    buf = torch.where(valid[:, None], rows, 0.0)      # (+0 bits: x * 0 can be -0, and the words are summed as integers)
                 h_src = _reduce_rows_(buf, grp)                    # (fresh, no gradient: reduced in place)
             else:                                                  # the rows I computed, at their positions of this block's source list
                 prev = blocks[l - 1]

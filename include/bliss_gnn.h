@@ -256,6 +256,11 @@ int bliss_shard_local_seeds(const int32_t* seeds_g, int32_t n_seeds, const int32
 int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2, const int32_t* n_local_dev, const int64_t* touched_key,
                                  const int64_t* touched_sum, const int32_t* n_touched_dev, int64_t* dense, int32_t num_nodes,
                                  int32_t* err, void* stream);
+/* block inputs, owner side (train_lightning.py:138 over shards): out[i, :] = table[nid[i] - lo, :] for the rows i < *n_rows_dev whose
+ * node this rank owns (lo <= nid[i] < hi), +0 bits elsewhere -- the zero-padded buffer the ranks then sum as integer words.  bf16 rows
+ * of even length, 4-byte aligned. */
+int bliss_shard_pack_rows(const int32_t* nid, const int32_t* n_rows_dev, int32_t cap_rows, int32_t lo, int32_t hi, const void* table_bf16,
+                          int64_t table_stride, int32_t row_len, void* out_bf16, int64_t out_stride, void* stream);
 int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
                            int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream);
 int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
