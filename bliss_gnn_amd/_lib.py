@@ -181,7 +181,7 @@ SIGNATURES = {
     "bliss_shard_scatter_partials": [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_shard_pack_rows": [_P, _P, _I32, _I32, _I32, _P, _I64, _I32, _P, _I64, _P],
     "bliss_shard_candidates": [_P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
-    "bliss_shard_select_kept": [_P, _P, _P, _P, C.c_uint64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P],
+    "bliss_shard_select_kept": [_P, _P, _P, _P, C.c_uint64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "bliss_gat_fused_supported": [_I32, _I32],
     "bliss_gat_segment_edges": [],
     "bliss_gat_fused_stamps": [_P, _P],

@@ -66,50 +66,63 @@ __global__ void __launch_bounds__(256) k_sd_scatter(const int* __restrict__ seed
   if (bad && err) atomicOr(err, bad);
 }
 
-// ---- ordered compaction, three launches: per-block counts, their scan, the writes ----------------------------------------------
-template <class Pred>
-__device__ __forceinline__ void sd_block_count(int n, int* __restrict__ block_cnt, Pred pred) {
-  const int i = blockIdx.x * SD_TPB + threadIdx.x;
-  const int c = __syncthreads_count(i < n && pred(i));
-  if (threadIdx.x == 0) block_cnt[blockIdx.x] = c;
-}
-
-// exclusive scan of the n_blocks counts in place; the total goes to *total
-__global__ void __launch_bounds__(SD_TPB) k_sd_scan(int* __restrict__ block_cnt, int n_blocks, int* __restrict__ total) {
-  __shared__ int sh[17];
-  int run = 0;
-  for (int base = 0; base < n_blocks; base += SD_TPB) {
-    const int i = base + threadIdx.x;
-    const int c = i < n_blocks ? block_cnt[i] : 0;
-    int tot, ex = block_excl_scan(c, sh, &tot);
-    if (i < n_blocks) block_cnt[i] = run + ex;
-    run += tot;
-    __syncthreads();
+// ---- ordered compaction in ONE launch: decoupled look-back ---------------------------------------------------------------------
+// Block b of 1024 elements needs the number of selected elements in the blocks before it.  One 64-bit status word per block:
+// tag << 62 | value, tag 1 = "my own count", tag 2 = "the inclusive prefix up to me".  A block publishes its count at once, then
+// walks back over its predecessors' words, adding counts until it meets an inclusive prefix (blocks are dispatched in index order,
+// so what it waits for is running or done; the spin is bounded like bliss_flag_wait's).  Two status arrays: the candidate pass
+// uses A and returns B to zero, the kept pass uses B and returns A to zero -- each is zero again before its next use.
+// (Round 3 started with count / scan / write launches: 18 launches per step on the critical stream.)
+#define SD_TAG_SHIFT 62
+__device__ __forceinline__ int sd_lookback(unsigned long long* status, int count, int* sh_prefix, int* err) {
+  if (threadIdx.x == 0) {
+    const int b = blockIdx.x;
+    long long ex = 0;
+    if (b == 0) {
+      __hip_atomic_store(status, (2ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(status + b, (1ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long spins = 0;
+      for (int j = b - 1; j >= 0;) {
+        const unsigned long long w = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tag = (unsigned)(w >> SD_TAG_SHIFT);
+        if (tag == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1ll << 22)) { if (err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
+          continue;
+        }
+        ex += (long long)(w & 0xffffffffull);
+        if (tag == 2) break;
+        --j;
+      }
+      __hip_atomic_store(status + b, (2ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)(ex + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *sh_prefix = (int)ex;
   }
-  if (threadIdx.x == 0) *total = run;
-}
-
-__global__ void __launch_bounds__(SD_TPB) k_sd_cand_count(const long long* __restrict__ dense, int V, int* __restrict__ block_cnt) {
-  sd_block_count(V, block_cnt, [&](int v) { return dense[(long long)V + v] != 0; });
+  __syncthreads();
+  return *sh_prefix;
 }
 
 // (the histogram is privatised in LDS like k_cand_number's: importances live in a narrow band -- sqrt of a sum of squared
 // fractions -- so a 4096-bin window + one counter for p == 0 catches them; plain global atomics on the few hot bins cost 70 us)
 #define SD_HWIN_LO 0x3000
 #define SD_HWIN_N 4096
-__global__ void __launch_bounds__(SD_TPB) k_sd_cand_write(const long long* __restrict__ dense, int V, int uniform_nodes,
-                                                          const int* __restrict__ block_off, const int* __restrict__ total,
-                                                          int* __restrict__ cand_nid, bf16_t* __restrict__ p, unsigned char* __restrict__ is_seed,
-                                                          int* __restrict__ hist, LayerCounts* cnt, int cap_c, int* err) {
+__global__ void __launch_bounds__(SD_TPB) k_sd_cand(const long long* __restrict__ dense, int V, int uniform_nodes,
+                                                    unsigned long long* __restrict__ status, unsigned long long* __restrict__ status_other, int n_other,
+                                                    int* __restrict__ cand_nid, bf16_t* __restrict__ p, unsigned char* __restrict__ is_seed,
+                                                    int* __restrict__ hist, LayerCounts* cnt, int cap_c, int* err) {
   __shared__ int sh[17];
+  __shared__ int sh_prefix;
   __shared__ int lh[SD_HWIN_N + 1];
   for (int i = threadIdx.x; i <= SD_HWIN_N; i += SD_TPB) lh[i] = 0;
+  for (int w = blockIdx.x * SD_TPB + threadIdx.x; w < n_other; w += gridDim.x * SD_TPB) status_other[w] = 0ull;   // (the kept pass's words)
   const int v = blockIdx.x * SD_TPB + threadIdx.x;
   const long long mark = v < V ? dense[(long long)V + v] : 0;
   int tot, ex = block_excl_scan(mark != 0 ? 1 : 0, sh, &tot);          // (its barriers also cover the zeroing of lh)
+  const int base = sd_lookback(status, tot, &sh_prefix, err);
   int bad = 0;
   if (mark != 0) {
-    const int at = block_off[blockIdx.x] + ex;
+    const int at = base + ex;
     if (at < cap_c) {
       const long long raw = dense[v];
       bf16_t pj;
@@ -127,8 +140,8 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_cand_write(const long long* __res
     const int c = lh[i];
     if (c) atomicAdd(&hist[i == SD_HWIN_N ? 0 : SD_HWIN_LO + i], c);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int C = *total;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {               // the last block knows the total
+    int C = base + tot;
     if (C > cap_c) C = cap_c;
     cnt->C = C; cnt->err = 0; cnt->iters = 0; cnt->all_one = 0;
   }
@@ -161,27 +174,17 @@ __device__ __forceinline__ bool sd_draw(int nid, bf16_t pj, bool seed, const Lay
   return sd_u24(key, nid) < bf2f(Pv);
 }
 
-__global__ void __launch_bounds__(SD_TPB) k_sd_keep_count(const int* __restrict__ cand_nid, const bf16_t* __restrict__ p,
-                                                          const unsigned char* __restrict__ is_seed, const LayerCounts* __restrict__ cnt,
-                                                          unsigned long long seed, const long long* __restrict__ step_dev, int layer,
-                                                          int* __restrict__ block_cnt) {
-  const unsigned long long key = sd_key(seed, (unsigned long long)*step_dev, layer);
-  sd_block_count(cnt->C, block_cnt, [&](int i) {
-    bf16_t Pv;
-    const bool s = is_seed[i] != 0;
-    return sd_draw(cand_nid[i], p[i], s, cnt, key, &Pv) && !s;
-  });
-}
-
-__global__ void __launch_bounds__(SD_TPB) k_sd_keep_write(const int* __restrict__ cand_nid, const bf16_t* __restrict__ p,
-                                                          const unsigned char* __restrict__ is_seed, const LayerCounts* __restrict__ cnt,
-                                                          unsigned long long seed, const long long* __restrict__ step_dev, int layer,
-                                                          const int* __restrict__ block_off, const int* __restrict__ total,
-                                                          const int* __restrict__ seeds_g, int n_seeds, const int* __restrict__ n_seeds_dev,
-                                                          bf16_t* __restrict__ P_out, int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
-                                                          int* __restrict__ kept_map, int cap_k, LayerCounts* layer_cnt,
-                                                          const int* __restrict__ n_local_dev, int* err) {
+__global__ void __launch_bounds__(SD_TPB) k_sd_keep(const int* __restrict__ cand_nid, const bf16_t* __restrict__ p,
+                                                    const unsigned char* __restrict__ is_seed, const LayerCounts* __restrict__ cnt,
+                                                    unsigned long long seed, const long long* __restrict__ step_dev, int layer,
+                                                    unsigned long long* __restrict__ status, unsigned long long* __restrict__ status_other, int n_other,
+                                                    const int* __restrict__ seeds_g, int n_seeds, const int* __restrict__ n_seeds_dev,
+                                                    bf16_t* __restrict__ P_out, int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
+                                                    int* __restrict__ kept_map, int cap_k, LayerCounts* layer_cnt,
+                                                    const int* __restrict__ n_local_dev, int* err) {
   __shared__ int sh[17];
+  __shared__ int sh_prefix;
+  for (int w = blockIdx.x * SD_TPB + threadIdx.x; w < n_other; w += gridDim.x * SD_TPB) status_other[w] = 0ull;   // (the candidate pass's words)
   const unsigned long long key = sd_key(seed, (unsigned long long)*step_dev, layer);
   const int S = n_seeds >= 0 ? n_seeds : *n_seeds_dev;
   const int C = cnt->C;
@@ -194,9 +197,10 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_keep_write(const int* __restrict_
     P_out[i] = Pv;
   }
   int tot, ex = block_excl_scan(keep_new, sh, &tot);
+  const int base = sd_lookback(status, tot, &sh_prefix, err);
   int bad = 0;
   if (keep_new) {
-    const int at = S + block_off[blockIdx.x] + ex;      // the seeds come first, in seed order (bandit_sampler.py:408-414 union)
+    const int at = S + base + ex;                       // the seeds come first, in seed order (bandit_sampler.py:408-414 union)
     if (at < cap_k) { kept_nid[at] = cand_nid[i]; node_prob[at] = Pv; kept_map[cand_nid[i]] = at; }
     else bad |= BLISS_ERR_CAP_KEPT;
   }
@@ -205,8 +209,8 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_keep_write(const int* __restrict_
     if (j < cap_k) { const int v = seeds_g[j]; kept_nid[j] = v; node_prob[j] = 0x3f80; kept_map[v] = j; }
     else bad |= BLISS_ERR_CAP_KEPT;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int K = S + *total;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    int K = S + base + tot;
     if (K > cap_k) K = cap_k;
     layer_cnt->K = K;
     layer_cnt->C = *n_local_dev;                        // what bliss_build_block's clean-up walks: cand_nid[0 .. C) = this rank's seeds
@@ -264,30 +268,29 @@ int bliss_shard_pack_rows(const int32_t* nid, const int32_t* n_rows_dev, int32_t
 
 int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
                            int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream) {
-  if (!dense || num_nodes <= 0 || !cand_nid || !p_bf16 || !is_seed || !hist || !counts || cap_c <= 0 || !scratch) return BLISS_EINVAL;
+  if (!dense || num_nodes <= 0 || !cand_nid || !p_bf16 || !is_seed || !hist || !counts || cap_c <= 0 || !scratch || ((uintptr_t)scratch & 7))
+    return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = sd_blocks(num_nodes);                  // scratch: int32[nb + 1]
-  k_sd_cand_count<<<nb, SD_TPB, 0, st>>>((const long long*)dense, num_nodes, scratch);
-  k_sd_scan<<<1, SD_TPB, 0, st>>>(scratch, nb, scratch + nb);
-  k_sd_cand_write<<<nb, SD_TPB, 0, st>>>((const long long*)dense, num_nodes, uniform_nodes, scratch, scratch + nb, cand_nid, (bf16_t*)p_bf16,
-                                         is_seed, hist, (LayerCounts*)counts, cap_c, err);
+  const int nb = sd_blocks(num_nodes), nb_k = sd_blocks(cap_c);   // scratch: uint64[nb + nb_k] -- this pass's status words, then the kept pass's
+  unsigned long long* st_a = reinterpret_cast<unsigned long long*>(scratch);
+  k_sd_cand<<<nb, SD_TPB, 0, st>>>((const long long*)dense, num_nodes, uniform_nodes, st_a, st_a + nb, nb_k, cand_nid, (bf16_t*)p_bf16, is_seed, hist,
+                                   (LayerCounts*)counts, cap_c, err);
   return (int)hipGetLastError();
 }
 
 int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
                             const int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
                             void* P_bf16, int32_t* kept_nid, void* node_prob_bf16, int32_t* kept_map, int32_t cap_k, int32_t cap_c,
-                            void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t* err, void* stream) {
+                            int32_t num_nodes, void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t* err, void* stream) {
   if (!cand_nid || !p_bf16 || !is_seed || !counts || !step_dev || !seeds_g || (n_seeds < 0 && !n_seeds_dev) || !P_bf16 || !kept_nid ||
-      !node_prob_bf16 || !kept_map || cap_k <= 0 || cap_c <= 0 || !layer_counts || !n_local_dev || !scratch) return BLISS_EINVAL;
+      !node_prob_bf16 || !kept_map || cap_k <= 0 || cap_c <= 0 || num_nodes <= 0 || !layer_counts || !n_local_dev || !scratch ||
+      ((uintptr_t)scratch & 7)) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = sd_blocks(cap_c);                      // scratch: int32[nb + 1]; blocks beyond the true count find nothing
-  k_sd_keep_count<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (const long long*)step_dev,
-                                         layer, scratch);
-  k_sd_scan<<<1, SD_TPB, 0, st>>>(scratch, nb, scratch + nb);
-  k_sd_keep_write<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (const long long*)step_dev,
-                                         layer, scratch, scratch + nb, seeds_g, n_seeds, n_seeds_dev, (bf16_t*)P_bf16, kept_nid,
-                                         (bf16_t*)node_prob_bf16, kept_map, cap_k, (LayerCounts*)layer_counts, n_local_dev, err);
+  const int nb = sd_blocks(cap_c), nb_c = sd_blocks(num_nodes);   // scratch: the SAME array as bliss_shard_candidates'; blocks beyond the count find nothing
+  unsigned long long* st_a = reinterpret_cast<unsigned long long*>(scratch);
+  k_sd_keep<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (const long long*)step_dev, layer,
+                                   st_a + nb_c, st_a, nb_c, seeds_g, n_seeds, n_seeds_dev, (bf16_t*)P_bf16, kept_nid, (bf16_t*)node_prob_bf16, kept_map,
+                                   cap_k, (LayerCounts*)layer_counts, n_local_dev, err);
   return (int)hipGetLastError();
 }
 

@@ -124,7 +124,7 @@ class DenseShardedSampler:
                  dense=torch.zeros(2 * V, dtype=torch.int64, device=dev),
                  cand=torch.zeros(V, dtype=torch.int32, device=dev), p=torch.zeros(V, dtype=torch.bfloat16, device=dev),
                  P=torch.zeros(V, dtype=torch.bfloat16, device=dev), is_seed=torch.zeros(V, dtype=torch.uint8, device=dev),
-                 scr_a=torch.zeros(nb, dtype=torch.int32, device=dev), scr_b=torch.zeros(nb, dtype=torch.int32, device=dev),
+                 scr_a=torch.zeros(2 * nb, dtype=torch.int64, device=dev),    # status words of the two ordered compactions
                  sel=torch.zeros(nb, dtype=torch.int32, device=dev), err=torch.zeros(1, dtype=torch.int32, device=dev),
                  step=torch.zeros(1, dtype=torch.int64, device=dev), seeds0=torch.zeros(S0, dtype=torch.int32, device=dev),
                  seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
@@ -210,7 +210,7 @@ class DenseShardedSampler:
                 chk(lib.bliss_poisson_scale(eng.hist.data_ptr(), rec_ptr, int(fan[n]), 0.9999, b["sel"].data_ptr(), st), "bliss_poisson_scale")
                 chk(lib.bliss_shard_select_kept(b["cand"].data_ptr(), b["p"].data_ptr(), b["is_seed"].data_ptr(), rec_ptr, self.seed, b["step"].data_ptr(),
                                                 n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
-                                                c_ws.kept_map, cap["K"], V, cnt_ptr, nloc_ptr, b["scr_b"].data_ptr(), b["err"].data_ptr(), st),
+                                                c_ws.kept_map, cap["K"], V, V, cnt_ptr, nloc_ptr, b["scr_a"].data_ptr(), b["err"].data_ptr(), st),
                     "bliss_shard_select_kept")
                 if hook is not None and part == "select":
                     hook(n)
