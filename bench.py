@@ -454,6 +454,28 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
             edges_dev.add_(sum(b.num_edges() for b in step.last["mfgs"]))
     for _ in range(args.warmup):
         one()
+    if static and step.graph is not None:
+        # the replayed loop is checked BEFORE it is timed (error words, flag time-outs), on every rank; if any rank objects, all ranks
+        # go on with the same step launched kernel by kernel (same collectives in the same order, so the ranks stay in step)
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            step.finish()
+        except RuntimeError as e:
+            print("rank %d: the captured sharded loop failed its check (%s)" % (rank, e), file=sys.stderr)
+            ok.zero_()
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            step.graph = None
+            launch = "static shapes, launched kernel by kernel (the captured loop failed its check on this node)"
+            eng = sampler.ops.eng
+            for w in (sampler._bufs["err"], eng.flag_err, eng.flags):
+                w.zero_()
+            torch.cuda.synchronize()
+            if pipelined:
+                step.prime(next(loader))
+            for _ in range(max(2, args.warmup // 4)):
+                one()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -471,7 +493,10 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, edges = float(tmax[0]), float(tsum[1])
-    sampler.check_errors()
+    if static:
+        step.finish()                                              # (error words, capacity overflows, flag time-outs: a bad run raises here)
+    else:
+        sampler.check_errors()
     roof = None
     if static and rank == 0 and not args.no_roofline:
         # the dominant library kernel of the sampler, timed with HIP events over a few steps launched kernel by kernel

@@ -141,6 +141,7 @@ SIGNATURES = {
     "bliss_rng_prepare": [_I32, _P],
     "bliss_mt_jump_poly": [_I64, _P],
     "bliss_flag_wait": [_P, _P, _P],
+    "bliss_flag_set_spin_bound": [C.c_int64],
     "bliss_flag_raise": [_P, _P],
     "bliss_gather_rows": [_P, _I64, _P, _I32, _I32, _P, _I64, _P, _P],
     "bliss_exp3_apply_ranks": [C.POINTER(Exp3RankLists), _P, _P, _P, _P],
@@ -180,6 +181,8 @@ SIGNATURES = {
     "bliss_shard_local_seeds": [_P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],
     "bliss_shard_scatter_partials": [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
     "bliss_shard_pack_rows": [_P, _P, _I32, _I32, _I32, _P, _I64, _I32, _P, _I64, _P],
+    "bliss_shard_place_rows": [_P, _I64, _P, _P, _I32, _P, _I64, _I32, _I32, _P],
+    "bliss_shard_take_rows": [_P, _I32, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P],
     "bliss_shard_candidates": [_P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "bliss_shard_select_kept": [_P, _P, _P, _P, C.c_uint64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
     "bliss_gat_fused_supported": [_I32, _I32],

@@ -1414,13 +1414,15 @@ inline int grid_for(int64_t n, int per_block, int max_blocks = 8192) {
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // one wave: wait until a producer on another stream has raised *flag (k_seg_scan's entry_flag), then lower it again.
-// Bounded: a flag that never comes (~1 s) sets *err and lets the stream continue, so the grid always drains.
-__global__ void __launch_bounds__(64) k_flag_wait(int* flag, int* err) {
+// Bounded: a flag that never comes (~1 s by default, bliss_flag_set_spin_bound) sets *err and lets the stream continue, so the
+// grid always drains.
+static long long g_flag_spin_bound = 1ll << 22;
+__global__ void __launch_bounds__(64) k_flag_wait(int* flag, int* err, long long bound) {
   if (threadIdx.x != 0) return;
   long long spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
     __builtin_amdgcn_s_sleep(8);
-    if (++spins > (1ll << 22)) { if (err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
+    if (++spins > bound) { if (err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1442,8 +1444,14 @@ int bliss_flag_raise(int32_t* flag, void* stream) {
 
 int bliss_flag_wait(int32_t* flag, int32_t* err_word, void* stream) {
   if (!flag) return BLISS_EINVAL;
-  k_flag_wait<<<1, 64, 0, (hipStream_t)stream>>>(flag, err_word);
+  k_flag_wait<<<1, 64, 0, (hipStream_t)stream>>>(flag, err_word, g_flag_spin_bound);
   return (int)hipGetLastError();
+}
+
+int bliss_flag_set_spin_bound(int64_t spins) {
+  if (spins < 1) return BLISS_EINVAL;
+  g_flag_spin_bound = spins;
+  return 0;
 }
 
 int bliss_frontier_prob(const bliss_graph_t* g, const bliss_node_maps_t* m, const void* w_pos, const int32_t* seeds,

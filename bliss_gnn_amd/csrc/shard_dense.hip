@@ -231,6 +231,58 @@ __global__ void __launch_bounds__(128) k_sd_pack_rows(const int* __restrict__ ni
   for (int w = threadIdx.x; w < row_words; w += 128) dst[w] = mine ? src[w] : 0u;
 }
 
+// ---- rows between a rank's own list and a block's list (the halo buffers of the layers behind the first, and the destination rows
+// of every layer).  pos[j], j < *n_dev: the position of this rank's j-th row in the block's list, ASCENDING (the own rows keep the
+// list's order: k_sd_local_seeds).  One wave per row, 32-bit words (two bf16).
+//   place: out[r] = src[j] where pos[j] == r, +0 bits for every other row (binary search: no zero-fill launch, no atomics)
+//   take:  out[j] = bf16(src[pos[j]]) for j < *n_dev, +0 bits for the rows behind (src bf16 or fp32, RNE as torch's .to(bfloat16))
+__global__ void __launch_bounds__(256) k_sd_place_rows(const unsigned* __restrict__ src, long long src_words, const int* __restrict__ pos,
+                                                       const int* __restrict__ n_dev, int cap_s, unsigned* __restrict__ out, long long out_words,
+                                                       int n_rows, int row_words) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  int n = *n_dev;
+  if (n > cap_s) n = cap_s;
+  int lo = 0, hi = n;                                   // the first j with pos[j] >= r
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (pos[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  const bool hit = lo < n && pos[lo] == r;
+  const unsigned* s = src + (long long)(hit ? lo : 0) * src_words;
+  unsigned* d = out + (long long)r * out_words;
+  for (int w = lane; w < row_words; w += 64) d[w] = hit ? s[w] : 0u;
+}
+
+template <bool F32>
+__global__ void __launch_bounds__(256) k_sd_take_rows(const void* __restrict__ src, long long src_stride, int n_src_rows, const int* __restrict__ pos,
+                                                      const int* __restrict__ n_dev, int cap_s, unsigned* __restrict__ out, long long out_words,
+                                                      int row_words) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= cap_s) return;
+  const int lane = threadIdx.x & 63;
+  int n = n_dev ? *n_dev : cap_s;
+  if (n > cap_s) n = cap_s;
+  int p = j < n ? pos[j] : -1;
+  if (p >= n_src_rows) p = -1;
+  unsigned* d = out + (long long)j * out_words;
+  if (p < 0) {
+    for (int w = lane; w < row_words; w += 64) d[w] = 0u;
+    return;
+  }
+  if (F32) {
+    const float2* s = reinterpret_cast<const float2*>(static_cast<const float*>(src) + (long long)p * src_stride);
+    for (int w = lane; w < row_words; w += 64) {
+      const float2 v = s[w];
+      d[w] = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    }
+  } else {
+    const unsigned* s = reinterpret_cast<const unsigned*>(static_cast<const bf16_t*>(src) + (long long)p * src_stride);
+    for (int w = lane; w < row_words; w += 64) d[w] = s[w];
+  }
+}
+
 inline int sd_blocks(int n) { return (n + SD_TPB - 1) / SD_TPB; }
 
 }  // namespace
@@ -263,6 +315,26 @@ int bliss_shard_pack_rows(const int32_t* nid, const int32_t* n_rows_dev, int32_t
       (out_stride & 1) || ((uintptr_t)table_bf16 & 3) || ((uintptr_t)out_bf16 & 3)) return BLISS_EINVAL;
   k_sd_pack_rows<<<cap_rows, 128, 0, (hipStream_t)stream>>>(nid, n_rows_dev, lo, hi, (const unsigned*)table_bf16, table_stride / 2, row_len / 2,
                                                             (unsigned*)out_bf16, out_stride / 2);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_place_rows(const void* src_bf16, int64_t src_stride, const int32_t* pos, const int32_t* n_dev, int32_t cap_s, void* out_bf16,
+                           int64_t out_stride, int32_t n_rows, int32_t row_len, void* stream) {
+  if (!src_bf16 || !pos || !n_dev || cap_s <= 0 || !out_bf16 || n_rows <= 0 || row_len <= 0 || (row_len & 1) || (src_stride & 1) || (out_stride & 1) ||
+      ((uintptr_t)src_bf16 & 3) || ((uintptr_t)out_bf16 & 3)) return BLISS_EINVAL;
+  k_sd_place_rows<<<(n_rows + 3) / 4, 256, 0, (hipStream_t)stream>>>((const unsigned*)src_bf16, src_stride / 2, pos, n_dev, cap_s, (unsigned*)out_bf16,
+                                                                     out_stride / 2, n_rows, row_len / 2);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_take_rows(const void* src, int32_t src_is_f32, int64_t src_stride, int32_t n_src_rows, const int32_t* pos, const int32_t* n_dev,
+                          int32_t cap_s, void* out_bf16, int64_t out_stride, int32_t row_len, void* stream) {
+  if (!src || !pos || cap_s <= 0 || n_src_rows <= 0 || !out_bf16 || row_len <= 0 || (row_len & 1) || (src_stride & 1) || (out_stride & 1) ||
+      ((uintptr_t)src & (src_is_f32 ? 7 : 3)) || ((uintptr_t)out_bf16 & 3)) return BLISS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (cap_s + 3) / 4;
+  if (src_is_f32) k_sd_take_rows<true><<<nb, 256, 0, st>>>(src, src_stride, n_src_rows, pos, n_dev, cap_s, (unsigned*)out_bf16, out_stride / 2, row_len / 2);
+  else k_sd_take_rows<false><<<nb, 256, 0, st>>>(src, src_stride, n_src_rows, pos, n_dev, cap_s, (unsigned*)out_bf16, out_stride / 2, row_len / 2);
   return (int)hipGetLastError();
 }
 

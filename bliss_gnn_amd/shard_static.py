@@ -412,6 +412,63 @@ class _PlaceRows(torch.autograd.Function):
         return torch.index_select(gp, 0, idx), None, None
 
 
+def _hip_rows(x, pos):
+    """The in-tree row kernels (csrc/shard_dense.hip) take bf16 rows of even length on the GPU and int32 positions."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] % 2 == 0 and pos.dtype == torch.int32 and pos.is_contiguous())
+
+
+def _place_rows(src, pos, n_dev, n_rows):
+    src = src.contiguous()
+    out = torch.empty(int(n_rows), src.shape[1], dtype=src.dtype, device=src.device)
+    _lib.check(_lib.lib.bliss_shard_place_rows(src.data_ptr(), src.stride(0), pos.data_ptr(), n_dev.data_ptr(), min(src.shape[0], pos.numel()),
+                                               out.data_ptr(), out.stride(0), int(n_rows), src.shape[1],
+                                               torch.cuda.current_stream().cuda_stream), "bliss_shard_place_rows")
+    return out
+
+
+def _take_rows(src, pos, n_dev, cap_s):
+    src = src.contiguous()
+    out = torch.empty(int(cap_s), src.shape[1], dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.lib.bliss_shard_take_rows(src.data_ptr(), 1 if src.dtype == torch.float32 else 0, src.stride(0), src.shape[0], pos.data_ptr(),
+                                              n_dev.data_ptr(), int(cap_s), out.data_ptr(), out.stride(0), src.shape[1],
+                                              torch.cuda.current_stream().cuda_stream), "bliss_shard_take_rows")
+    return out
+
+
+class _TakeRowsHip(torch.autograd.Function):
+    """_TakeRows in one launch each way: x[pos[j]] for this rank's j < *n_dev rows (+0 behind); backward: the rows back at their
+    positions, +0 elsewhere (pos ascending: no zero-fill, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, n_dev):
+        ctx.save_for_backward(pos, n_dev)
+        ctx.n = x.shape[0]
+        return _take_rows(x, pos, n_dev, pos.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, n_dev = ctx.saved_tensors
+        return _place_rows(g, pos, n_dev, ctx.n), None, None
+
+
+class _PlaceAndReduceHip(torch.autograd.Function):
+    """_PlaceAndReduce on the in-tree row kernels: the zero-padded buffer in one launch, the halo all-reduce on it in place;
+    backward: the fp32 gradient buffer summed over the ranks, then this rank's rows of it, rounded to bf16, in one launch."""
+
+    @staticmethod
+    def forward(ctx, h, pos, n_dev, n_rows, group, group_bwd=None):
+        ctx.save_for_backward(pos, n_dev)
+        ctx.cap_s, ctx.group = h.shape[0], (group if group_bwd is None else group_bwd)
+        return _reduce_rows_(_place_rows(h, pos, n_dev, n_rows), group)
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, n_dev = ctx.saved_tensors
+        gp = g.float().contiguous()
+        _all_reduce(gp, ctx.group)                               # a row's gradient: the sum over the ranks that consumed it
+        return _take_rows(gp, pos, n_dev, ctx.cap_s), None, None, None, None, None
+
+
 def _xdev_of(t, group=None):
     return t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
@@ -529,14 +586,19 @@ class StaticShardedTrainStep:
             else:                                                  # the rows I computed, at their positions of this block's source list
                 prev = blocks[l - 1]
                 cap_s = prev.num_dst_nodes()
-                n_prev = n_local[L - l]                            # block l-1 <-> sampling layer L-l
-                idx = torch.where(self._arange(cap_s) < n_prev, prev.dst_pos.long(), cap_k)
-                h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp, self._group_bwd())
+                if _hip_rows(h, prev.dst_pos):                      # block l-1 <-> sampling layer L-l
+                    h_src = _PlaceAndReduceHip.apply(h, prev.dst_pos, n_local[L - l: L - l + 1], cap_k, grp, self._group_bwd())
+                else:
+                    idx = torch.where(self._arange(cap_s) < n_local[L - l], prev.dst_pos.long(), cap_k)
+                    h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp, self._group_bwd())
             halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
             blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
             # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
             # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
-            h_dst = _TakeRows.apply(h_src, blk.dst_pos.long())
+            if _hip_rows(h_src, blk.dst_pos):
+                h_dst = _TakeRowsHip.apply(h_src, blk.dst_pos, n_local[L - 1 - l: L - l])
+            else:
+                h_dst = _TakeRows.apply(h_src, blk.dst_pos.long())
             if self._fused_layer_ok(layer, h_src):
                 # an aggregate-first layer's tail on the in-tree MFMA tiles (nn._SageDualLinear: fc_neigh(h_neigh) + fc_self(h_dst) +
                 # bias, ReLU and dropout in ONE launch, its backward on csrc/sage_bwd.hip) -- the true row count from the device
@@ -864,6 +926,10 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                 self._sample(s)
         import os
         self.use_flags = os.environ.get("BLISS_SHARD_FLAGS", "1") != "0" and self._flags_usable()
+        if self.use_flags and self.g.world > 1:
+            # the waits of this loop sit in front of work that contains collectives: a peer's hiccup of a second must not read as
+            # "the flag never came" (the bound is a kernel argument: it is captured with the graphs below)
+            _lib.check(_lib.lib.bliss_flag_set_spin_bound(1 << 27), "bliss_flag_set_spin_bound")
         # BLISS_SHARD_THIRD=1: the next batch's blocks as a graph of their own on a third stream, layer by layer behind "layer n's kept
         # list is final" flags (the single-GPU loop's arrangement).  Correct (same bits) but 2.6 ms/step instead of 1.02 here: the
         # spinning waits of that graph sit on a hardware queue the backward pass needs -- measured, off by default

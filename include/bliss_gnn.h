@@ -137,6 +137,9 @@ int bliss_layer_counts_bytes(void);
  * resets it to 0.  One producer and one consumer per flag and round.  The wait is bounded (~1 s): on a timeout bit 256
  * is OR-ed into *err_word (optional) and the stream continues. */
 int bliss_flag_wait(int32_t* flag, int32_t* err_word, void* stream);
+/* The bound of the waits enqueued from now on, in polls (~0.25 us each; default 2^22).  A loop whose flags wait on work that
+ * contains collectives raises it: a peer rank's hiccup must not read as "the flag never came". */
+int bliss_flag_set_spin_bound(int64_t spins);
 /* Raise *flag from `stream` (a one-thread kernel).  The hot path raises its flags from kernels it runs anyway
  * (entry_flag); this entry point exists so that a caller can PROBE, with harmless kernels, whether a wait enqueued on one
  * stream and a raise enqueued later on another really run side by side (they do not when the two streams share a
@@ -264,6 +267,17 @@ int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2,
  * of even length, 4-byte aligned. */
 int bliss_shard_pack_rows(const int32_t* nid, const int32_t* n_rows_dev, int32_t cap_rows, int32_t lo, int32_t hi, const void* table_bf16,
                           int64_t table_stride, int32_t row_len, void* out_bf16, int64_t out_stride, void* stream);
+/* rows between a rank's own list and a block's list (model.py:318-332 over shards: the inputs of the layers behind the first, the
+ * destination rows h[:num_dst] of every layer, and the gradients on the way back).  pos[j], j < *n_dev (<= cap_s): the position of this
+ * rank's j-th row in the block's list, ASCENDING.  bf16 rows of even length, 4-byte aligned (fp32 source: 8-byte).
+ *   bliss_shard_place_rows: out[r, :] = src[j, :] where pos[j] == r, +0 bits for every other row r < n_rows -- the zero-padded buffer
+ *                           that is then summed over the ranks as integer words, in one launch;
+ *   bliss_shard_take_rows:  out[j, :] = bf16(src[pos[j], :]) for j < *n_dev (n_dev NULL: all cap_s rows), +0 bits behind; src is bf16,
+ *                           or fp32 rounded to nearest even (the all-reduced gradient buffer). */
+int bliss_shard_place_rows(const void* src_bf16, int64_t src_stride, const int32_t* pos, const int32_t* n_dev, int32_t cap_s, void* out_bf16,
+                           int64_t out_stride, int32_t n_rows, int32_t row_len, void* stream);
+int bliss_shard_take_rows(const void* src, int32_t src_is_f32, int64_t src_stride, int32_t n_src_rows, const int32_t* pos, const int32_t* n_dev,
+                          int32_t cap_s, void* out_bf16, int64_t out_stride, int32_t row_len, void* stream);
 int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
                            int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream);
 int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,

@@ -1,0 +1,17 @@
+"""Per-queue busy time from a rocprofv3 kernel trace (scratch tool): python scratch/trace_streams.py <kernel_trace.csv> [skip_frac]"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = len(rows)
+rows = rows[int(n * 0.5):int(n * 0.9)]                     # the timed region's middle
+t0, t1 = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
+qkey = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
+busy = collections.defaultdict(int); cnt = collections.defaultdict(int); names = collections.defaultdict(lambda: collections.defaultdict(int))
+for r in rows:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    q = r[qkey]; busy[q] += d; cnt[q] += 1; names[q][r["Kernel_Name"][:70]] += d
+print("window %.3f ms, %d kernels, key %s" % ((t1 - t0) / 1e6, len(rows), qkey))
+for q in busy:
+    print("queue %s: busy %.3f ms (%.1f%%), %d launches" % (q, busy[q] / 1e6, 100.0 * busy[q] / (t1 - t0), cnt[q]))
+    for k, v in sorted(names[q].items(), key=lambda kv: -kv[1])[:14]:
+        print("    %6.1f%%  %s" % (100.0 * v / busy[q], k))

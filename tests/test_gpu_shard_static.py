@@ -267,3 +267,53 @@ def test_pipelined_sharded_loop_trains_like_the_one_stream_step(cuda):
             assert torch.equal(outs[kind][2], outs["one-stream"][2]), kind
     finally:
         dist.destroy_process_group()
+
+
+def test_row_kernels_place_and_take(cuda):
+    """bliss_shard_place_rows / bliss_shard_take_rows against the torch form they replace (zeros + index_copy_; index_select +
+    .to(bfloat16)): same bits, including the +0 padding rows and the round-to-nearest-even of the fp32 gradient buffer."""
+    from bliss_gnn_amd import shard_static as ss
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    for cap_s, n, n_rows, D in ((64, 37, 500, 256), (300, 300, 301, 602), (128, 0, 77, 2), (50, 1, 9, 130)):
+        pos_true = torch.sort(torch.randperm(n_rows, generator=gen)[:n]).values.to(torch.int32)
+        pos = torch.zeros(cap_s, dtype=torch.int32)
+        pos[:n] = pos_true                                        # (the padding entries point at row 0, as the sampler leaves them)
+        pos, n_dev = pos.to(dev), torch.tensor([n], dtype=torch.int32, device=dev)
+        h = torch.randn(cap_s, D, generator=gen).to(dev).bfloat16()
+        out = ss._place_rows(h, pos, n_dev, n_rows)
+        want = torch.zeros(n_rows, D, dtype=torch.bfloat16, device=dev)
+        want[pos_true.long().to(dev)] = h[:n]
+        assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+        for src in (torch.randn(n_rows, D, generator=gen).to(dev).bfloat16(), (torch.randn(n_rows, D, generator=gen) * 3).to(dev)):
+            got = ss._take_rows(src, pos, n_dev, cap_s)
+            ref = torch.zeros(cap_s, D, dtype=torch.bfloat16, device=dev)
+            ref[:n] = src[pos_true.long().to(dev)].to(torch.bfloat16)
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # through autograd: the same values and gradients as the index forms
+    cap_s, n, n_rows, D = 96, 70, 400, 64
+    pos_true = torch.sort(torch.randperm(n_rows, generator=gen)[:n]).values
+    pos = torch.zeros(cap_s, dtype=torch.int32); pos[:n] = pos_true.to(torch.int32)
+    pos, n_dev = pos.to(dev), torch.tensor([n], dtype=torch.int32, device=dev)
+    x = torch.randn(n_rows, D, generator=gen).to(dev).bfloat16()
+    w = torch.randn(cap_s, D, generator=gen).to(dev).bfloat16()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = ss._TakeRowsHip.apply(xa, pos, n_dev)
+    yb = ss._TakeRows.apply(xb, pos.long())
+    assert torch.equal(ya[:n], yb[:n]) and not ya[n:].any()
+    mask = (torch.arange(cap_s, device=dev) < n)[:, None]
+    (ya * w).sum().backward(); (torch.where(mask, yb, 0.0) * w).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29747"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        ha, hb = w.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        za = ss._PlaceAndReduceHip.apply(ha, pos, n_dev, n_rows, None, None)
+        idx = torch.where(torch.arange(cap_s, device=dev) < n, pos.long(), n_rows)
+        zb = ss._PlaceAndReduce.apply(hb, idx, n_rows, None, None)
+        assert torch.equal(za.view(torch.int16), zb.view(torch.int16))
+        (za.float() * x.float()).sum().backward(); (zb.float() * x.float()).sum().backward()
+        assert torch.equal(ha.grad, hb.grad)
+    finally:
+        dist.destroy_process_group()
