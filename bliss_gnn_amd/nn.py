@@ -337,6 +337,51 @@ class _SageLinearPair(torch.autograd.Function):
         return dx, None, d_wn, d_ws, d_b, None, None, None, None
 
 
+class _SageLinearSplit(torch.autograd.Function):
+    """_SageLinearPair for a block whose destinations are NOT its leading source rows (a shard's block: the destinations are
+    this rank's seeds, anywhere in the global source list): fc_neigh over the source rows and fc_self (+bias) over the
+    destination rows handed in beside them, ONE launch; the input rows' bf16 norms come with it.  Backward on
+    csrc/sage_bwd.hip: both weight gradients and the bias gradient in one launch pair, an input gradient per operand."""
+
+    @staticmethod
+    def forward(ctx, x_src, x_dst, w_neigh, w_self, b_self, src_dev, dst_dev):
+        ctx.set_materialize_grads(False)
+        xs, xd, wn, ws = _bf16c(x_src), _bf16c(x_dst), _bf16c(w_neigh), _bf16c(w_self)
+        dev, n_out = xs.device, wn.shape[0]
+        z = torch.empty(xs.shape[0], n_out, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(xd.shape[0], n_out, dtype=torch.bfloat16, device=dev)
+        norm = torch.empty(xs.shape[0], dtype=torch.bfloat16, device=dev)
+        _tile_gemm(_tg_args(xs, wn, z, xs.shape[0], m_dev=src_dev, in_norm=norm),
+                   _tg_args(xd, ws, y, xd.shape[0], bias=b_self, m_dev=dst_dev))
+        ctx.save_for_backward(xs, xd, wn, ws)
+        ctx.has_bias, ctx.src_dev, ctx.dst_dev = b_self is not None, src_dev, dst_dev
+        ctx.mark_non_differentiable(norm)
+        return z, y, norm
+
+    @staticmethod
+    def backward(ctx, dz, dy, _dnorm):
+        xs, xd, wn, ws = ctx.saved_tensors
+        d_wn = d_ws = d_b = dxs = dxd = None
+        probs = []
+        if dz is not None:
+            dz = _bf16c(dz)
+            probs.append((dz, xs, xs.shape[0], ctx.src_dev, False))
+        if dy is not None:
+            dy = _bf16c(dy)
+            probs.append((dy, xd, xd.shape[0], ctx.dst_dev, ctx.has_bias))
+        if probs:
+            outs = sage_wgrad(probs)
+            if dz is not None:
+                d_wn = outs[0][0]
+            if dy is not None:
+                d_ws, d_b = outs[-1]
+        if dz is not None and ctx.needs_input_grad[0]:
+            dxs = sage_dgrad(dz, wn, xs.shape[0], ctx.src_dev)
+        if dy is not None and ctx.needs_input_grad[1]:
+            dxd = sage_dgrad(dy, ws, xd.shape[0], ctx.dst_dev)
+        return dxs, dxd, d_wn, d_ws, d_b, None, None
+
+
 _ones_rows = {}
 
 

@@ -559,6 +559,18 @@ class StaticShardedTrainStep:
                 and tile_gemm_ok(layer._in_src_feats, layer._out_feats) and layer.fc_self.bias is not None and layer.norm is None
                 and layer.activation is None and layer.feat_drop.p == 0)
 
+    def _split_layer_ok(self, layer, h):
+        """The same for a Linear-first SAGEConv (in > out): nn._SageLinearSplit + the fused epilogue."""
+        import os
+        from .nn import tile_gemm_ok
+        m = self.model
+        act = getattr(m, "activation", None)
+        relu = act in (torch.relu, torch.nn.functional.relu) or isinstance(act, torch.nn.ReLU)
+        return (os.environ.get("BLISS_SHARD_MFMA", "1") != "0" and relu and hasattr(m, "_dropout_state") and isinstance(m.dropout, torch.nn.Dropout)
+                and h.is_cuda and h.dtype == torch.bfloat16 and layer._in_src_feats > layer._out_feats
+                and tile_gemm_ok(layer._in_src_feats, layer._out_feats) and layer.fc_self.bias is not None and layer.norm is None
+                and layer.activation is None and layer.feat_drop.p == 0)
+
     def _forward(self, blocks, slot=0):
         from .nn import embed_norm
         g, model, grp = self.g, self.model, self.group
@@ -592,7 +604,9 @@ class StaticShardedTrainStep:
                     idx = torch.where(self._arange(cap_s) < n_local[L - l], prev.dst_pos.long(), cap_k)
                     h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp, self._group_bwd())
             halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
-            blk.srcdata["embed_norm"] = embed_norm(h_src)          # model.py:318-320
+            split = self._split_layer_ok(layer, h_src)
+            if not split:
+                blk.srcdata["embed_norm"] = embed_norm(h_src)      # model.py:318-320
             # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
             # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
             if _hip_rows(h_src, blk.dst_pos):
@@ -610,6 +624,19 @@ class StaticShardedTrainStep:
                 rows_dev = n_local.data_ptr() + 4 * (L - 1 - l)
                 h, _ = _SageDualLinear.apply(agg, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias, not last, p, ctr, seed,
                                              blk.num_dst_nodes(), rows_dev)
+            elif split:
+                # a Linear-first layer: fc_neigh over the source rows, fc_self + bias over the destination rows and the source rows'
+                # norms (:318-320, same bits as embed_norm) in ONE launch on the MFMA tiles; then the aggregation; then the sum, ReLU
+                # and dropout (:321-333) in one launch.  True row counts from the device (K of the block, this rank's destinations)
+                from .nn import _SageLinearSplit, sage_epilogue, weighted_aggregate
+                last = l == L - 1
+                p = model.dropout.p if (model.training and not last) else 0.0
+                ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
+                z, y, in_norm = _SageLinearSplit.apply(h_src, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias,
+                                                       blk._counts_dev.data_ptr() + 12, n_local.data_ptr() + 4 * (L - 1 - l))
+                blk.srcdata["embed_norm"] = in_norm
+                agg = weighted_aggregate(blk, z, blk.edata["edge_weights"], mean=True)
+                h = (y + agg) if last else sage_epilogue(y, agg, p, ctr, seed)[0]
             else:
                 h = layer(blk, (h_src, h_dst), edge_weight=blk.edata["edge_weights"])
                 if l < L - 1:
