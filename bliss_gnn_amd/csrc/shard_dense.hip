@@ -37,8 +37,10 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_local_seeds(const int* __restrict
     run += tot;
     __syncthreads();
   }
-  // (positions beyond the count stay valid indices: consumers gather through seed_pos at capacity)
-  for (int i = run + threadIdx.x; i < cap_s; i += SD_TPB) seed_pos[i] = 0;
+  // (positions beyond the count stay valid indices, the ids behind them valid ids -- the list's first entry: consumers read both
+  // at capacity, e.g. the label gather of the padded destination rows)
+  const int pad = S > 0 ? seeds_g[0] : lo;
+  for (int i = run + threadIdx.x; i < cap_s; i += SD_TPB) { seed_pos[i] = 0; seeds_l[i] = pad; }
   if (threadIdx.x == 0) *n_local_dev = run;
 }
 

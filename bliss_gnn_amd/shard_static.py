@@ -129,7 +129,6 @@ class DenseShardedSampler:
                  step=torch.zeros(1, dtype=torch.int64, device=dev), seeds0=torch.zeros(S0, dtype=torch.int32, device=dev),
                  seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
                  seed_pos=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
-                 dst_nid=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in eng.caps],
                  n_local=torch.zeros(L, dtype=torch.int32, device=dev),
                  counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(), rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(),
                  nloc_host=torch.empty(L, dtype=torch.int32).pin_memory(), err_host=torch.empty(1, dtype=torch.int32).pin_memory())
@@ -149,7 +148,6 @@ class DenseShardedSampler:
                                     seeds0=torch.zeros_like(b["seeds0"]), n_local=torch.zeros(L, dtype=torch.int32, device=dev),
                                     seeds_l=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
                                     seed_pos=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
-                                    dst_nid=[torch.zeros(c["S"], dtype=torch.int32, device=dev) for c in caps],
                                     counts_host=torch.empty(L * 10, dtype=torch.int32).pin_memory(),
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
@@ -226,9 +224,9 @@ class DenseShardedSampler:
             if not select:                                         # (the block objects exist: made by the "select" part)
                 cur, n_seeds, n_seeds_dev = kept, -1, cnt_ptr + 12
                 continue
-            # (the destinations' ids into a persistent per-slot buffer: block objects of one slot are interchangeable between graphs)
-            torch.index_select(kept, 0, seed_pos.long(), out=sb["dst_nid"][n])
-            blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos, dst_nid=sb["dst_nid"][n])
+            # (the destinations' ids = this rank's seeds: bliss_shard_local_seeds wrote them, padded with the list's first entry, into
+            # a persistent per-slot buffer -- block objects of one slot are interchangeable between graphs)
+            blk = ShardBlock(g, cap["K"], cs, b_indptr, b_src, b_dst, b_pos, b_eid, kept, seed_pos, dst_nid=seeds_l)
             blk._edge_weights, blk._q, blk._node_prob = b_w, b_q, node_prob
             blk._counts, blk._counts_dev, blk._layer = None, cdev, layer
             blk._nnz_ptr = sb["counts"].data_ptr() + 40 * n + 16

@@ -240,7 +240,8 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
 /* The STATIC-SHAPE sharded sampler (csrc/shard_dense.hip, bliss_gnn_amd/shard_static.py): the same split as above with every
  * exchange made dense, so that a layer has ONE collective of a fixed shape and no size ever reaches the host:
  *   bliss_shard_local_seeds:      the seeds of the global list (n_seeds, or *n_seeds_dev when n_seeds < 0) that lie in [lo, hi),
- *                                 order kept -> seeds_l (and a second copy: what bliss_build_block's clean-up walks),
+ *                                 order kept -> seeds_l (padded to cap_s with the list's first entry: a block's destination ids at capacity;
+ *                                 and a second, unpadded copy: what bliss_build_block's clean-up walks),
  *                                 seed_pos[i] = position in the global list (0 beyond the count), *n_local_dev;
  *   bliss_shard_scatter_partials: zeroes dense (int64 [2 * num_nodes]) and scatters the per-source partial sums that
  *                                 bliss_frontier_prob(BLISS_MODE_PARTIALS) left (seeds: seed_p2; others: touched_key / touched_sum,

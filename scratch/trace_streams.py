@@ -6,12 +6,18 @@ n = len(rows)
 rows = rows[int(n * 0.5):int(n * 0.9)]                     # the timed region's middle
 t0, t1 = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
 qkey = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
+import re
+def short(n):
+    m = re.findall(r"(\w+Functor\w*<[\w:]+>|\w+_kernel_cuda|\w+_kernel_impl|k_\w+|Cijk_\w{10}.{0,40}MT\w+|nccl\w+|index\w+|\w+_kernel\b)", n)
+    keep = [x for x in m if not x.startswith(("elementwise_kernel", "vectorized_elementwise", "gpu_kernel"))]
+    return (" ".join(dict.fromkeys(keep[:3])) or n)[:90]
+calls = collections.defaultdict(lambda: collections.defaultdict(int))
 busy = collections.defaultdict(int); cnt = collections.defaultdict(int); names = collections.defaultdict(lambda: collections.defaultdict(int))
 for r in rows:
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    q = r[qkey]; busy[q] += d; cnt[q] += 1; names[q][r["Kernel_Name"][:70]] += d
+    q = r[qkey]; busy[q] += d; cnt[q] += 1; names[q][short(r["Kernel_Name"])] += d; calls[q][short(r["Kernel_Name"])] += 1
 print("window %.3f ms, %d kernels, key %s" % ((t1 - t0) / 1e6, len(rows), qkey))
 for q in busy:
     print("queue %s: busy %.3f ms (%.1f%%), %d launches" % (q, busy[q] / 1e6, 100.0 * busy[q] / (t1 - t0), cnt[q]))
-    for k, v in sorted(names[q].items(), key=lambda kv: -kv[1])[:14]:
-        print("    %6.1f%%  %s" % (100.0 * v / busy[q], k))
+    for k, v in sorted(names[q].items(), key=lambda kv: -kv[1])[:45]:
+        print("    %6.1f%%  %5d  %s" % (100.0 * v / busy[q], calls[q][k], k))
