@@ -427,7 +427,7 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
                 launch = ("%s per step on two streams (static shapes): forward + EXP3 and the next batch's sampling with its "
                           "dense all-reduces on the critical stream; loss, backward, gradient all-reduce and Adam beside them, on a "
                           "communicator of their own" % (("three HIP graphs on three streams (the third builds the next batch's blocks) ordered by device flags" if step.use_third else
-                                                          "two HIP graphs ordered by device flags") if step.use_flags else
+                                                          ("two HIP graphs ordered by device flags, the input-most block built on the backward stream beside the next forward pass's first transform" if step.late_block else "two HIP graphs ordered by device flags")) if step.use_flags else
                                                          "three HIP graphs ordered by stream events")) if pipelined else \
                          "ONE HIP graph per step: sampler + its dense all-reduces + halo all-reduces + model + Adam + EXP3 (static shapes)"
             except Exception as e:                                 # noqa: BLE001 -- a runtime that cannot capture collectives
@@ -439,8 +439,9 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
         def one():
             step(next(loader))
             cnt = sampler._slot_bufs(step.slot if pipelined else 0)["counts"]
-            if pipelined and step.graph is not None and step.use_third:        # (the blocks just sampled are built on the third stream)
-                with torch.cuda.stream(step.third):
+            if pipelined and step.graph is not None and (step.use_third or step.late_block):
+                # (the blocks just sampled are finished on another stream: the third one, or the backward stream for the last block)
+                with torch.cuda.stream(step.third if step.use_third else step.side):
                     edges_dev.add_(cnt[4::10].sum())
             else:
                 edges_dev.add_(cnt[4::10].sum())

@@ -152,7 +152,7 @@ class DenseShardedSampler:
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
 
-    def enqueue(self, seeds_g, slot=0, part=None, hook=None):
+    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None):
         """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
         outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
         advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors.
@@ -160,6 +160,8 @@ class DenseShardedSampler:
         ``part``: None = everything.  "select" = candidates, draw and kept lists of all layers without the blocks themselves
         (``hook(n)`` is called behind layer n's kept list); "build" = only the blocks (generate_block, :269-339) of a preceding
         "select" with the same slot (``hook(n)`` in front of layer n's block) -- for a loop that builds them on another stream.
+        ``defer``: sampling layers whose block this call does NOT build; ``layers``: the only ones a "build" call builds (the loop
+        that leaves the input-most block to the backward stream: PipelinedShardedTrainStep).
         Needs one scratch set per layer: a layer's dense maps live until its block is built."""
         if not self.static:
             raise RuntimeError("enqueue() is the static HIP path; construct the sampler without ops")
@@ -175,7 +177,7 @@ class DenseShardedSampler:
         lib, chk = _lib.lib, _lib.check
         V = eng.V
         select, build = part in (None, "select"), part in (None, "build")
-        if part is not None and eng.scratch_sets < L:
+        if (part is not None or defer) and eng.scratch_sets < L:
             raise RuntimeError("split enqueue needs one scratch set per layer (set ops.eng.scratch_sets before the first call)")
         if select:
             sb["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
@@ -215,7 +217,7 @@ class DenseShardedSampler:
             # (measured and not kept: the block forked to a side stream INSIDE one graph -- correct, but the forked graph replayed at
             # 4.4 ms instead of 1.4: this runtime serialises branches of one graph badly; see PipelinedShardedTrainStep for the form
             # that works: a graph of its own on a third stream, ordered by device flags)
-            if build:
+            if build and n not in defer and (layers is None or n in layers):
                 if hook is not None and part == "build":
                     hook(n)
                 chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
@@ -796,7 +798,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.ev_f, self.ev_b = torch.cuda.Event(), torch.cuda.Event()
         self.g_main, self.g_fx, self.g_s, self.g_b, self.g_blk = [None, None], [None, None], [None, None], [None, None], [None, None]
         self._held = [None, None]
-        self._flags_primed, self.use_flags, self.use_third = False, False, False
+        self._flags_primed, self.use_flags, self.use_third, self.late_block = False, False, False, False
 
     # ---- the three parts ---------------------------------------------------------------------------------------------------
     def _sample(self, slot):
@@ -810,6 +812,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         return pred
 
     FLAG_BLK_DONE, FLAG_F_DONE, FLAG_B_DONE = 11, 12, 13        # slots of the engine's device flags; 0 .. L-1: "layer n's kept list is final"
+    FLAG_SEL_DONE = 10                                          # "the next batch's kept lists are final" (late-block mode)
 
     def _flags_usable(self, tries=4):
         """Device flags order two streams only if the streams really run side by side (HIP multiplexes streams onto a few
@@ -834,7 +837,8 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         for name in ("side", "third"):
             for _ in range(tries):
                 st = getattr(self, name)
-                if probe(st, main) and probe(main, st):
+                # (the third stream's waits must not sit on the backward stream's queue either: a spinning wait there holds B back)
+                if probe(st, main) and probe(main, st) and (name == "side" or (probe(st, self.side) and probe(self.side, st))):
                     break
                 setattr(self, name, torch.cuda.Stream())
             else:
@@ -878,7 +882,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
             # each graph cost 40-90 us per boundary (profiles/r03_u: 1.10 ms/step with three event-ordered graphs)
             if not self._flags_primed:                           # nothing precedes the first step; its blocks were built by prime()
                 self._flag(self.FLAG_B_DONE, True)
-                if self.use_third:
+                if self.use_third or self.late_block:
                     self._flag(self.FLAG_BLK_DONE, True)
                 self._flags_primed = True
             self.g_main[s].replay()
@@ -959,6 +963,13 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         # list is final" flags (the single-GPU loop's arrangement).  Correct (same bits) but 2.6 ms/step instead of 1.02 here: the
         # spinning waits of that graph sit on a hardware queue the backward pass needs -- measured, off by default
         self.use_third = self.use_flags and os.environ.get("BLISS_SHARD_THIRD", "0") == "1"
+        # BLISS_SHARD_LATE_BLOCK (default on): the input-most block of batch t+1 -- the last and largest of the sampler -- is built on
+        # the BACKWARD stream, behind B(t) and a "kept lists final" flag, while the main stream already runs the part of F(t+1) that
+        # needs only the kept list (feature rows, halo sum, the input layer's two Linears); F's first aggregation waits for the
+        # block (nn._wait_block), as in the single-GPU loop.  Two streams, two graphs per step as before
+        self.late_block = self.use_flags and not self.use_third and os.environ.get("BLISS_SHARD_LATE_BLOCK", "1") != "0"
+        L_s = len(self.sampler.nodes_per_layer)
+        eng = self.sampler.ops.eng
         g_fx = [None, None]
         for s in (0, 1):
             g_b[s] = torch.cuda.CUDAGraph()
@@ -969,10 +980,18 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     if self.use_third:
                         self._flag(self.FLAG_BLK_DONE, False)    # batch t's blocks are built (third stream, during step t-1)
                     blocks = self.blocks2[s]
+                    if self.late_block:                          # (consumed by the first aggregation of F: a wait for BLK_DONE)
+                        blocks[0]._ready = (eng.flags.data_ptr() + 4 * self.FLAG_BLK_DONE, eng.flag_err.data_ptr())
                     self._held[s] = self._forward(blocks, s)     # F(t)
+                    if self.late_block and getattr(blocks[0], "_ready", None) is not None:
+                        raise RuntimeError("late-block mode: the forward pass never waited for the input block")
                     self._flag(self.FLAG_F_DONE, True)
                     self.sampler.exp3(blocks)                    # X(t)
-                    if self.use_third:                           # S(t+1) without its blocks; "layer n's kept list is final": flag n
+                    if self.late_block:                          # S(t+1) but for its last block
+                        self._gather_seeds()
+                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=(L_s - 1,))
+                        self._flag(self.FLAG_SEL_DONE, True)
+                    elif self.use_third:                           # S(t+1) without its blocks; "layer n's kept list is final": flag n
                         self._gather_seeds()
                         self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, part="select", hook=lambda n: self._flag(n, True))
                     else:
@@ -989,6 +1008,10 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     self._flag(self.FLAG_F_DONE, False)
                     self._bwd(self._held[s], s)                  # B(t)
                     self._flag(self.FLAG_B_DONE, True)
+                    if self.late_block:                          # the input-most block of batch t+1
+                        self._flag(self.FLAG_SEL_DONE, False)
+                        self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", layers=(L_s - 1,))
+                        self._flag(self.FLAG_BLK_DONE, True)
             else:
                 g_fx[s] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_fx[s], pool=pool, stream=cap, **_cap_kw()):

@@ -21,3 +21,13 @@ for q in busy:
     print("queue %s: busy %.3f ms (%.1f%%), %d launches" % (q, busy[q] / 1e6, 100.0 * busy[q] / (t1 - t0), cnt[q]))
     for k, v in sorted(names[q].items(), key=lambda kv: -kv[1])[:45]:
         print("    %6.1f%%  %5d  %s" % (100.0 * v / busy[q], calls[q][k], k))
+
+if len(sys.argv) > 2 and sys.argv[2] == "timeline":
+    # one window of ~3 ms from the middle: every kernel with its start offset, duration and stream
+    mid = rows[len(rows) // 2]
+    w0 = int(mid["Start_Timestamp"])
+    print("\ntimeline (us from window start; stream; duration; kernel)")
+    for r in rows:
+        a = int(r["Start_Timestamp"]) - w0
+        if 0 <= a < 4_000_000:
+            print("%9.1f  q%-2s %7.1f  %s" % (a / 1e3, r[qkey], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, short(r["Kernel_Name"])[:60]))
