@@ -152,7 +152,7 @@ class DenseShardedSampler:
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
 
-    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None):
+    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None, ready_flag=0):
         """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
         outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
         advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors.
@@ -161,7 +161,8 @@ class DenseShardedSampler:
         (``hook(n)`` is called behind layer n's kept list); "build" = only the blocks (generate_block, :269-339) of a preceding
         "select" with the same slot (``hook(n)`` in front of layer n's block) -- for a loop that builds them on another stream.
         ``defer``: sampling layers whose block this call does NOT build; ``layers``: the only ones a "build" call builds (the loop
-        that leaves the input-most block to the backward stream: PipelinedShardedTrainStep).
+        that leaves the input-most block to the backward stream: PipelinedShardedTrainStep; ``ready_flag``: device flag that
+        bliss_build_block raises once the blocks' forward arrays are final, BEFORE it sorts the by-source lists of the backward pass).
         Needs one scratch set per layer: a layer's dense maps live until its block is built."""
         if not self.static:
             raise RuntimeError("enqueue() is the static HIP path; construct the sampler without ops")
@@ -220,8 +221,10 @@ class DenseShardedSampler:
             if build and n not in defer and (layers is None or n in layers):
                 if hook is not None and part == "build":
                     hook(n)
+                keep_flag, c_ws.block_ready_flag = c_ws.block_ready_flag, (ready_flag or c_ws.block_ready_flag)
                 chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
                                           eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
+                c_ws.block_ready_flag = keep_flag
             b_indptr, b_src, b_dst, b_pos, b_eid, b_w, b_q, kept, node_prob, cdev, t_indptr, t_edge = lay
             if not select:                                         # (the block objects exist: made by the "select" part)
                 cur, n_seeds, n_seeds_dev = kept, -1, cnt_ptr + 12
@@ -1010,8 +1013,9 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     self._flag(self.FLAG_B_DONE, True)
                     if self.late_block:                          # the input-most block of batch t+1
                         self._flag(self.FLAG_SEL_DONE, False)
-                        self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", layers=(L_s - 1,))
-                        self._flag(self.FLAG_BLK_DONE, True)
+                        # (BLK_DONE is raised by bliss_build_block itself, in front of the by-source lists only B(t+1) reads -- this stream)
+                        self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", layers=(L_s - 1,),
+                                             ready_flag=eng.flags.data_ptr() + 4 * self.FLAG_BLK_DONE)
             else:
                 g_fx[s] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_fx[s], pool=pool, stream=cap, **_cap_kw()):
