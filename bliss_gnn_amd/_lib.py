@@ -170,6 +170,7 @@ SIGNATURES = {
     "bliss_graph_prepare": [_P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
     "bliss_exp3_step": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
+    "bliss_exp3_update_blocks": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
     "bliss_exp3_step_deferred": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P, _P],
     "bliss_exp3_normalize_pending": [C.POINTER(Exp3Block), _I32, _I64, _P],
     "bliss_exp3_apply": [_P, _P, _P, _P, _P, _I32, _P, _P],
@@ -180,6 +181,7 @@ SIGNATURES = {
     "bliss_sage_wgrad": [C.POINTER(WGrad), _I32, _P, _I64, _P],
     "bliss_shard_local_seeds": [_P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P],
     "bliss_shard_scatter_partials": [_P, _P, _P, _P, _P, _P, _P, _I32, _P, _P],
+    "bliss_shard_zero_dense": [_P, _I32, _P],
     "bliss_shard_pack_rows": [_P, _P, _I32, _I32, _I32, _P, _I64, _I32, _P, _I64, _P],
     "bliss_shard_place_rows": [_P, _I64, _P, _P, _I32, _P, _I64, _I32, _I32, _P],
     "bliss_shard_take_rows": [_P, _I32, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P],

@@ -558,7 +558,7 @@ int bliss_exp3_update(const bliss_graph_t* g, const void* edge_w_pos, void* w_po
 }
 
 static int exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
-                     float delta_f, int32_t* err, void* stream, bool defer, int32_t* done_flag) {
+                     float delta_f, int32_t* err, void* stream, bool defer, int32_t* done_flag, bool normalize = true) {
   if (!g || !blocks || n_blocks <= 0 || n_blocks > BLISS_EXP3_MAX_BLOCKS || !err) return BLISS_EINVAL;
   Exp3Multi m;
   m.n = n_blocks;
@@ -579,6 +579,7 @@ static int exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss
   m.grid_begin[n_blocks] = total;
   hipStream_t st = (hipStream_t)stream;
   PROF_LAUNCH(BK_EXP3_UPDATE, st, k_exp3_update_multi<<<total, E3_TPB, 0, st>>>(g->indptr, (const bf16_t*)edge_w_pos, m, delta_f, err));
+  if (!normalize) return (int)hipGetLastError();
   int64_t per_row = (g->num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
   // usually every workgroup returns at once (norm == 1.0), but a row that does need the pass streams 4 bytes per edge and
   // wants the whole chip: 1024 workgroups per row
@@ -592,6 +593,11 @@ static int exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss
 int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
                     float delta_f, int32_t* err, void* stream) {
   return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, false, nullptr);
+}
+
+int bliss_exp3_update_blocks(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                             float delta_f, int32_t* err, void* stream) {
+  return exp3_step(g, edge_w_pos, blocks, n_blocks, delta_f, err, stream, false, nullptr, false);
 }
 
 int bliss_exp3_step_deferred(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,

@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_local_seeds(const int* __restrict
 
 // ---- partial sums -> dense ------------------------------------------------------------------------------------------------
 // (hipMemsetAsync issued from library code into a stream that torch is capturing did not replay with the graph here -- the
-// buffer kept the marks of earlier steps from the second replay on -- so the zeroing is a kernel like everything else)
+// buffer kept the marks of earlier steps from the second replay on -- so the zeroing is a kernel like everything else.  Round 3,
+// later: the buffer is zeroed once (bliss_shard_zero_dense) and k_sd_cand returns the entries it read to zero: one launch less per layer)
 __global__ void __launch_bounds__(256) k_sd_zero(long long* __restrict__ p, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0;
 }
@@ -71,35 +72,44 @@ __global__ void __launch_bounds__(256) k_sd_scatter(const int* __restrict__ seed
 // ---- ordered compaction in ONE launch: decoupled look-back ---------------------------------------------------------------------
 // Block b of 1024 elements needs the number of selected elements in the blocks before it.  One 64-bit status word per block:
 // tag << 62 | value, tag 1 = "my own count", tag 2 = "the inclusive prefix up to me".  A block publishes its count at once, then
-// walks back over its predecessors' words, adding counts until it meets an inclusive prefix (blocks are dispatched in index order,
+// walks back over its predecessors' words -- 64 at a time, one per lane of its first wave --, adding counts until it meets an
+// inclusive prefix (blocks are dispatched in index order,
 // so what it waits for is running or done; the spin is bounded like bliss_flag_wait's).  Two status arrays: the candidate pass
 // uses A and returns B to zero, the kept pass uses B and returns A to zero -- each is zero again before its next use.
 // (Round 3 started with count / scan / write launches: 18 launches per step on the critical stream.)
 #define SD_TAG_SHIFT 62
 __device__ __forceinline__ int sd_lookback(unsigned long long* status, int count, int* sh_prefix, int* err) {
-  if (threadIdx.x == 0) {
-    const int b = blockIdx.x;
-    long long ex = 0;
+  if (threadIdx.x < 64) {                               // the block's first wave: lane l looks at block hi - l, 64 predecessors per round
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int ex = 0;
     if (b == 0) {
-      __hip_atomic_store(status, (2ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(status, (2ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      __hip_atomic_store(status + b, (1ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(status + b, (1ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int hi = b - 1;
       long long spins = 0;
-      for (int j = b - 1; j >= 0;) {
-        const unsigned long long w = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        const int j = hi - lane;
+        const unsigned long long w = j >= 0 ? __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : (2ull << SD_TAG_SHIFT);            // (in front of block 0: an inclusive prefix of 0)
         const unsigned tag = (unsigned)(w >> SD_TAG_SHIFT);
-        if (tag == 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1ll << 22)) { if (err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
+        const unsigned long long ready = __ballot(tag != 0), incl = __ballot(tag == 2);
+        const int k = incl ? __ffsll((long long)incl) - 1 : 63;                  // the nearest inclusive prefix ends the walk
+        const unsigned long long need = k == 63 ? ~0ull : ((1ull << (k + 1)) - 1);
+        if ((ready & need) != need) {                   // someone in between has not published yet
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1ll << 22)) { if (lane == 0 && err) atomicOr(err, BLISS_ERR_FLAG_TIMEOUT); break; }
           continue;
         }
-        ex += (long long)(w & 0xffffffffull);
-        if (tag == 2) break;
-        --j;
+        int v = lane <= k ? (int)(w & 0xffffffffull) : 0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        ex += v;
+        if (incl) break;
+        hi -= 64;
       }
-      __hip_atomic_store(status + b, (2ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)(ex + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(status + b, (2ull << SD_TAG_SHIFT) | (unsigned long long)(unsigned)(ex + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    *sh_prefix = (int)ex;
+    if (lane == 0) *sh_prefix = ex;
   }
   __syncthreads();
   return *sh_prefix;
@@ -109,7 +119,7 @@ __device__ __forceinline__ int sd_lookback(unsigned long long* status, int count
 // fractions -- so a 4096-bin window + one counter for p == 0 catches them; plain global atomics on the few hot bins cost 70 us)
 #define SD_HWIN_LO 0x3000
 #define SD_HWIN_N 4096
-__global__ void __launch_bounds__(SD_TPB) k_sd_cand(const long long* __restrict__ dense, int V, int uniform_nodes,
+__global__ void __launch_bounds__(SD_TPB) k_sd_cand(long long* __restrict__ dense, int V, int uniform_nodes,
                                                     unsigned long long* __restrict__ status, unsigned long long* __restrict__ status_other, int n_other,
                                                     int* __restrict__ cand_nid, bf16_t* __restrict__ p, unsigned char* __restrict__ is_seed,
                                                     int* __restrict__ hist, LayerCounts* cnt, int cap_c, int* err) {
@@ -125,8 +135,9 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_cand(const long long* __restrict_
   int bad = 0;
   if (mark != 0) {
     const int at = base + ex;
+    const long long raw = dense[v];
+    dense[v] = 0; dense[(long long)V + v] = 0;          // back to zero for the next scatter (only marked nodes are non-zero)
     if (at < cap_c) {
-      const long long raw = dense[v];
       bf16_t pj;
       if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;                       // bandit_sampler.py:79-81
       else pj = f2bf(sqrtf(bf2f(fixed_to_bf(raw, FRAC_SRC, &bad))));                  // :75 torch.sqrt(prob)
@@ -305,9 +316,16 @@ int bliss_shard_scatter_partials(const int32_t* seeds_l, const int64_t* seed_p2,
   hipStream_t st = (hipStream_t)stream;
   int grid = (num_nodes + 255) / 256;
   if (grid > 1024) grid = 1024;
-  k_sd_zero<<<grid, 256, 0, st>>>((long long*)dense, 2ll * num_nodes);       // (a kernel, not hipMemsetAsync: see k_sd_zero)
   k_sd_scatter<<<grid, 256, 0, st>>>(seeds_l, (const long long*)seed_p2, n_local_dev, (const unsigned long long*)touched_key,
                                      (const long long*)touched_sum, n_touched_dev, (long long*)dense, num_nodes, err);
+  return (int)hipGetLastError();
+}
+
+int bliss_shard_zero_dense(int64_t* dense, int32_t num_nodes, void* stream) {
+  if (!dense || num_nodes <= 0) return BLISS_EINVAL;
+  int grid = (num_nodes + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  k_sd_zero<<<grid, 256, 0, (hipStream_t)stream>>>((long long*)dense, 2ll * num_nodes);       // (a kernel, not hipMemsetAsync: see k_sd_zero)
   return (int)hipGetLastError();
 }
 
@@ -340,14 +358,14 @@ int bliss_shard_take_rows(const void* src, int32_t src_is_f32, int64_t src_strid
   return (int)hipGetLastError();
 }
 
-int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
+int bliss_shard_candidates(int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
                            int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream) {
   if (!dense || num_nodes <= 0 || !cand_nid || !p_bf16 || !is_seed || !hist || !counts || cap_c <= 0 || !scratch || ((uintptr_t)scratch & 7))
     return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nb = sd_blocks(num_nodes), nb_k = sd_blocks(cap_c);   // scratch: uint64[nb + nb_k] -- this pass's status words, then the kept pass's
   unsigned long long* st_a = reinterpret_cast<unsigned long long*>(scratch);
-  k_sd_cand<<<nb, SD_TPB, 0, st>>>((const long long*)dense, num_nodes, uniform_nodes, st_a, st_a + nb, nb_k, cand_nid, (bf16_t*)p_bf16, is_seed, hist,
+  k_sd_cand<<<nb, SD_TPB, 0, st>>>((long long*)dense, num_nodes, uniform_nodes, st_a, st_a + nb, nb_k, cand_nid, (bf16_t*)p_bf16, is_seed, hist,
                                    (LayerCounts*)counts, cap_c, err);
   return (int)hipGetLastError();
 }

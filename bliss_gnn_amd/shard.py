@@ -331,6 +331,27 @@ class _HipShardOps:
             blk._counts_dev.data_ptr() + 16, B, delta_f, rewards.data_ptr(), 0, 1, self.err.data_ptr(), self._st()), "bliss_exp3_update")
         blk.edata["rewards"] = rewards
 
+    def exp3_update_all(self, blks, delta_f):
+        """exp3_update for all blocks of a step in ONE launch (bliss_exp3_update_blocks; the layers' rows are disjoint)."""
+        g = self.g
+        if self.edge_w_pos is None:
+            from .bandit_sampler import normalized_edata
+            self.edge_w_pos = g.by_position(normalized_edata(g)).contiguous()
+        recs = (_lib.Exp3Block * len(blks))()
+        keep = []
+        for i, blk in enumerate(blks):
+            B, idx = blk.num_edges(), blk._layer
+            rewards = torch.empty(max(B, 1), dtype=torch.bfloat16, device=g.device)
+            en, nid = blk.srcdata["embed_norm"].contiguous(), blk.dstdata[NID].contiguous()
+            keep.append((en, nid))
+            recs[i] = _lib.Exp3Block(self.w_pos[idx].data_ptr(), self.row_sum[idx].data_ptr(), self.scratch[idx].data_ptr(),
+                                     self.norms[idx:].data_ptr(), blk.indptr.data_ptr(), blk.src.data_ptr(), blk.dst.data_ptr(),
+                                     blk.pos.data_ptr(), blk._q.data_ptr(), blk._node_prob.data_ptr(), en.data_ptr(), 0, nid.data_ptr(),
+                                     blk._counts_dev.data_ptr() + 16, rewards.data_ptr(), B, 0)
+            blk.edata["rewards"] = rewards
+        _lib.check(_lib.lib.bliss_exp3_update_blocks(C.byref(self.eng.c_graph), self.edge_w_pos.data_ptr(), recs, len(blks), delta_f,
+                                                     self.err.data_ptr(), self._st()), "bliss_exp3_update_blocks")
+
     def normalize(self, idx, group=None):
         """F.normalize(row, p=1) (:249) over the row that is spread over all shards: the norm is the all-reduced exact sum."""
         limbs = _all_reduce(self.row_sum[idx].clone(), group)

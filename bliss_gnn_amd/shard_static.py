@@ -181,11 +181,17 @@ class DenseShardedSampler:
         if (part is not None or defer) and eng.scratch_sets < L:
             raise RuntimeError("split enqueue needs one scratch set per layer (set ops.eng.scratch_sets before the first call)")
         if select:
-            sb["seeds0"].copy_(seeds_g.to(torch.int32), non_blocking=True)
+            if seeds_g.dtype == torch.int32 and seeds_g.is_contiguous() and seeds_g.is_cuda:
+                seeds0 = seeds_g                                   # (read by this call's first layer only: no copy into the slot)
+            else:
+                seeds0 = sb["seeds0"]
+                seeds0.copy_(seeds_g.to(torch.int32), non_blocking=True)
+        else:
+            seeds0 = sb["seeds0"]
         eta_f, ome_f = float(np.float32(self.eta)), float(np.float32(1.0 - self.eta))
         bins = eng._bin_buffers()
         n_touched_ptr = bins["cursor"].data_ptr() + 4 * eng.n_bins
-        cur, n_seeds, n_seeds_dev = sb["seeds0"], S0, 0
+        cur, n_seeds, n_seeds_dev = seeds0, S0, 0
         blocks = []
         for n, layer in enumerate(order):
             cap = eng.caps[n]
@@ -287,8 +293,11 @@ class DenseShardedSampler:
     def exp3(self, mfgs, g=None):
         """bandit_sampler.py:251-267 on the owned in-edges of every block, then the global L1 renormalisation."""
         ops = self.ops
-        for mfg in mfgs:
-            ops.exp3_update(mfg, mfg.srcdata["embed_norm"], self._delta_f)
+        if hasattr(ops, "exp3_update_all") and 0 < len(mfgs) <= _lib.EXP3_MAX_BLOCKS and all(m.num_edges() > 0 for m in mfgs):
+            ops.exp3_update_all(mfgs, self._delta_f)             # one launch for all blocks
+        else:
+            for mfg in mfgs:
+                ops.exp3_update(mfg, mfg.srcdata["embed_norm"], self._delta_f)
         if not hasattr(ops, "row_sum"):                          # (test doubles: one normalisation per layer)
             for idx in range(len(mfgs)):
                 ops.normalize(idx, self.group)

@@ -243,11 +243,14 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
  *                                 order kept -> seeds_l (padded to cap_s with the list's first entry: a block's destination ids at capacity;
  *                                 and a second, unpadded copy: what bliss_build_block's clean-up walks),
  *                                 seed_pos[i] = position in the global list (0 beyond the count), *n_local_dev;
- *   bliss_shard_scatter_partials: zeroes dense (int64 [2 * num_nodes]) and scatters the per-source partial sums that
+ *   bliss_shard_zero_dense:       dense (int64 [2 * num_nodes]) to zero, by a kernel (once, after allocation: the calls below keep it zero
+ *                                 between uses);
+ *   bliss_shard_scatter_partials: into a ZERO dense buffer, scatters the per-source partial sums that
  *                                 bliss_frontier_prob(BLISS_MODE_PARTIALS) left (seeds: seed_p2; others: touched_key / touched_sum,
  *                                 their count in *n_touched_dev) into dense[v], with dense[num_nodes + v] = 1 (+ 2^32 for a seed).
  *                                 The caller all-reduces dense (integer sums: exact for any shard count, any order);
- *   bliss_shard_candidates:       candidates = nodes with a non-zero mark, ascending id: cand_nid, p_j = sqrt(bf16(sum)) (:75),
+ *   bliss_shard_candidates:       candidates = nodes with a non-zero mark, ascending id: cand_nid, p_j = sqrt(bf16(sum)) (:75); every
+ *                                 entry of dense it read goes back to zero (the next bliss_shard_scatter_partials finds it clean);
  *                                 is_seed, the histogram of p's bit patterns, counts->C -- one launch, the ordered compaction by decoupled
  *                                 look-back over one 64-bit status word per 1024 nodes.  scratch: 8-byte aligned, uint64[ceil(num_nodes /
  *                                 1024) + ceil(cap_c / 1024)], zero-initialised once and SHARED with bliss_shard_select_kept (each of
@@ -279,7 +282,8 @@ int bliss_shard_place_rows(const void* src_bf16, int64_t src_stride, const int32
                            int64_t out_stride, int32_t n_rows, int32_t row_len, void* stream);
 int bliss_shard_take_rows(const void* src, int32_t src_is_f32, int64_t src_stride, int32_t n_src_rows, const int32_t* pos, const int32_t* n_dev,
                           int32_t cap_s, void* out_bf16, int64_t out_stride, int32_t row_len, void* stream);
-int bliss_shard_candidates(const int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
+int bliss_shard_zero_dense(int64_t* dense, int32_t num_nodes, void* stream);
+int bliss_shard_candidates(int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
                            int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream);
 int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
                             const int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
@@ -459,6 +463,10 @@ typedef struct {
 } bliss_exp3_block_t;
 int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
                     float delta_f, int32_t* err, void* stream);
+/* Only the first of the two launches: the updates of all blocks, rows and row sums left un-normalised -- for rows that are
+ * spread over several shards, whose norm is the all-reduced sum (bliss_exp3_normalize_global). */
+int bliss_exp3_update_blocks(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
+                             float delta_f, int32_t* err, void* stream);
 
 /* The same with F.normalize's pass over the rows taken off the caller's critical path.  The pass (4 bytes of HBM traffic per
  * edge of the graph, whenever the bf16 norm of a row is not exactly 1.0) is the only part of exp3() that scales with |E|, and
