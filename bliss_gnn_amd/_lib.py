@@ -186,7 +186,7 @@ SIGNATURES = {
     "bliss_shard_place_rows": [_P, _I64, _P, _P, _I32, _P, _I64, _I32, _I32, _P],
     "bliss_shard_take_rows": [_P, _I32, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _P],
     "bliss_shard_candidates": [_P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
-    "bliss_shard_select_kept": [_P, _P, _P, _P, C.c_uint64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "bliss_shard_select_kept": [_P, _P, _P, _P, C.c_uint64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P],
     "bliss_gat_fused_supported": [_I32, _I32],
     "bliss_gat_segment_edges": [],
     "bliss_gat_fused_stamps": [_P, _P],

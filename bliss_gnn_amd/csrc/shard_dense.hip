@@ -189,12 +189,13 @@ __device__ __forceinline__ bool sd_draw(int nid, bf16_t pj, bool seed, const Lay
 
 __global__ void __launch_bounds__(SD_TPB) k_sd_keep(const int* __restrict__ cand_nid, const bf16_t* __restrict__ p,
                                                     const unsigned char* __restrict__ is_seed, const LayerCounts* __restrict__ cnt,
-                                                    unsigned long long seed, const long long* __restrict__ step_dev, int layer,
+                                                    unsigned long long seed, long long* __restrict__ step_dev, int layer,
                                                     unsigned long long* __restrict__ status, unsigned long long* __restrict__ status_other, int n_other,
                                                     const int* __restrict__ seeds_g, int n_seeds, const int* __restrict__ n_seeds_dev,
                                                     bf16_t* __restrict__ P_out, int* __restrict__ kept_nid, bf16_t* __restrict__ node_prob,
                                                     int* __restrict__ kept_map, int cap_k, LayerCounts* layer_cnt,
-                                                    const int* __restrict__ n_local_dev, int* err) {
+                                                    const int* __restrict__ n_local_dev, unsigned* ticket, int bump_step, int* done_flag,
+                                                    int* err) {
   __shared__ int sh[17];
   __shared__ int sh_prefix;
   for (int w = blockIdx.x * SD_TPB + threadIdx.x; w < n_other; w += gridDim.x * SD_TPB) status_other[w] = 0ull;   // (the candidate pass's words)
@@ -229,6 +230,18 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_keep(const int* __restrict__ cand
     layer_cnt->C = *n_local_dev;                        // what bliss_build_block's clean-up walks: cand_nid[0 .. C) = this rank's seeds
   }
   if (bad && err) atomicOr(err, bad);
+  if (bump_step || done_flag) {
+    // the LAST workgroup to finish (a ticket, left zero): every workgroup has read the step number and written its part of the lists
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bump_step) *step_dev += 1;
+        if (done_flag) __hip_atomic_store(done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // ---- block inputs, owner side: out[i] = table[nid[i] - lo] for the rows i < K this rank owns, +0 elsewhere (the halo buffer that
@@ -371,18 +384,19 @@ int bliss_shard_candidates(int64_t* dense, int32_t num_nodes, int32_t uniform_no
 }
 
 int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
-                            const int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
+                            int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
                             void* P_bf16, int32_t* kept_nid, void* node_prob_bf16, int32_t* kept_map, int32_t cap_k, int32_t cap_c,
-                            int32_t num_nodes, void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t* err, void* stream) {
+                            int32_t num_nodes, void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t bump_step,
+                            int32_t* done_flag, int32_t* err, void* stream) {
   if (!cand_nid || !p_bf16 || !is_seed || !counts || !step_dev || !seeds_g || (n_seeds < 0 && !n_seeds_dev) || !P_bf16 || !kept_nid ||
       !node_prob_bf16 || !kept_map || cap_k <= 0 || cap_c <= 0 || num_nodes <= 0 || !layer_counts || !n_local_dev || !scratch ||
       ((uintptr_t)scratch & 7)) return BLISS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nb = sd_blocks(cap_c), nb_c = sd_blocks(num_nodes);   // scratch: the SAME array as bliss_shard_candidates'; blocks beyond the count find nothing
   unsigned long long* st_a = reinterpret_cast<unsigned long long*>(scratch);
-  k_sd_keep<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (const long long*)step_dev, layer,
+  k_sd_keep<<<nb, SD_TPB, 0, st>>>(cand_nid, (const bf16_t*)p_bf16, is_seed, (const LayerCounts*)counts, seed, (long long*)step_dev, layer,
                                    st_a + nb_c, st_a, nb_c, seeds_g, n_seeds, n_seeds_dev, (bf16_t*)P_bf16, kept_nid, (bf16_t*)node_prob_bf16, kept_map,
-                                   cap_k, (LayerCounts*)layer_counts, n_local_dev, err);
+                                   cap_k, (LayerCounts*)layer_counts, n_local_dev, reinterpret_cast<unsigned*>(st_a + nb_c + nb), bump_step, done_flag, err);
   return (int)hipGetLastError();
 }
 

@@ -340,27 +340,32 @@ class _SageLinearPair(torch.autograd.Function):
 class _SageLinearSplit(torch.autograd.Function):
     """_SageLinearPair for a block whose destinations are NOT its leading source rows (a shard's block: the destinations are
     this rank's seeds, anywhere in the global source list): fc_neigh over the source rows and fc_self (+bias) over the
-    destination rows handed in beside them, ONE launch; the input rows' bf16 norms come with it.  Backward on
-    csrc/sage_bwd.hip: both weight gradients and the bias gradient in one launch pair, an input gradient per operand."""
+    destination rows -- handed in beside them, or gathered from the source rows through ``dst_ids`` by the launch itself --,
+    ONE launch; the input rows' bf16 norms come with it.  Backward on csrc/sage_bwd.hip: both weight gradients and the bias
+    gradient in one launch pair, an input gradient per operand."""
 
     @staticmethod
-    def forward(ctx, x_src, x_dst, w_neigh, w_self, b_self, src_dev, dst_dev):
+    def forward(ctx, x_src, x_dst, w_neigh, w_self, b_self, src_dev, dst_dev, dst_ids=None):
         ctx.set_materialize_grads(False)
-        xs, xd, wn, ws = _bf16c(x_src), _bf16c(x_dst), _bf16c(w_neigh), _bf16c(w_self)
+        xs, wn, ws = _bf16c(x_src), _bf16c(w_neigh), _bf16c(w_self)
         dev, n_out = xs.device, wn.shape[0]
+        gathered = x_dst is None
+        n_dst = dst_ids.numel() if gathered else x_dst.shape[0]
+        xd = torch.empty(n_dst, xs.shape[1], dtype=torch.bfloat16, device=dev) if gathered else _bf16c(x_dst)
         z = torch.empty(xs.shape[0], n_out, dtype=torch.bfloat16, device=dev)
-        y = torch.empty(xd.shape[0], n_out, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(n_dst, n_out, dtype=torch.bfloat16, device=dev)
         norm = torch.empty(xs.shape[0], dtype=torch.bfloat16, device=dev)
-        _tile_gemm(_tg_args(xs, wn, z, xs.shape[0], m_dev=src_dev, in_norm=norm),
-                   _tg_args(xd, ws, y, xd.shape[0], bias=b_self, m_dev=dst_dev))
-        ctx.save_for_backward(xs, xd, wn, ws)
-        ctx.has_bias, ctx.src_dev, ctx.dst_dev = b_self is not None, src_dev, dst_dev
+        second = (_tg_args(xs, ws, y, n_dst, ids=dst_ids, bias=b_self, m_dev=dst_dev, a_copy=xd) if gathered
+                  else _tg_args(xd, ws, y, n_dst, bias=b_self, m_dev=dst_dev))
+        _tile_gemm(_tg_args(xs, wn, z, xs.shape[0], m_dev=src_dev, in_norm=norm), second)
+        ctx.save_for_backward(xs, xd, wn, ws, dst_ids if gathered else None)
+        ctx.has_bias, ctx.src_dev, ctx.dst_dev, ctx.gathered = b_self is not None, src_dev, dst_dev, gathered
         ctx.mark_non_differentiable(norm)
         return z, y, norm
 
     @staticmethod
     def backward(ctx, dz, dy, _dnorm):
-        xs, xd, wn, ws = ctx.saved_tensors
+        xs, xd, wn, ws, ids = ctx.saved_tensors
         d_wn = d_ws = d_b = dxs = dxd = None
         probs = []
         if dz is not None:
@@ -377,9 +382,13 @@ class _SageLinearSplit(torch.autograd.Function):
                 d_ws, d_b = outs[-1]
         if dz is not None and ctx.needs_input_grad[0]:
             dxs = sage_dgrad(dz, wn, xs.shape[0], ctx.src_dev)
-        if dy is not None and ctx.needs_input_grad[1]:
-            dxd = sage_dgrad(dy, ws, xd.shape[0], ctx.dst_dev)
-        return dxs, dxd, d_wn, d_ws, d_b, None, None
+        if dy is not None and ctx.needs_input_grad[0 if ctx.gathered else 1]:
+            dxd = sage_dgrad(dy, ws, xd.shape[0], ctx.dst_dev)           # (rows at or beyond the true count: zeros)
+            if ctx.gathered:                                             # the destination rows came out of x_src: back into its gradient
+                dxs = torch.empty_like(xs).fill_(0) if dxs is None else dxs
+                dxs.index_add_(0, ids, dxd)                              # (the padding ids repeat row 0 and carry zero rows)
+                dxd = None
+        return dxs, dxd, d_wn, d_ws, d_b, None, None, None
 
 
 _ones_rows = {}

@@ -152,7 +152,7 @@ class DenseShardedSampler:
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
 
-    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None, ready_flag=0):
+    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None, ready_flag=0, sel_done_flag=0):
         """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
         outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
         advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors.
@@ -162,7 +162,8 @@ class DenseShardedSampler:
         "select" with the same slot (``hook(n)`` in front of layer n's block) -- for a loop that builds them on another stream.
         ``defer``: sampling layers whose block this call does NOT build; ``layers``: the only ones a "build" call builds (the loop
         that leaves the input-most block to the backward stream: PipelinedShardedTrainStep; ``ready_flag``: device flag that
-        bliss_build_block raises once the blocks' forward arrays are final, BEFORE it sorts the by-source lists of the backward pass).
+        bliss_build_block raises once the blocks' forward arrays are final, BEFORE it sorts the by-source lists of the backward pass;
+        ``sel_done_flag``: device flag raised by the last layer's bliss_shard_select_kept: all kept lists are final).
         Needs one scratch set per layer: a layer's dense maps live until its block is built."""
         if not self.static:
             raise RuntimeError("enqueue() is the static HIP path; construct the sampler without ops")
@@ -217,7 +218,8 @@ class DenseShardedSampler:
                 chk(lib.bliss_poisson_scale(eng.hist.data_ptr(), rec_ptr, int(fan[n]), 0.9999, b["sel"].data_ptr(), st), "bliss_poisson_scale")
                 chk(lib.bliss_shard_select_kept(b["cand"].data_ptr(), b["p"].data_ptr(), b["is_seed"].data_ptr(), rec_ptr, self.seed, b["step"].data_ptr(),
                                                 n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
-                                                c_ws.kept_map, cap["K"], V, V, cnt_ptr, nloc_ptr, b["scr_a"].data_ptr(), b["err"].data_ptr(), st),
+                                                c_ws.kept_map, cap["K"], V, V, cnt_ptr, nloc_ptr, b["scr_a"].data_ptr(), 1 if n == L - 1 else 0,
+                                                int(sel_done_flag) if n == L - 1 else 0, b["err"].data_ptr(), st),
                     "bliss_shard_select_kept")
                 if hook is not None and part == "select":
                     hook(n)
@@ -249,8 +251,7 @@ class DenseShardedSampler:
             cur, n_seeds, n_seeds_dev = kept, -1, cnt_ptr + 12
         if not select:
             return None
-        b["step"].add_(1)
-        self._static_blocks = blocks
+        self._static_blocks = blocks                             # (the step number went up by one in the last layer's select_kept)
         return blocks
 
     def finish(self, slot=0):
@@ -526,7 +527,7 @@ class StaticShardedTrainStep:
         self.opt = make_adam(model, lr, capturable=True)
         dev = shard.device
         self.my_seeds = torch.zeros(self.batch, dtype=torch.int32, device=dev)
-        self.seeds_g = torch.zeros(self.batch * shard.world, dtype=torch.int32, device=dev)
+        self.seeds_g = torch.zeros(self.batch * shard.world, dtype=torch.int32, device=dev) if shard.world > 1 else self.my_seeds
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.graph = None
         self.last = {}
@@ -549,6 +550,8 @@ class StaticShardedTrainStep:
         return t
 
     def _gather_seeds(self):
+        if self.seeds_g is self.my_seeds:                         # (a world of one rank: the global list IS this rank's)
+            return
         if self.g.world == 1:
             self.seeds_g.copy_(self.my_seeds)
         elif dist.get_backend(self.group) == "nccl":
@@ -621,7 +624,9 @@ class StaticShardedTrainStep:
                 blk.srcdata["embed_norm"] = embed_norm(h_src)      # model.py:318-320
             # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
             # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
-            if _hip_rows(h_src, blk.dst_pos):
+            if split and blk.dst_pos.dtype == torch.int32 and blk.dst_pos.is_contiguous():
+                h_dst = None                                       # (the Linear-first launch gathers its destination rows itself)
+            elif _hip_rows(h_src, blk.dst_pos):
                 h_dst = _TakeRowsHip.apply(h_src, blk.dst_pos, n_local[L - 1 - l: L - l])
             else:
                 h_dst = _TakeRows.apply(h_src, blk.dst_pos.long())
@@ -645,7 +650,8 @@ class StaticShardedTrainStep:
                 p = model.dropout.p if (model.training and not last) else 0.0
                 ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
                 z, y, in_norm = _SageLinearSplit.apply(h_src, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias,
-                                                       blk._counts_dev.data_ptr() + 12, n_local.data_ptr() + 4 * (L - 1 - l))
+                                                       blk._counts_dev.data_ptr() + 12, n_local.data_ptr() + 4 * (L - 1 - l),
+                                                       blk.dst_pos if h_dst is None else None)
                 blk.srcdata["embed_norm"] = in_norm
                 agg = weighted_aggregate(blk, z, blk.edata["edge_weights"], mean=True)
                 h = (y + agg) if last else sage_epilogue(y, agg, p, ctr, seed)[0]
@@ -1001,8 +1007,8 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     self.sampler.exp3(blocks)                    # X(t)
                     if self.late_block:                          # S(t+1) but for its last block
                         self._gather_seeds()
-                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=(L_s - 1,))
-                        self._flag(self.FLAG_SEL_DONE, True)
+                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=(L_s - 1,),
+                                                                   sel_done_flag=eng.flags.data_ptr() + 4 * self.FLAG_SEL_DONE)
                     elif self.use_third:                           # S(t+1) without its blocks; "layer n's kept list is final": flag n
                         self._gather_seeds()
                         self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, part="select", hook=lambda n: self._flag(n, True))

@@ -253,13 +253,15 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
  *                                 entry of dense it read goes back to zero (the next bliss_shard_scatter_partials finds it clean);
  *                                 is_seed, the histogram of p's bit patterns, counts->C -- one launch, the ordered compaction by decoupled
  *                                 look-back over one 64-bit status word per 1024 nodes.  scratch: 8-byte aligned, uint64[ceil(num_nodes /
- *                                 1024) + ceil(cap_c / 1024)], zero-initialised once and SHARED with bliss_shard_select_kept (each of
+ *                                 1024) + ceil(cap_c / 1024) + 1], zero-initialised once and SHARED with bliss_shard_select_kept (each of
  *                                 the two calls returns the other's words to zero, so they alternate: candidates, select, candidates ...);
  *   (bliss_poisson_scale on that histogram and counts)
  *   bliss_shard_select_kept:      P_j and the keyed draw (as bliss_keyed_select, the step read from *step_dev), kept list =
  *                                 the seeds in seed order, then the drawn non-seeds in node order: kept_nid, node_prob, kept_map
  *                                 [kept_nid[i]] = i, layer_counts->K, layer_counts->C = *n_local_dev (bliss_build_block's clean-up
- *                                 bound); scratch: the array bliss_shard_candidates was given (same num_nodes and cap_c).
+ *                                 bound); scratch: the array bliss_shard_candidates was given (same num_nodes and cap_c; ONE more 64-bit word behind the
+ *                                 status words: a ticket).  When the launch's last workgroup has finished: bump_step != 0 adds 1 to *step_dev
+ *                                 (a sampler's last layer), done_flag (optional) is raised (bliss_flag_wait's protocol).
  * (source: bandit_sampler.py:47-82, 381-425; no reference counterpart for the split itself -- SURVEY.md section 8e) */
 int bliss_shard_local_seeds(const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev, int32_t lo, int32_t hi, int32_t cap_s,
                             int32_t* seeds_l, int32_t* seeds_l_copy, int32_t* seed_pos, int32_t* n_local_dev, int32_t* err, void* stream);
@@ -286,9 +288,10 @@ int bliss_shard_zero_dense(int64_t* dense, int32_t num_nodes, void* stream);
 int bliss_shard_candidates(int64_t* dense, int32_t num_nodes, int32_t uniform_nodes, int32_t* cand_nid, void* p_bf16, uint8_t* is_seed,
                            int32_t* hist, void* counts, int32_t cap_c, int32_t* scratch, int32_t* err, void* stream);
 int bliss_shard_select_kept(const int32_t* cand_nid, const void* p_bf16, const uint8_t* is_seed, const void* counts, uint64_t seed,
-                            const int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
+                            int64_t* step_dev, int32_t layer, const int32_t* seeds_g, int32_t n_seeds, const int32_t* n_seeds_dev,
                             void* P_bf16, int32_t* kept_nid, void* node_prob_bf16, int32_t* kept_map, int32_t cap_k, int32_t cap_c,
-                            int32_t num_nodes, void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t* err, void* stream);
+                            int32_t num_nodes, void* layer_counts, const int32_t* n_local_dev, int32_t* scratch, int32_t bump_step,
+                            int32_t* done_flag, int32_t* err, void* stream);
 /* bliss_exp3_normalize with the norm taken from norm_limbs (int64[3 * BLISS_ROWSUM_SLOTS], e.g. the all-reduced row sums of
  * all shards) instead of row_sum; row_sum receives the exact sum of THIS row part after the division. */
 int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum, const int64_t* norm_limbs, int64_t* scratch,
