@@ -39,3 +39,12 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_flag_spin_bound_setter_is_host_only():
+    """bliss_flag_set_spin_bound touches no device: a loop whose flags wait on collectives raises the bound before it captures
+    its graphs (shard_static.PipelinedShardedTrainStep, worlds of more than one rank); invalid bounds are refused."""
+    from bliss_gnn_amd import _lib
+    assert _lib.lib.bliss_flag_set_spin_bound(1 << 27) == 0
+    assert _lib.lib.bliss_flag_set_spin_bound(0) == _lib.EINVAL
+    assert _lib.lib.bliss_flag_set_spin_bound(1 << 22) == 0     # (the default again)
