@@ -152,6 +152,7 @@ SIGNATURES = {
     "bliss_tile_gemm": [C.POINTER(TileGemm), C.POINTER(TileGemm), _P],
     "bliss_cross_entropy": [_P, _I64, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _P],
     "bliss_cross_entropy_sum": [_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _P, _I64, _P, _P, _P, _P],
+    "bliss_cross_entropy_masked": [_P, _I64, _P, _I64, _P, _I32, _P, _I32, _I32, _P, _F, _I32, _P, _P, _I64, _P, _P, _P, _P],
     "bliss_adam_step": [C.POINTER(AdamTensors), _P, _F, _F, _F, _F, _P],
     "bliss_cand_importance": [_P, _I32, C.c_int, _P, _P, _P],
     "bliss_poisson_scale": [_P, _P, _I32, _D, _P, _P],

@@ -19,10 +19,22 @@ __global__ void __launch_bounds__(CE_TPB) k_cross_entropy(const bf16_t* __restri
                                                           long long stride2, const long long* __restrict__ labels,
                                                           const int* __restrict__ label_ids,
                                                           int n_rows, int n_cls, float* __restrict__ row_loss, bf16_t* __restrict__ dlogits,
-                                                          long long d_stride, float* __restrict__ loss_out, unsigned* ticket, int* err) {
+                                                          long long d_stride, float* __restrict__ loss_out, unsigned* ticket, int* err,
+                                                          const int* __restrict__ n_rows_dev, float denom, int id_off, int n_table) {
+  // masked form (bliss_cross_entropy_masked): only the first *n_rows_dev rows count (the others get a zero gradient row and no
+  // loss), the divisor is `denom` (a global batch, not this rank's rows), label ids are node ids minus id_off into a table of
+  // n_table rows
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const float inv_n = 1.0f / (float)n_rows;
+  const float inv_n = 1.0f / (denom > 0.f ? denom : (float)n_rows);
+  int n_valid = n_rows;
+  if (n_rows_dev) { const int v = *n_rows_dev; n_valid = v < n_rows ? (v < 0 ? 0 : v) : n_rows; }
   for (int r = blockIdx.x * (CE_TPB / 64) + wave; r < n_rows; r += gridDim.x * (CE_TPB / 64)) {
+    if (r >= n_valid) {                                 // (wave-uniform)
+      bf16_t* g0 = dlogits + (long long)r * d_stride;
+      for (int c = lane; c < n_cls; c += 64) g0[c] = 0;
+      if (lane == 0) row_loss[r] = 0.f;
+      continue;
+    }
     const bf16_t* x1 = logits + (long long)r * stride;
     const bf16_t* x2 = logits2 ? logits2 + (long long)r * stride2 : nullptr;
     auto X = [&](int c) { return x2 ? rbf(bf2f(x1[c]) + bf2f(x2[c])) : bf2f(x1[c]); };
@@ -32,8 +44,11 @@ __global__ void __launch_bounds__(CE_TPB) k_cross_entropy(const bf16_t* __restri
     float s = 0.f;
     for (int c = lane; c < n_cls; c += 64) s += __expf(X(c) - m);
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    const long long y = labels[label_ids ? (long long)label_ids[r] : (long long)r];
-    const bool ok = y >= 0 && y < n_cls;
+    long long li = label_ids ? (long long)label_ids[r] - id_off : (long long)r;
+    const bool in_table = n_table <= 0 || (li >= 0 && li < n_table);
+    if (!in_table) li = 0;
+    const long long y = labels[li];
+    const bool ok = in_table && y >= 0 && y < n_cls;
     if (!ok && lane == 0) atomicOr(err, BLISS_ERR_CAP_CAND);            // label out of range (torch raises a device assert)
     const float lse = m + __logf(s);
     if (lane == 0) row_loss[r] = ok ? lse - X((int)y) : 0.f;
@@ -73,12 +88,14 @@ __global__ void __launch_bounds__(CE_TPB) k_cross_entropy(const bf16_t* __restri
 
 static int ce_launch(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* labels, const int32_t* label_ids,
                      int32_t n_rows, int32_t n_cls, float* row_loss, void* dlogits, int64_t d_stride, float* loss_out, uint32_t* ticket,
-                     int32_t* err, void* stream) {
+                     int32_t* err, void* stream, const int32_t* n_rows_dev = nullptr, float denom = 0.f, int32_t id_off = 0,
+                     int32_t n_table = 0) {
   if (!logits || !labels || !row_loss || !dlogits || !loss_out || !ticket || !err || n_rows <= 0 || n_cls <= 0) return BLISS_EINVAL;
   int grid = (n_rows + CE_TPB / 64 - 1) / (CE_TPB / 64);
   if (grid > 1024) grid = 1024;
   k_cross_entropy<<<grid, CE_TPB, 0, (hipStream_t)stream>>>((const bf16_t*)logits, stride, (const bf16_t*)logits2, stride2, (const long long*)labels,
-                                                            label_ids, n_rows, n_cls, row_loss, (bf16_t*)dlogits, d_stride, loss_out, ticket, err);
+                                                            label_ids, n_rows, n_cls, row_loss, (bf16_t*)dlogits, d_stride, loss_out, ticket, err,
+                                                            n_rows_dev, denom, id_off, n_table);
   return (int)hipGetLastError();
 }
 
@@ -94,4 +111,13 @@ extern "C" int bliss_cross_entropy_sum(const void* logits, int64_t stride, const
   if (!logits2 && !label_ids) return BLISS_EINVAL;
   return ce_launch(logits, stride, logits2, stride2, label_table, label_ids, n_rows, n_cls, row_loss, dlogits, d_stride, loss_out, ticket, err,
                    stream);
+}
+
+extern "C" int bliss_cross_entropy_masked(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* label_table,
+                                          int32_t n_table, const int32_t* label_ids, int32_t id_off, int32_t n_rows, const int32_t* n_rows_dev,
+                                          float denom, int32_t n_cls, float* row_loss, void* dlogits, int64_t d_stride, float* loss_out,
+                                          uint32_t* ticket, int32_t* err, void* stream) {
+  if (!label_ids || !n_rows_dev || n_table <= 0 || !(denom > 0.f)) return BLISS_EINVAL;
+  return ce_launch(logits, stride, logits2, stride2, label_table, label_ids, n_rows, n_cls, row_loss, dlogits, d_stride, loss_out, ticket, err,
+                   stream, n_rows_dev, denom, id_off, n_table);
 }

@@ -529,6 +529,7 @@ class StaticShardedTrainStep:
         self.my_seeds = torch.zeros(self.batch, dtype=torch.int32, device=dev)
         self.seeds_g = torch.zeros(self.batch * shard.world, dtype=torch.int32, device=dev) if shard.world > 1 else self.my_seeds
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ce_state = torch.zeros(2, dtype=torch.int32, device=dev)                           # the loss kernel's [0] ticket, [1] error word
         self.graph = None
         self.last = {}
         self.bytes_per_step = 0
@@ -654,7 +655,10 @@ class StaticShardedTrainStep:
                                                        blk.dst_pos if h_dst is None else None)
                 blk.srcdata["embed_norm"] = in_norm
                 agg = weighted_aggregate(blk, z, blk.edata["edge_weights"], mean=True)
-                h = (y + agg) if last else sage_epilogue(y, agg, p, ctr, seed)[0]
+                if last and self._fused_loss_ok(y):
+                    h = (y, agg)                                   # (the loss launch adds them: bliss_cross_entropy_masked)
+                else:
+                    h = (y + agg) if last else sage_epilogue(y, agg, p, ctr, seed)[0]
             else:
                 h = layer(blk, (h_src, h_dst), edge_weight=blk.edata["edge_weights"])
                 if l < L - 1:
@@ -662,11 +666,55 @@ class StaticShardedTrainStep:
         self._halo_bytes = halo_bytes
         return h
 
+    def _fused_loss_ok(self, logits):
+        """nn.CrossEntropyLoss on the in-tree kernel (csrc/loss.hip, masked form): bf16 logits on the GPU, class-index labels."""
+        import os
+        lab = self.g.ndata_owned.get("labels") if hasattr(self.g.ndata_owned, "get") else None
+        return (os.environ.get("BLISS_SHARD_FUSED_LOSS", "1") != "0" and not self.multilabel and logits.is_cuda
+                and logits.dtype == torch.bfloat16 and logits.dim() == 2 and logits.stride(1) == 1 and lab is not None
+                and lab.dtype == torch.int64 and lab.dim() == 1 and lab.is_contiguous())
+
+    def _fused_loss_backward_step(self, blocks, pred, slot, grp):
+        """The loss and its gradient in ONE launch (masked mean cross-entropy over this rank's output seeds, divided by the GLOBAL
+        batch, the output layer's two addends summed inside), ``backward`` from that gradient, gradient all-reduce, Adam."""
+        g = self.g
+        a, b = pred if isinstance(pred, tuple) else (pred, None)
+        last = blocks[-1]
+        nid = last.dstdata[NID]
+        nid = nid if (nid.dtype == torch.int32 and nid.is_contiguous()) else nid.to(torch.int32).contiguous()
+        lab = g.ndata_owned["labels"]
+        n_rows, n_cls = a.shape
+        n_mine = self.sampler._slot_bufs(slot)["n_local"]                                         # [0]: sampling layer 0 = the output block
+        dx = torch.empty(n_rows, n_cls, dtype=torch.bfloat16, device=a.device)
+        rows = torch.empty(n_rows, dtype=torch.float32, device=a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        ad, bd = a.detach(), (None if b is None else b.detach())
+        _lib.check(_lib.lib.bliss_cross_entropy_masked(ad.data_ptr(), ad.stride(0), 0 if bd is None else bd.data_ptr(),
+                                                       0 if bd is None else bd.stride(0), lab.data_ptr(), lab.numel(), nid.data_ptr(), g.lo,
+                                                       n_rows, n_mine.data_ptr(), float(self.batch * g.world), n_cls, rows.data_ptr(),
+                                                       dx.data_ptr(), dx.stride(0), loss.data_ptr(), self._ce_state.data_ptr(),
+                                                       self._ce_state.data_ptr() + 4, torch.cuda.current_stream().cuda_stream),
+                   "bliss_cross_entropy_masked")
+        self.opt.zero_grad(set_to_none=True)
+        if b is None:
+            a.backward(dx)
+        else:
+            torch.autograd.backward([a, b], [dx, dx])
+        self._allreduce_gradients(1.0, grp)                      # (the gradients carry 1 / global batch already)
+        self.opt.step()
+        _all_reduce(loss, grp)
+        self.loss_dev.copy_(loss)
+        n_par = sum(p.numel() for p in self.model.parameters())
+        self.bytes_per_step = self.sampler.bytes_per_step + self._halo_bytes + 4 * n_par + 4 * self.batch + 96 * 8 * len(blocks) + 4
+        return ad if bd is None else ad + bd
+
     def _loss_backward_step(self, blocks, pred, slot=0):
         """Masked loss over this rank's output seeds, backward, gradient all-reduce, Adam, the global mean loss (the collectives of
         this part go through ``_group_bwd()`` when the loop runs it beside the sampler)."""
         g = self.g
         grp = self._group_bwd() if self._group_bwd() is not None else self.group
+        if isinstance(pred, tuple) or self._fused_loss_ok(pred):
+            return self._fused_loss_backward_step(blocks, pred, slot, grp)
         last = blocks[-1]
         cap_s = last.num_dst_nodes()
         n_mine = self.sampler._slot_bufs(slot)["n_local"][0]                                      # (sampling layer 0 = the output block)
@@ -706,11 +754,13 @@ class StaticShardedTrainStep:
         """Sum the gradients over the ranks and scale by 1 / global batch: ONE flat fp32 bucket (cat, cast, all-reduce, scale,
         cast, one multi-tensor copy back) instead of a cast and a copy per parameter."""
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        if not grads:
+        if not grads or (self.g.world == 1 and scale == 1.0):    # (alone and already scaled: the gradients are final)
             return
         flat = torch.cat([g_.reshape(-1) for g_ in grads]).float()
         _all_reduce(flat, self.group if group is None else group)
-        flat = flat.mul_(scale).to(grads[0].dtype)
+        if scale != 1.0:
+            flat = flat.mul_(scale)
+        flat = flat.to(grads[0].dtype)
         views, off = [], 0
         for g_ in grads:
             n = g_.numel()
@@ -776,7 +826,12 @@ class StaticShardedTrainStep:
         """The step's one synchronisation: true block sizes, error words, the loss."""
         sizes = self.sampler.finish()
         self.sampler.check_errors()
+        self._check_loss_errors()
         return float(self.loss_dev.item()), sizes
+
+    def _check_loss_errors(self):
+        if int(self._ce_state[1].item()):
+            raise RuntimeError("the loss kernel met a label outside [0, n_classes) or a destination id outside this rank's range")
 
     def close(self):
         import gc
@@ -937,6 +992,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         torch.cuda.current_stream().synchronize()
         sizes = self.sampler.finish(self.slot)
         self.sampler.check_errors()
+        self._check_loss_errors()
         if self.graph is not None and self.use_flags and int(self.sampler.ops.eng.flag_err.item()):
             raise RuntimeError("a cross-stream flag never arrived (bliss_flag_wait timed out): the pipelined results are invalid")
         return float(self.loss_dev.item()), sizes

@@ -357,6 +357,15 @@ int bliss_cross_entropy(const void* logits, int64_t stride, const int64_t* label
 int bliss_cross_entropy_sum(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* label_table,
                             const int32_t* label_ids, int32_t n_rows, int32_t n_cls, float* row_loss, void* dlogits, int64_t d_stride,
                             float* loss_out, uint32_t* ticket, int32_t* err, void* stream);
+/* The same for a rank of a sharded step (train_lightning.py:139-142 over destination-range shards): only the first *n_rows_dev of
+ * the n_rows (capacity) rows are this rank's output seeds -- the others get a zero gradient row and no loss --, the labels are
+ * label_table[label_ids[r] - id_off] (global node ids into the owner's table of n_table rows), and the divisor is `denom` (the
+ * GLOBAL batch): *loss_out = sum_r loss_r / denom, so that the ranks' losses and gradients ADD to the global mean.  logits2 may be
+ * NULL. */
+int bliss_cross_entropy_masked(const void* logits, int64_t stride, const void* logits2, int64_t stride2, const int64_t* label_table,
+                               int32_t n_table, const int32_t* label_ids, int32_t id_off, int32_t n_rows, const int32_t* n_rows_dev,
+                               float denom, int32_t n_cls, float* row_loss, void* dlogits, int64_t d_stride, float* loss_out,
+                               uint32_t* ticket, int32_t* err, void* stream);
 
 /* th.optim.Adam(self.parameters(), lr) (train_lightning.py:205-206) for a bf16 module: parameters, gradients and both moment
  * buffers bf16, one launch over all tensors, math in fp32, one rounding per stored value.  state: float[4] on the device --
