@@ -587,7 +587,10 @@ class StaticShardedTrainStep:
                 and tile_gemm_ok(layer._in_src_feats, layer._out_feats) and layer.fc_self.bias is not None and layer.norm is None
                 and layer.activation is None and layer.feat_drop.p == 0)
 
-    def _forward(self, blocks, slot=0):
+    def _forward(self, blocks, slot=0, defer_output=False):
+        """SAGE.forward (model.py:312-333) over this rank's blocks.  ``defer_output``: stop in front of the output layer's compute
+        -- its input rows are in place and their norms stored (all the EXP3 update reads, section 6 item 16) -- and return a
+        pending record for ``_forward_output`` (the loop that runs the output layer on the backward stream)."""
         from .nn import embed_norm
         g, model, grp = self.g, self.model, self.group
         lo, hi = g.lo, g.hi
@@ -620,50 +623,67 @@ class StaticShardedTrainStep:
                     idx = torch.where(self._arange(cap_s) < n_local[L - l], prev.dst_pos.long(), cap_k)
                     h_src = _PlaceAndReduce.apply(h, idx, cap_k, grp, self._group_bwd())
             halo_bytes += cap_k * h_src.shape[1] * h_src.element_size() * (1 if l == 0 else 3)      # (+ the fp32 gradient buffer)
-            split = self._split_layer_ok(layer, h_src)
-            if not split:
-                blk.srcdata["embed_norm"] = embed_norm(h_src)      # model.py:318-320
-            # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
-            # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
-            if split and blk.dst_pos.dtype == torch.int32 and blk.dst_pos.is_contiguous():
-                h_dst = None                                       # (the Linear-first launch gathers its destination rows itself)
-            elif _hip_rows(h_src, blk.dst_pos):
-                h_dst = _TakeRowsHip.apply(h_src, blk.dst_pos, n_local[L - 1 - l: L - l])
-            else:
-                h_dst = _TakeRows.apply(h_src, blk.dst_pos.long())
-            if self._fused_layer_ok(layer, h_src):
-                # an aggregate-first layer's tail on the in-tree MFMA tiles (nn._SageDualLinear: fc_neigh(h_neigh) + fc_self(h_dst) +
-                # bias, ReLU and dropout in ONE launch, its backward on csrc/sage_bwd.hip) -- the true row count from the device
-                from .nn import _SageDualLinear, weighted_aggregate
-                last = l == L - 1
-                p = model.dropout.p if (model.training and not last) else 0.0
-                ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
-                agg = weighted_aggregate(blk, h_src, blk.edata["edge_weights"], mean=True)
-                rows_dev = n_local.data_ptr() + 4 * (L - 1 - l)
-                h, _ = _SageDualLinear.apply(agg, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias, not last, p, ctr, seed,
-                                             blk.num_dst_nodes(), rows_dev)
-            elif split:
-                # a Linear-first layer: fc_neigh over the source rows, fc_self + bias over the destination rows and the source rows'
-                # norms (:318-320, same bits as embed_norm) in ONE launch on the MFMA tiles; then the aggregation; then the sum, ReLU
-                # and dropout (:321-333) in one launch.  True row counts from the device (K of the block, this rank's destinations)
-                from .nn import _SageLinearSplit, sage_epilogue, weighted_aggregate
-                last = l == L - 1
-                p = model.dropout.p if (model.training and not last) else 0.0
-                ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
-                z, y, in_norm = _SageLinearSplit.apply(h_src, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias,
-                                                       blk._counts_dev.data_ptr() + 12, n_local.data_ptr() + 4 * (L - 1 - l),
-                                                       blk.dst_pos if h_dst is None else None)
-                blk.srcdata["embed_norm"] = in_norm
-                agg = weighted_aggregate(blk, z, blk.edata["edge_weights"], mean=True)
-                if last and self._fused_loss_ok(y):
-                    h = (y, agg)                                   # (the loss launch adds them: bliss_cross_entropy_masked)
-                else:
-                    h = (y + agg) if last else sage_epilogue(y, agg, p, ctr, seed)[0]
-            else:
-                h = layer(blk, (h_src, h_dst), edge_weight=blk.edata["edge_weights"])
-                if l < L - 1:
-                    h = model.dropout(model.activation(h))         # :330-332
+            if defer_output and l == L - 1:
+                blk.srcdata["embed_norm"] = embed_norm(h_src)      # model.py:318-320 (a Linear-first launch would leave the same bits)
+                self._halo_bytes = halo_bytes
+                return ("pending", h_src)
+            h = self._layer_compute(l, L, layer, blk, h_src, n_local, True)
         self._halo_bytes = halo_bytes
+        return h
+
+    def _forward_output(self, blocks, pending, slot=0):
+        """The output layer of a ``_forward(..., defer_output=True)``."""
+        L = len(blocks)
+        return self._layer_compute(L - 1, L, self.model.layers[L - 1], blocks[L - 1], pending[1],
+                                   self.sampler._slot_bufs(slot)["n_local"], False)
+
+    def _layer_compute(self, l, L, layer, blk, h_src, n_local, set_norm):
+        from .nn import embed_norm
+        model = self.model
+        split = self._split_layer_ok(layer, h_src)
+        if not split and set_norm:
+            blk.srcdata["embed_norm"] = embed_norm(h_src)      # model.py:318-320
+        # (the padding entries of dst_pos all point at row 0: advanced indexing's backward would sort and serialise them --
+        # 0.94 ms per layer on the Reddit-like step; index_add_ is atomic, and the duplicates carry zero gradients)
+        if split and blk.dst_pos.dtype == torch.int32 and blk.dst_pos.is_contiguous():
+            h_dst = None                                       # (the Linear-first launch gathers its destination rows itself)
+        elif _hip_rows(h_src, blk.dst_pos):
+            h_dst = _TakeRowsHip.apply(h_src, blk.dst_pos, n_local[L - 1 - l: L - l])
+        else:
+            h_dst = _TakeRows.apply(h_src, blk.dst_pos.long())
+        if self._fused_layer_ok(layer, h_src):
+            # an aggregate-first layer's tail on the in-tree MFMA tiles (nn._SageDualLinear: fc_neigh(h_neigh) + fc_self(h_dst) +
+            # bias, ReLU and dropout in ONE launch, its backward on csrc/sage_bwd.hip) -- the true row count from the device
+            from .nn import _SageDualLinear, weighted_aggregate
+            last = l == L - 1
+            p = model.dropout.p if (model.training and not last) else 0.0
+            ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
+            agg = weighted_aggregate(blk, h_src, blk.edata["edge_weights"], mean=True)
+            rows_dev = n_local.data_ptr() + 4 * (L - 1 - l)
+            h, _ = _SageDualLinear.apply(agg, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias, not last, p, ctr, seed,
+                                         blk.num_dst_nodes(), rows_dev)
+        elif split:
+            # a Linear-first layer: fc_neigh over the source rows, fc_self + bias over the destination rows and the source rows'
+            # norms (:318-320, same bits as embed_norm) in ONE launch on the MFMA tiles; then the aggregation; then the sum, ReLU
+            # and dropout (:321-333) in one launch.  True row counts from the device (K of the block, this rank's destinations)
+            from .nn import _SageLinearSplit, sage_epilogue, weighted_aggregate
+            last = l == L - 1
+            p = model.dropout.p if (model.training and not last) else 0.0
+            ctr, seed = model._dropout_state(l, h_src.device) if p > 0 else (None, 0)
+            z, y, in_norm = _SageLinearSplit.apply(h_src, h_dst, layer.fc_neigh.weight, layer.fc_self.weight, layer.fc_self.bias,
+                                                   blk._counts_dev.data_ptr() + 12, n_local.data_ptr() + 4 * (L - 1 - l),
+                                                   blk.dst_pos if h_dst is None else None)
+            if set_norm:
+                blk.srcdata["embed_norm"] = in_norm
+            agg = weighted_aggregate(blk, z, blk.edata["edge_weights"], mean=True)
+            if last and self._fused_loss_ok(y):
+                h = (y, agg)                                   # (the loss launch adds them: bliss_cross_entropy_masked)
+            else:
+                h = (y + agg) if last else sage_epilogue(y, agg, p, ctr, seed)[0]
+        else:
+            h = layer(blk, (h_src, h_dst), edge_weight=blk.edata["edge_weights"])
+            if l < L - 1:
+                h = model.dropout(model.activation(h))         # :330-332
         return h
 
     def _fused_loss_ok(self, logits):
@@ -871,7 +891,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.ev_f, self.ev_b = torch.cuda.Event(), torch.cuda.Event()
         self.g_main, self.g_fx, self.g_s, self.g_b, self.g_blk = [None, None], [None, None], [None, None], [None, None], [None, None]
         self._held = [None, None]
-        self._flags_primed, self.use_flags, self.use_third, self.late_block = False, False, False, False
+        self._flags_primed, self.use_flags, self.use_third, self.late_block, self.split_output = False, False, False, False, False
 
     # ---- the three parts ---------------------------------------------------------------------------------------------------
     def _sample(self, slot):
@@ -927,6 +947,8 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
             _lib.check(_lib.lib.bliss_flag_wait(eng.flags.data_ptr() + 4 * which, eng.flag_err.data_ptr(), st), "bliss_flag_wait")
 
     def _bwd(self, pred, slot):
+        if isinstance(pred, tuple) and len(pred) == 2 and isinstance(pred[0], str):      # (the output layer was left to this stream)
+            pred = self._forward_output(self.blocks2[slot], pred, slot)
         out = self._loss_backward_step(self.blocks2[slot], pred, slot)
         self.last = dict(mfgs=self.blocks2[slot], pred=out, slot=slot)
 
@@ -1044,6 +1066,10 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.late_block = self.use_flags and not self.use_third and os.environ.get("BLISS_SHARD_LATE_BLOCK", "1") != "0"
         L_s = len(self.sampler.nodes_per_layer)
         eng = self.sampler.ops.eng
+        # BLISS_SHARD_SPLIT_OUTPUT (default on): the forward split of the single-GPU loop (section 6 item 16) -- the EXP3 update reads the
+        # blocks' INPUT row norms and nothing the output layer computes, so the critical stream goes from the output layer's input
+        # rows straight to X(t) and S(t+1); the output layer itself runs in front of the loss on the backward stream
+        self.split_output = self.use_flags and L_s > 1 and os.environ.get("BLISS_SHARD_SPLIT_OUTPUT", "1") != "0"
         g_fx = [None, None]
         for s in (0, 1):
             g_b[s] = torch.cuda.CUDAGraph()
@@ -1056,7 +1082,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     blocks = self.blocks2[s]
                     if self.late_block:                          # (consumed by the first aggregation of F: a wait for BLK_DONE)
                         blocks[0]._ready = (eng.flags.data_ptr() + 4 * self.FLAG_BLK_DONE, eng.flag_err.data_ptr())
-                    self._held[s] = self._forward(blocks, s)     # F(t)
+                    self._held[s] = self._forward(blocks, s, defer_output=self.split_output)     # F(t)
                     if self.late_block and getattr(blocks[0], "_ready", None) is not None:
                         raise RuntimeError("late-block mode: the forward pass never waited for the input block")
                     self._flag(self.FLAG_F_DONE, True)
