@@ -317,3 +317,40 @@ def test_row_kernels_place_and_take(cuda):
         assert torch.equal(ha.grad, hb.grad)
     finally:
         dist.destroy_process_group()
+
+
+def test_masked_cross_entropy_kernel(cuda):
+    """bliss_cross_entropy_masked against a plain fp32 torch reference: sum over the first *n rows of CE(bf16(a + b), label) / denom,
+    gradient (softmax - onehot) / denom on those rows (within one bf16 rounding), exactly +0 on the padding rows -- which may
+    carry destination ids outside this rank's range."""
+    from bliss_gnn_amd import _lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    cap, n, C, lo, n_table, denom = 96, 61, 41, 1000, 500, 512.0
+    a = torch.randn(cap, C, generator=gen).to(dev).bfloat16()
+    b = torch.randn(cap, C, generator=gen).to(dev).bfloat16()
+    table = torch.randint(0, C, (n_table,), generator=gen).to(dev)
+    ids = torch.randint(lo, lo + n_table, (cap,), generator=gen).to(torch.int32)
+    ids[n:] = 7                                                   # (padding: another rank's node)
+    ids = ids.to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    state = torch.zeros(2, dtype=torch.int32, device=dev)
+    for second in (b, None):
+        dx = torch.full((cap, C), 9.0, dtype=torch.bfloat16, device=dev)
+        rows = torch.empty(cap, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib.bliss_cross_entropy_masked(a.data_ptr(), a.stride(0), 0 if second is None else second.data_ptr(),
+                                                       0 if second is None else second.stride(0), table.data_ptr(), n_table, ids.data_ptr(), lo,
+                                                       cap, n_dev.data_ptr(), denom, C, rows.data_ptr(), dx.data_ptr(), dx.stride(0),
+                                                       loss.data_ptr(), state.data_ptr(), state.data_ptr() + 4,
+                                                       torch.cuda.current_stream().cuda_stream), "bliss_cross_entropy_masked")
+        torch.cuda.synchronize()
+        x = (a if second is None else (a.float() + second.float()).bfloat16()).float()[:n].requires_grad_(True)
+        y = table[(ids[:n].long() - lo)]
+        ref = torch.nn.functional.cross_entropy(x, y, reduction="sum") / denom
+        ref.backward()
+        assert int(state[1]) == 0 and int(state[0]) == 0
+        assert abs(float(loss) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+        assert not dx[n:].view(torch.int16).any()
+        g, gr = dx[:n].float(), x.grad
+        assert torch.allclose(g, gr, rtol=2.0 ** -7, atol=2.0 ** -7 / denom)
