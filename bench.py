@@ -349,6 +349,8 @@ def main():
         traffic, traffic_src = None, None
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # separate rocprofv3 --pmc passes
+        # (the passes of THIS workload: a GATv2 run's file carries the same sampler kernels, but it is not this command's)
+        pmc_files = [f for f in pmc_files if ("gat" in os.path.basename(f)) == (args.model == "gat")] or pmc_files
         pmc_file = pmc_files[-1] if pmc_files else ""
         if pmc_file:
             raw = json.load(open(pmc_file))
