@@ -152,7 +152,7 @@ class DenseShardedSampler:
                                     rec_host=torch.empty(L, 10, dtype=torch.int32).pin_memory(), nloc_host=torch.empty(L, dtype=torch.int32).pin_memory())
         return b["slots"][slot]
 
-    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None, ready_flag=0, sel_done_flag=0):
+    def enqueue(self, seeds_g, slot=0, part=None, hook=None, defer=(), layers=None, ready_flag=0, sel_done_flag=0, layer_done_flags=0):
         """One sample_blocks (bandit_sampler.py:341-367) for the global seed list, on the current stream, with capacity-padded
         outputs and NO host sync: safe inside HIP-graph capture.  The step number of the keyed draw lives on the device and
         advances by one per call / replay.  Returns this rank's blocks, input-most first; ``finish()`` reads sizes and errors.
@@ -163,7 +163,9 @@ class DenseShardedSampler:
         ``defer``: sampling layers whose block this call does NOT build; ``layers``: the only ones a "build" call builds (the loop
         that leaves the input-most block to the backward stream: PipelinedShardedTrainStep; ``ready_flag``: device flag that
         bliss_build_block raises once the blocks' forward arrays are final, BEFORE it sorts the by-source lists of the backward pass;
-        ``sel_done_flag``: device flag raised by the last layer's bliss_shard_select_kept: all kept lists are final).
+        ``sel_done_flag``: device flag raised by the last layer's bliss_shard_select_kept: all kept lists are final;
+        ``layer_done_flags``: address of L consecutive device flags, flag n raised by layer n's select_kept: its kept list is final.
+        ``ready_flag`` applies to the input-most block only).
         Needs one scratch set per layer: a layer's dense maps live until its block is built."""
         if not self.static:
             raise RuntimeError("enqueue() is the static HIP path; construct the sampler without ops")
@@ -219,7 +221,7 @@ class DenseShardedSampler:
                 chk(lib.bliss_shard_select_kept(b["cand"].data_ptr(), b["p"].data_ptr(), b["is_seed"].data_ptr(), rec_ptr, self.seed, b["step"].data_ptr(),
                                                 n, cur.data_ptr(), n_seeds, n_seeds_dev, b["P"].data_ptr(), kept_nid.data_ptr(), c_ws.node_prob,
                                                 c_ws.kept_map, cap["K"], V, V, cnt_ptr, nloc_ptr, b["scr_a"].data_ptr(), 1 if n == L - 1 else 0,
-                                                int(sel_done_flag) if n == L - 1 else 0, b["err"].data_ptr(), st),
+                                                (int(layer_done_flags) + 4 * n) if layer_done_flags else (int(sel_done_flag) if n == L - 1 else 0), b["err"].data_ptr(), st),
                     "bliss_shard_select_kept")
                 if hook is not None and part == "select":
                     hook(n)
@@ -229,7 +231,7 @@ class DenseShardedSampler:
             if build and n not in defer and (layers is None or n in layers):
                 if hook is not None and part == "build":
                     hook(n)
-                keep_flag, c_ws.block_ready_flag = c_ws.block_ready_flag, (ready_flag or c_ws.block_ready_flag)
+                keep_flag, c_ws.block_ready_flag = c_ws.block_ready_flag, ((ready_flag if n == L - 1 else 0) or c_ws.block_ready_flag)
                 chk(lib.bliss_build_block(C.byref(eng.c_graph), C.byref(eng._set(n)["c_maps"]), w_pos.data_ptr(), seeds_l.data_ptr(), cs, ops.mode,
                                           eta_f, ome_f, eng.Eg, C.byref(c_ws), C.byref(c_out), st), "bliss_build_block")
                 c_ws.block_ready_flag = keep_flag
@@ -892,6 +894,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         self.g_main, self.g_fx, self.g_s, self.g_b, self.g_blk = [None, None], [None, None], [None, None], [None, None], [None, None]
         self._held = [None, None]
         self._flags_primed, self.use_flags, self.use_third, self.late_block, self.split_output = False, False, False, False, False
+        self.late_all = False
 
     # ---- the three parts ---------------------------------------------------------------------------------------------------
     def _sample(self, slot):
@@ -1063,7 +1066,11 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         # the BACKWARD stream, behind B(t) and a "kept lists final" flag, while the main stream already runs the part of F(t+1) that
         # needs only the kept list (feature rows, halo sum, the input layer's two Linears); F's first aggregation waits for the
         # block (nn._wait_block), as in the single-GPU loop.  Two streams, two graphs per step as before
-        self.late_block = self.use_flags and not self.use_third and os.environ.get("BLISS_SHARD_LATE_BLOCK", "1") != "0"
+        self.late_block = self.use_flags and not self.use_third and os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") != "0"
+        # BLISS_SHARD_LATE_BLOCK=2 (default): ALL blocks of batch t+1 go to the backward stream, block n behind "layer n's kept list is
+        # final" (raised by that layer's select launch itself): the backward stream had the room since the loss kernel, and the
+        # critical stream keeps only the candidate chain.  =1: the input-most block only
+        self.late_all = self.late_block and os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") == "2"
         L_s = len(self.sampler.nodes_per_layer)
         eng = self.sampler.ops.eng
         # BLISS_SHARD_SPLIT_OUTPUT (default on): the forward split of the single-GPU loop (section 6 item 16) -- the EXP3 update reads the
@@ -1087,7 +1094,11 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                         raise RuntimeError("late-block mode: the forward pass never waited for the input block")
                     self._flag(self.FLAG_F_DONE, True)
                     self.sampler.exp3(blocks)                    # X(t)
-                    if self.late_block:                          # S(t+1) but for its last block
+                    if self.late_block and self.late_all:        # S(t+1) without its blocks: flag n = "layer n's kept list is final"
+                        self._gather_seeds()
+                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=tuple(range(L_s)),
+                                                                   layer_done_flags=eng.flags.data_ptr())
+                    elif self.late_block:                        # S(t+1) but for its last block
                         self._gather_seeds()
                         self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=(L_s - 1,),
                                                                    sel_done_flag=eng.flags.data_ptr() + 4 * self.FLAG_SEL_DONE)
@@ -1108,7 +1119,10 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     self._flag(self.FLAG_F_DONE, False)
                     self._bwd(self._held[s], s)                  # B(t)
                     self._flag(self.FLAG_B_DONE, True)
-                    if self.late_block:                          # the input-most block of batch t+1
+                    if self.late_block and self.late_all:        # all blocks of batch t+1, each behind its layer's flag
+                        self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", hook=lambda n: self._flag(n, False),
+                                             ready_flag=eng.flags.data_ptr() + 4 * self.FLAG_BLK_DONE)
+                    elif self.late_block:                        # the input-most block of batch t+1
                         self._flag(self.FLAG_SEL_DONE, False)
                         # (BLK_DONE is raised by bliss_build_block itself, in front of the by-source lists only B(t+1) reads -- this stream)
                         self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", layers=(L_s - 1,),
