@@ -1070,7 +1070,8 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         # BLISS_SHARD_LATE_BLOCK=2 (default): ALL blocks of batch t+1 go to the backward stream, block n behind "layer n's kept list is
         # final" (raised by that layer's select launch itself): the backward stream had the room since the loss kernel, and the
         # critical stream keeps only the candidate chain.  =1: the input-most block only
-        self.late_all = self.late_block and os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") == "2"
+        self.late_all = self.late_block and os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") in ("2", "3")
+        late_from = 1 if os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") == "3" else 0          # (=3: the output block stays on the critical stream)
         L_s = len(self.sampler.nodes_per_layer)
         eng = self.sampler.ops.eng
         # BLISS_SHARD_SPLIT_OUTPUT (default on): the forward split of the single-GPU loop (section 6 item 16) -- the EXP3 update reads the
@@ -1096,7 +1097,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     self.sampler.exp3(blocks)                    # X(t)
                     if self.late_block and self.late_all:        # S(t+1) without its blocks: flag n = "layer n's kept list is final"
                         self._gather_seeds()
-                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=tuple(range(L_s)),
+                        self.blocks2[1 - s] = self.sampler.enqueue(self.seeds_g, slot=1 - s, defer=tuple(range(late_from, L_s)),
                                                                    layer_done_flags=eng.flags.data_ptr())
                     elif self.late_block:                        # S(t+1) but for its last block
                         self._gather_seeds()
@@ -1121,7 +1122,7 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
                     self._flag(self.FLAG_B_DONE, True)
                     if self.late_block and self.late_all:        # all blocks of batch t+1, each behind its layer's flag
                         self.sampler.enqueue(self.seeds_g, slot=1 - s, part="build", hook=lambda n: self._flag(n, False),
-                                             ready_flag=eng.flags.data_ptr() + 4 * self.FLAG_BLK_DONE)
+                                             layers=tuple(range(late_from, L_s)), ready_flag=eng.flags.data_ptr() + 4 * self.FLAG_BLK_DONE)
                     elif self.late_block:                        # the input-most block of batch t+1
                         self._flag(self.FLAG_SEL_DONE, False)
                         # (BLK_DONE is raised by bliss_build_block itself, in front of the by-source lists only B(t+1) reads -- this stream)
