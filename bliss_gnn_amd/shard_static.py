@@ -1066,12 +1066,15 @@ class PipelinedShardedTrainStep(StaticShardedTrainStep):
         # the BACKWARD stream, behind B(t) and a "kept lists final" flag, while the main stream already runs the part of F(t+1) that
         # needs only the kept list (feature rows, halo sum, the input layer's two Linears); F's first aggregation waits for the
         # block (nn._wait_block), as in the single-GPU loop.  Two streams, two graphs per step as before
-        self.late_block = self.use_flags and not self.use_third and os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") != "0"
+        # (multi-label runs keep the loss on torch ops: their backward stream is the longer chain already -- Yelp-like 1549 steps/s
+        # with all blocks there against 1613 with the input-most block only -- so they default to 1)
+        late_mode = os.environ.get("BLISS_SHARD_LATE_BLOCK", "1" if self.multilabel else "2")
+        self.late_block = self.use_flags and not self.use_third and late_mode != "0"
         # BLISS_SHARD_LATE_BLOCK=2 (default): ALL blocks of batch t+1 go to the backward stream, block n behind "layer n's kept list is
         # final" (raised by that layer's select launch itself): the backward stream had the room since the loss kernel, and the
         # critical stream keeps only the candidate chain.  =1: the input-most block only
-        self.late_all = self.late_block and os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") in ("2", "3")
-        late_from = 1 if os.environ.get("BLISS_SHARD_LATE_BLOCK", "2") == "3" else 0          # (=3: the output block stays on the critical stream)
+        self.late_all = self.late_block and late_mode in ("2", "3")
+        late_from = 1 if late_mode == "3" else 0                 # (=3: the output block stays on the critical stream)
         L_s = len(self.sampler.nodes_per_layer)
         eng = self.sampler.ops.eng
         # BLISS_SHARD_SPLIT_OUTPUT (default on): the forward split of the single-GPU loop (section 6 item 16) -- the EXP3 update reads the
