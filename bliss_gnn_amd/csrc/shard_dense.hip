@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(256) k_sd_scatter(const int* __restrict__ seed
     if (i < n_local) { v = seeds_l[i]; s = seed_p2[i]; mark = SD_SEED_MARK + 1; }     // a seed is a candidate whatever its sum (shard.py)
     else { v = (int)(tkey[i - n_local] & 0xffffffffull); s = tsum[i - n_local]; mark = 1; }
     if (v < 0 || v >= V) { bad = BLISS_ERR_CAP_CAND; continue; }
-    dense[v] = s;                                       // (one writer per node on a rank: local seeds and touched sources are disjoint)
-    dense[(long long)V + v] = mark;
+    // (one writer per node on a rank: local seeds and touched sources are disjoint.  Sum and mark side by side: ONE 16-byte store,
+    // one line per node -- as two arrays [2, V] the scatter moved 13 MB per launch for 1.6 MB of payload, profiles/r03_z_shards_pmc.json)
+    *reinterpret_cast<longlong2*>(dense + 2ll * v) = make_longlong2(s, mark);
   }
   if (bad && err) atomicOr(err, bad);
 }
@@ -129,14 +130,15 @@ __global__ void __launch_bounds__(SD_TPB) k_sd_cand(long long* __restrict__ dens
   for (int i = threadIdx.x; i <= SD_HWIN_N; i += SD_TPB) lh[i] = 0;
   for (int w = blockIdx.x * SD_TPB + threadIdx.x; w < n_other; w += gridDim.x * SD_TPB) status_other[w] = 0ull;   // (the kept pass's words)
   const int v = blockIdx.x * SD_TPB + threadIdx.x;
-  const long long mark = v < V ? dense[(long long)V + v] : 0;
+  const longlong2 sm = v < V ? *reinterpret_cast<const longlong2*>(dense + 2ll * v) : make_longlong2(0, 0);
+  const long long mark = sm.y;
   int tot, ex = block_excl_scan(mark != 0 ? 1 : 0, sh, &tot);          // (its barriers also cover the zeroing of lh)
   const int base = sd_lookback(status, tot, &sh_prefix, err);
   int bad = 0;
   if (mark != 0) {
     const int at = base + ex;
-    const long long raw = dense[v];
-    dense[v] = 0; dense[(long long)V + v] = 0;          // back to zero for the next scatter (only marked nodes are non-zero)
+    const long long raw = sm.x;
+    *reinterpret_cast<longlong2*>(dense + 2ll * v) = make_longlong2(0, 0);     // back to zero for the next scatter (only marked nodes are non-zero)
     if (at < cap_c) {
       bf16_t pj;
       if (uniform_nodes) pj = raw ? (bf16_t)0x3f80 : (bf16_t)0;                       // bandit_sampler.py:79-81

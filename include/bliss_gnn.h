@@ -247,7 +247,7 @@ int bliss_keyed_select(const int32_t* nid, const void* p_bf16, const uint8_t* is
  *                                 between uses);
  *   bliss_shard_scatter_partials: into a ZERO dense buffer, scatters the per-source partial sums that
  *                                 bliss_frontier_prob(BLISS_MODE_PARTIALS) left (seeds: seed_p2; others: touched_key / touched_sum,
- *                                 their count in *n_touched_dev) into dense[v], with dense[num_nodes + v] = 1 (+ 2^32 for a seed).
+ *                                 their count in *n_touched_dev) into dense[2 v], with dense[2 v + 1] = 1 (+ 2^32 for a seed): sum and mark side by side.
  *                                 The caller all-reduces dense (integer sums: exact for any shard count, any order);
  *   bliss_shard_candidates:       candidates = nodes with a non-zero mark, ascending id: cand_nid, p_j = sqrt(bf16(sum)) (:75); every
  *                                 entry of dense it read goes back to zero (the next bliss_shard_scatter_partials finds it clean);
