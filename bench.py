@@ -533,7 +533,7 @@ def bench_shards(args, ip, ix, ei, feats, labels, train_nid, cfg, hidden, dev, r
             "data": "synthetic",
             "config": {"workload": "%s-like Chung-Lu graph |V|=%d, 3-layer SAGE hidden %d, sharded poisson-bandit (keyed draws) fanouts %s, "
                                    "batch %d per GPU" % (args.config, ip.numel() - 1, hidden, "/".join(map(str, cfg["fanouts"])), cfg["batch"]),
-                       "parallelism": ("destination-range shards x%d (per layer ONE dense int64 [2,|V|] all-reduce; halo rows as capacity-sized "
+                       "parallelism": ("destination-range shards x%d (per layer ONE dense int64 [|V|,2] all-reduce; halo rows as capacity-sized "
                                        "all-reduces; gradient, EXP3 row-sum and loss all-reduces)" % world) if static else
                                       ("destination-range shards x%d (partials all-to-all, histogram all-reduce, kept-list all-gather, halo "
                                        "gathers, gradient all-reduce)" % world),

@@ -7,7 +7,7 @@ all-gather of the kept lists -- three exchanges per sampling layer with data-dep
 
   * one sampling layer = ONE all-reduce of a fixed shape.  Every rank expands the columns of the seeds it owns and reduces
     (q/sum q)^2 by source over its own edges (bandit_sampler.py:67-73: the same kernels, ``BLISS_MODE_PARTIALS``), then scatters
-    these exact Q.44 partial sums into an ``int64 [2, |V|]`` buffer (sum; touch mark, + 2^32 for a seed) which is all-reduced
+    these exact Q.44 partial sums into an ``int64 [|V|, 2]`` buffer (sum and touch mark side by side, + 2^32 for a seed) which is all-reduced
     (1.9 MB on the Reddit-like graph).  Integer sums: the result has the same bits for any number of shards and any reduction
     order.  Every rank then holds every source's sum and derives THE SAME candidate list (ascending node id), importances,
     histogram, Poisson scale (:391-401), keyed draw (:403-406, :422-424) and kept list -- replicated work instead of routed data;
