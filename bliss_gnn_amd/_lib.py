@@ -171,6 +171,7 @@ SIGNATURES = {
     "bliss_graph_prepare": [_P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P, _I64, _P],
     "bliss_exp3_update": [C.POINTER(Graph), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I32, _F, _P, _P, C.c_int, _P, _P],
     "bliss_exp3_step": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
+    "bliss_exp3_normalize_global_rows": [C.POINTER(Exp3Block), _I32, _I64, _P, _I64, _P],
     "bliss_exp3_update_blocks": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P],
     "bliss_exp3_step_deferred": [C.POINTER(Graph), _P, C.POINTER(Exp3Block), _I32, _F, _P, _P, _P],
     "bliss_exp3_normalize_pending": [C.POINTER(Exp3Block), _I32, _I64, _P],

@@ -489,6 +489,13 @@ __global__ void __launch_bounds__(E3_TPB) k_normalize_row(bf16_t* w, int64_t n, 
                                                           const int64_t* norm_src) {
   normalize_row_body(w, n, row_sum, scratch, norm_out, blockIdx.x, gridDim.x, norm_src);
 }
+// the rows of all layers in one launch, each row's norm from its own all-reduced limbs (rows spread over several shards)
+__global__ void __launch_bounds__(E3_TPB) k_normalize_rows_global(const Exp3Multi m, int64_t n, int per_row, const int64_t* __restrict__ limbs,
+                                                                  int64_t limb_stride) {
+  const int r = blockIdx.x / per_row;
+  const bliss_exp3_block_t& k = m.blk[r];
+  normalize_row_body((bf16_t*)k.w_pos, n, k.row_sum, k.scratch, (bf16_t*)k.norm_out, (int)blockIdx.x - r * per_row, per_row, limbs + r * limb_stride);
+}
 // the rows of all layers in one launch: gridDim.x / n_rows workgroups per row
 __global__ void __launch_bounds__(E3_TPB) k_normalize_rows(const Exp3Multi m, int64_t n, int per_row, int mode) {
   const int r = blockIdx.x / per_row;
@@ -704,6 +711,25 @@ int bliss_exp3_normalize_global(void* w_pos, int64_t num_edges, int64_t* row_sum
   if (grid > norm_wgs()) grid = norm_wgs();
   if (grid < 1) grid = 1;
   PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_row<<<(int)grid, E3_TPB, 0, st>>>((bf16_t*)w_pos, num_edges, row_sum, scratch, (bf16_t*)norm_out_bf16, norm_limbs));
+  return (int)hipGetLastError();
+}
+
+int bliss_exp3_normalize_global_rows(const bliss_exp3_block_t* rows, int32_t n_rows, int64_t num_edges, const int64_t* norm_limbs,
+                                     int64_t limb_stride, void* stream) {
+  if (!rows || n_rows <= 0 || n_rows > BLISS_EXP3_MAX_BLOCKS || num_edges <= 0 || !norm_limbs || limb_stride < 3 * ROWSUM_SLOTS) return BLISS_EINVAL;
+  Exp3Multi m;
+  m.n = n_rows;
+  m.done_flag = nullptr;
+  for (int i = 0; i < n_rows; ++i) {
+    if (!rows[i].w_pos || !rows[i].row_sum || !rows[i].scratch) return BLISS_EINVAL;
+    m.blk[i] = rows[i];
+    m.grid_begin[i] = 0;
+  }
+  int64_t per_row = (num_edges + E3_TPB * 8 - 1) / (E3_TPB * 8);
+  if (per_row > norm_wgs()) per_row = norm_wgs();
+  if (per_row < 1) per_row = 1;
+  hipStream_t st = (hipStream_t)stream;
+  PROF_LAUNCH(BK_NORMALIZE, st, k_normalize_rows_global<<<(int)(per_row * n_rows), E3_TPB, 0, st>>>(m, num_edges, (int)per_row, norm_limbs, limb_stride));
   return (int)hipGetLastError();
 }
 

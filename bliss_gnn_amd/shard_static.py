@@ -309,6 +309,14 @@ class DenseShardedSampler:
         L = len(mfgs)
         limbs = _all_reduce(ops.row_sum[:L].clone(), self.group)
         st = torch.cuda.current_stream().cuda_stream
+        if L <= _lib.EXP3_MAX_BLOCKS and limbs.is_contiguous():   # all rows in ONE launch
+            rows = (_lib.Exp3Block * L)()
+            for idx in range(L):
+                rows[idx] = _lib.Exp3Block(ops.w_pos[idx].data_ptr(), ops.row_sum[idx].data_ptr(), ops.scratch[idx].data_ptr(),
+                                           ops.norms[idx:].data_ptr(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+            _lib.check(_lib.lib.bliss_exp3_normalize_global_rows(rows, L, self.g.num_edges(), limbs.data_ptr(), limbs.stride(0), st),
+                       "bliss_exp3_normalize_global_rows")
+            return
         for idx in range(L):
             _lib.check(_lib.lib.bliss_exp3_normalize_global(ops.w_pos[idx].data_ptr(), self.g.num_edges(), ops.row_sum[idx].data_ptr(),
                                                             limbs[idx].data_ptr(), ops.scratch[idx].data_ptr(), ops.norms[idx:].data_ptr(), st),

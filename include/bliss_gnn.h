@@ -479,6 +479,10 @@ int bliss_exp3_step(const bliss_graph_t* g, const void* edge_w_pos, const bliss_
  * spread over several shards, whose norm is the all-reduced sum (bliss_exp3_normalize_global). */
 int bliss_exp3_update_blocks(const bliss_graph_t* g, const void* edge_w_pos, const bliss_exp3_block_t* blocks, int32_t n_blocks,
                              float delta_f, int32_t* err, void* stream);
+/* bliss_exp3_normalize_global for several rows in ONE launch (fields used: w_pos, row_sum, scratch, norm_out); row r's all-reduced
+ * limbs at norm_limbs + r * limb_stride. */
+int bliss_exp3_normalize_global_rows(const bliss_exp3_block_t* rows, int32_t n_rows, int64_t num_edges, const int64_t* norm_limbs,
+                                     int64_t limb_stride, void* stream);
 
 /* The same with F.normalize's pass over the rows taken off the caller's critical path.  The pass (4 bytes of HBM traffic per
  * edge of the graph, whenever the bf16 norm of a row is not exactly 1.0) is the only part of exp3() that scales with |E|, and
