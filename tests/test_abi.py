@@ -48,3 +48,25 @@ def test_flag_spin_bound_setter_is_host_only():
     assert _lib.lib.bliss_flag_set_spin_bound(1 << 27) == 0
     assert _lib.lib.bliss_flag_set_spin_bound(0) == _lib.EINVAL
     assert _lib.lib.bliss_flag_set_spin_bound(1 << 22) == 0     # (the default again)
+
+
+def test_new_entry_points_refuse_bad_arguments_before_any_launch():
+    """The round-3 entry points validate their arguments on the host (no kernel is launched for a refused call, so this runs
+    without a GPU): null pointers, odd row lengths, misaligned scratch, a non-positive divisor."""
+    import ctypes as C
+    from bliss_gnn_amd import _lib
+    lib, E = _lib.lib, _lib.EINVAL
+    buf = (C.c_int64 * 64)()
+    p = C.addressof(buf)
+    assert lib.bliss_shard_place_rows(0, 8, p, p, 4, p, 8, 4, 8, 0) == E                  # no source
+    assert lib.bliss_shard_place_rows(p, 8, p, p, 4, p, 8, 4, 7, 0) == E                  # odd row length
+    assert lib.bliss_shard_take_rows(p, 0, 8, 4, 0, 0, 4, p, 8, 8, 0) == E                # no positions
+    assert lib.bliss_shard_take_rows(p + 4, 1, 8, 4, p, 0, 4, p, 8, 8, 0) == E            # fp32 source not 8-byte aligned
+    assert lib.bliss_shard_pack_rows(p, p, 4, 10, 10, p, 8, 8, p, 8, 0) == E              # empty node range
+    assert lib.bliss_shard_zero_dense(0, 16, 0) == E
+    assert lib.bliss_shard_candidates(p, 16, 0, p, p, p, p, p, 16, p + 4, p, 0) == E      # scratch not 8-byte aligned
+    assert lib.bliss_cross_entropy_masked(p, 8, 0, 0, p, 4, p, 0, 4, p, 0.0, 3, p, p, 8, p, p, p, 0) == E   # divisor 0
+    assert lib.bliss_cross_entropy_masked(p, 8, 0, 0, p, 4, 0, 0, 4, p, 8.0, 3, p, p, 8, p, p, p, 0) == E   # no label ids
+    rows = (_lib.Exp3Block * 1)()
+    assert lib.bliss_exp3_normalize_global_rows(rows, 1, 100, p, 96, 0) == E             # a row without buffers
+    assert lib.bliss_exp3_normalize_global_rows(rows, 0, 100, p, 96, 0) == E
